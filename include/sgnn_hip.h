@@ -1,0 +1,207 @@
+/*
+ * sgnn_hip.h — C ABI of libsgnn_hip.so, the MI355X (gfx950) sparse generative 3D
+ * convolution hot path that sits behind SG-NN's `sparseconvnet` operator surface.
+ *
+ * Boundary being replaced.  The reference (angeladai/sgnn) reaches its sparse-op
+ * arithmetic only through `import sparseconvnet as scn` (torch/model.py:7; call
+ * sites torch/model.py:31-47, 178-188, 253-257, 296, 380).  Upstream's own native
+ * boundary is a pybind11 module (`sparseconvnet.SCN`: class Metadata_3 plus
+ * <Op>_updateOutput / <Op>_backward free functions taking at::Tensor&), i.e. not
+ * a C ABI.  This header is the C ABI that takes its place; each entry point names
+ * the scn operation / reference line it serves.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host";
+ *  - every function is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    performs no allocation and no device synchronisation;
+ *  - the caller owns all memory (features, tables, hash storage, workspaces);
+ *    workspace sizes come from the *_ws_bytes() queries;
+ *  - return value: 0 = SGNN_OK, negative = error; sgnn_last_error() returns a
+ *    thread-local message.  Nothing throws across the ABI;
+ *  - coordinates are int32[4] = {z, y, x, batch} per site (16-byte rows), each
+ *    spatial coordinate in [0, 65535], batch in [0, 32767]
+ *    (layout contract: torch/scene_dataloader.py:13-36);
+ *  - feature matrices are row-major float32 (N, C), contiguous.
+ *  - neighbour / children tables are int32 [K][ld] (offset-major), -1 = no rule.
+ *    A "rulebook" in upstream's sense is { (k, table[k][j], j) : table[k][j] >= 0 }.
+ */
+#ifndef SGNN_HIP_H
+#define SGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGNN_OK 0
+#define SGNN_EINVAL (-1)    /* bad argument */
+#define SGNN_EHIP (-2)      /* HIP runtime / launch failure */
+#define SGNN_EOVERFLOW (-3) /* size exceeds an internal 31-bit index */
+#define SGNN_ENOWS (-4)     /* workspace too small */
+
+/* status bits written (atomically OR-ed) into the device `status` word */
+#define SGNN_STATUS_COORD_RANGE 1 /* a coordinate was outside the supported range */
+#define SGNN_STATUS_DUPLICATE 2   /* InputLayer(mode=0) saw the same site twice */
+
+typedef void *sgnn_stream_t; /* hipStream_t */
+
+const char *sgnn_last_error(void);
+int sgnn_version(void);
+/* name of the gfx target the kernels were compiled for ("gfx950") */
+const char *sgnn_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * Voxel hash grid — scn.InputLayer(3, size, mode=0) (torch/model.py:31,178,185,253)
+ * ------------------------------------------------------------------------- */
+
+/* capacity (power of two, >= 2n, >= 1024) of the open-addressing table for n sites */
+int64_t sgnn_hash_capacity(int64_t n);
+
+/* int64 [z,y,x,b] rows (the reference's LongTensor locs) -> int32 rows; sets
+ * SGNN_STATUS_COORD_RANGE if a value is out of range */
+int sgnn_coords_from_i64(const int64_t *locs, int64_t n, int32_t *coords, int32_t *status,
+                         sgnn_stream_t stream);
+/* and back (metadata.getSpatialLocations, torch/model.py:380) */
+int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, sgnn_stream_t stream);
+
+/* build key->row table: keys[cap] (uint64), vals[cap] (int32).  The function
+ * clears the table itself.  Sets SGNN_STATUS_DUPLICATE on repeated sites. */
+int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
+                    int32_t *status, sgnn_stream_t stream);
+
+/* row of each query site, or -1 (concat_skip join, torch/model.py:338-355) */
+int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *query,
+                     int64_t m, int32_t *rows, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Rulebooks
+ * ------------------------------------------------------------------------- */
+
+/* 3x3x3 submanifold rulebook (scn.SubmanifoldConvolution, torch/model.py:32,38,40,179,186,254):
+ * nbr[k*ld + j] = row of the site at p_j + d_k, k = (dz+1)*9+(dy+1)*3+(dx+1), else -1.
+ * ld >= n. */
+int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
+                        const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
+                        sgnn_stream_t stream);
+
+/* stride-2 / size-2 rulebook, phase 1 (scn.Convolution(...,2,2), torch/model.py:44):
+ * finds the coarse active set unique(floor(p/2)) in FIRST-TOUCH order of the fine
+ * rows (wave ballot + prefix-sum compaction), writes
+ *   parent[i]              coarse row of fine site i
+ *   coarse_coords[c*4..]   coordinates of coarse row c   (room for nf rows)
+ *   ckeys/cvals (ccap)     hash grid of the coarse level (key -> coarse row)
+ *   *n_coarse (device)     number of coarse sites
+ * ccap = sgnn_hash_capacity(nf). */
+int64_t sgnn_down2_ws_bytes(int64_t nf);
+int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint64_t *ckeys, int32_t *cvals,
+                        int64_t ccap, int32_t *parent, int32_t *coarse_coords, int64_t *n_coarse,
+                        void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+/* phase 2, once the host knows n_coarse: offset-major tables
+ *   children[k*ldc + c] = fine row whose parent is c and whose offset
+ *                         (z&1)*4+(y&1)*2+(x&1) is k, else -1        (8 x ldc)
+ *   ptable[k*ldf + i]   = parent[i] if offset(i)==k else -1          (8 x ldf)
+ * children drives the forward conv / unpool-backward, ptable the data-gradient. */
+int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t nf,
+                      int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
+                      sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Sparse convolution: out[j] = sum_k W[k]^T x[table[k][j]]   (fp32 MFMA 16x16x4)
+ * serves SubmanifoldConvolution fwd (table = nbr, K = 27), Convolution(2,2) fwd
+ * (table = children, K = 8) and both data-gradients:
+ *   subm  dX: x := dY, table = nbr,    flags = TRANSPOSE_W | FLIP_K
+ *   down2 dX: x := dY, table = ptable, flags = TRANSPOSE_W
+ * w is always the layer's weight (K, c_in_layer, c_out_layer); with TRANSPOSE_W the
+ * call's cin/cout are (c_out_layer, c_in_layer).
+ * in_shift: feature row = table value >> in_shift (3 = features live on the
+ * parents of an 8-child expansion, torch/model.py:192-207; 0 otherwise).
+ * ------------------------------------------------------------------------- */
+#define SGNN_CONV_TRANSPOSE_W 1
+#define SGNN_CONV_FLIP_K 2
+int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                  int64_t n_out, int cout, float *y, int flags, int in_shift,
+                  sgnn_stream_t stream);
+
+/* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic
+ * two-stage reduction through the workspace. */
+int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin, int cout);
+int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, int cout, const int32_t *table,
+                         int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
+                         int64_t ws_bytes, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * scn.BatchNormReLU / BatchNormalization (torch/model.py:37,39,42,45,181,187,256)
+ * leak: 0 = ReLU, 1 = plain batch norm.  momentum = fraction of OLD running value kept.
+ * training: batch statistics (biased var to normalise, unbiased into running_var),
+ * save_mean/save_invstd (C floats each) kept for backward.
+ * ------------------------------------------------------------------------- */
+int64_t sgnn_bn_ws_bytes(int64_t n, int c);
+int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                float *running_mean, float *running_var, float eps, float momentum, int training,
+                float leak, float *save_mean, float *save_invstd, float *y, void *ws,
+                int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, const float *gamma,
+                const float *beta, const float *save_mean, const float *save_invstd, int training,
+                float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
+                sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Row movement (all pure copies / sums, fp32 rows of c floats)
+ * ------------------------------------------------------------------------- */
+/* dst[r] = src[idx[r]]  (UnPooling fwd: idx = parent; mask compaction: idx = sel) */
+int sgnn_gather_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
+                     sgnn_stream_t stream);
+/* dst (n_dst rows, zero-filled here) ; dst[idx[r]] = src[r]   (idx unique) */
+int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
+                      int64_t n_dst, sgnn_stream_t stream);
+/* dst[j] = sum_k src[table[k*ld+j]] over valid entries (UnPooling bwd: table = children) */
+int sgnn_gather_sum(const float *src, int c, const int32_t *table, int64_t ld, int K,
+                    int64_t n_out, float *dst, sgnn_stream_t stream);
+/* dst[r*rep + t] = src[r]  (to_next_level_locs feature replication, torch/model.py:203) */
+int sgnn_repeat_rows(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream);
+/* dst[r] = sum_t src[r*rep + t]  (its gradient) */
+int sgnn_sum_groups(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream);
+/* dst[r] = [ a[ia ? ia[r] : r] | (ib ? (ib[r] >= 0 ? b[ib[r]] : 0) : b[r]) ]
+ * serves JoinTable (ia = ib = NULL), concat_skip (ib = hash_lookup rows, torch/model.py:354)
+ * and the fused mask-compaction concat (ia = ib = sel, torch/model.py:242,330) */
+int sgnn_concat_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb,
+                     const int32_t *ib, int64_t m, float *dst, sgnn_stream_t stream);
+/* gradient of sgnn_concat_rows: da (na rows) / db (nb rows) are zero-filled here when the
+ * matching index is given; indices are unique so no atomics are needed.  da or db may be NULL. */
+int sgnn_concat_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib,
+                         int64_t m, float *da, int64_t na, float *db, int64_t nb,
+                         sgnn_stream_t stream);
+/* y = a + b  (scn.AddTable) */
+int sgnn_add(const float *a, const float *b, int64_t count, float *y, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Generative glue
+ * ------------------------------------------------------------------------- */
+/* children coords: out[(8i+j)] = {2z+dz, 2y+dy, 2x+dx, b}, j = 4dz+2dy+dx
+ * (Refinement.to_next_level_locs, torch/model.py:192-207) */
+int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, sgnn_stream_t stream);
+/* all voxel coordinates of a dense (B, d0, d1, d2) volume, batch-major raster order
+ * (GenModel.dense_coarse_to_sparse, torch/model.py:319-321) */
+int sgnn_dense_coords(int batch, int d0, int d1, int d2, int32_t *out, sgnn_stream_t stream);
+/* stable compaction: sel[0..count) = ascending rows i with sigmoid(logits[i*stride]) > 0.5
+ * (torch/model.py:233,322); wave ballot + prefix sum.  *count is a device int64. */
+int64_t sgnn_compact_ws_bytes(int64_t n);
+int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_t n, int32_t *sel,
+                         int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+/* same for an explicit uint8 mask */
+int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, int64_t *count, void *ws,
+                      int64_t ws_bytes, sgnn_stream_t stream);
+
+/* scn.SparseToDense (torch/model.py:47): dense (B, C, d0, d1, d2) zero-filled here */
+int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, int c, float *dense,
+                         int batch, int d0, int d1, int d2, sgnn_stream_t stream);
+/* feats[r][ch] = dense[b][ch][z][y][x] at coords[r]  (its gradient, and the NCDHW -> rows
+ * permute of dense_coarse_to_sparse, torch/model.py:324-327) */
+int sgnn_dense_to_sparse(const float *dense, const int32_t *coords, int64_t n, int c, float *feats,
+                         int batch, int d0, int d1, int d2, sgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGNN_HIP_H */

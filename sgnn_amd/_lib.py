@@ -1,0 +1,103 @@
+"""ctypes binding of libsgnn_hip.so (C ABI declared in include/sgnn_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no MI355X is
+visible, every operator raises.  PyTorch is used only for device memory, streams and autograd
+bookkeeping; no torch type crosses the ABI (raw device pointers + sizes + the HIP stream).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsgnn_hip.so')
+
+c_i32, c_i64, c_f32, c_vp, c_cp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
+
+# name -> (restype, argtypes); mirrors include/sgnn_hip.h one to one
+PROTOTYPES = {
+    'sgnn_last_error': (c_cp, []),
+    'sgnn_version': (c_i32, []),
+    'sgnn_arch': (c_cp, []),
+    'sgnn_hash_capacity': (c_i64, [c_i64]),
+    'sgnn_coords_from_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_coords_to_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
+    'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_conv_fwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
+    'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),
+    'sgnn_bn_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_bn_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_gather_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_scatter_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_gather_sum': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),
+    'sgnn_repeat_rows': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    'sgnn_sum_groups': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    'sgnn_concat_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_concat_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_add': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_expand8_coords': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_dense_coords': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'sgnn_compact_ws_bytes': (c_i64, [c_i64]),
+    'sgnn_compact_sigmoid': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_compact_mask': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_sparse_to_dense': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'sgnn_dense_to_sparse': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+class SgnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise SgnnError('libsgnn_hip.so not found at %s — run `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback for the sparse operators)' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise SgnnError('sgnn_amd needs a visible MI355X (torch.cuda.is_available() is False); '
+                        'the HIP operators have no CPU fallback')
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current torch stream; raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise SgnnError('%s failed (%d): %s' % (name, rc, lib.sgnn_last_error().decode()))
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a (contiguous) tensor, or NULL for None."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,339 @@
+// scn.BatchNormReLU / BatchNormalization over the N active rows (torch/model.py:37,39,42,45,
+// 181,187,256 and the FullyConvolutionalNet bodies).
+//
+// HBM-bound row passes over a row-major (N, C) slab:
+//   stats  : one read  — per-thread fp32 partial sums over a short run of rows, flushed into
+//            fp64 accumulators (keeps E[x^2]-E[x]^2 exact to fp32 resolution), workgroup
+//            tree in LDS, per-workgroup partials reduced in fixed order (deterministic);
+//   apply  : one read + one write, float4 when C % 4 == 0;
+//   bwd    : reduce pass (dy, x read) + apply pass (dy, x read, dx written).
+// Thread mapping keeps a thread on a fixed channel group: blockDim = RPB rows x CQ column
+// groups, CQ = C/VEC, so per-channel constants live in registers.
+#include "common.h"
+
+#define BN_MAX_BLOCKS 1024
+#define BN_FLUSH 16
+
+struct BnGeom {
+  int vec;   // 4 or 1 floats per thread-column
+  int cq;    // column groups per row
+  int rpb;   // rows per block iteration
+};
+
+static BnGeom bn_geom(int c) {
+  BnGeom g;
+  g.vec = (c % 4 == 0) ? 4 : 1;
+  g.cq = c / g.vec;
+  g.rpb = 256 / g.cq;
+  if (g.rpb < 1) g.rpb = 1;
+  return g;
+}
+
+static int bn_blocks(int64_t n, const BnGeom &g) {
+  int64_t b = (n + (int64_t)g.rpb * BN_FLUSH - 1) / ((int64_t)g.rpb * BN_FLUSH);
+  if (b < 1) b = 1;
+  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  return (int)b;
+}
+
+SGNN_EXPORT int64_t sgnn_bn_ws_bytes(int64_t n, int c) {
+  (void)n;
+  return (int64_t)BN_MAX_BLOCKS * 2 * c * (int64_t)sizeof(double) + 4 * (int64_t)c * sizeof(float) + 256;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// partial[blk][0][c] = sum_a, partial[blk][1][c] = sum_b over this block's rows where
+//   MODE 0 (forward stats):  a = x,            b = x*x
+//   MODE 1 (backward):       a = dz,           b = dz * xhat      (dz = dy masked by the ReLU/leak)
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, const float *__restrict__ dy,
+                                                   int64_t n, int c, int cq, int rpb,
+                                                   const float *__restrict__ mean,
+                                                   const float *__restrict__ invstd,
+                                                   const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float leak,
+                                                   double *__restrict__ partial) {
+  extern __shared__ double sh[];  // [rpb][2][c] would be large; reduce per column group instead
+  const int tid = threadIdx.x;
+  const int col = tid % cq, rloc = tid / cq;
+  const bool active = rloc < rpb;
+  double sa[VEC], sb[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) sa[v] = sb[v] = 0.0;
+  float m_[VEC], is_[VEC], g_[VEC], b_[VEC];
+  if (MODE == 1 && active) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      m_[v] = mean[col * VEC + v];
+      is_[v] = invstd[col * VEC + v];
+      g_[v] = gamma ? gamma[col * VEC + v] : 1.f;
+      b_[v] = beta ? beta[col * VEC + v] : 0.f;
+    }
+  }
+  if (active) {
+    const int64_t step = (int64_t)gridDim.x * rpb;
+    int64_t row = (int64_t)blockIdx.x * rpb + rloc;
+    while (row < n) {
+      float fa[VEC], fb[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) fa[v] = fb[v] = 0.f;
+#pragma unroll 4
+      for (int it = 0; it < BN_FLUSH && row < n; ++it, row += step) {
+        float xv[VEC];
+        load_vec<VEC>(x + row * c + col * VEC, xv);
+        if (MODE == 0) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            fa[v] += xv[v];
+            fb[v] = fmaf(xv[v], xv[v], fb[v]);
+          }
+        } else {
+          float dv[VEC];
+          load_vec<VEC>(dy + row * c + col * VEC, dv);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xh = (xv[v] - m_[v]) * is_[v];
+            const float yv = fmaf(xh, g_[v], b_[v]);
+            const float dz = yv > 0.f ? dv[v] : dv[v] * leak;
+            fa[v] += dz;
+            fb[v] = fmaf(dz, xh, fb[v]);
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        sa[v] += (double)fa[v];
+        sb[v] += (double)fb[v];
+      }
+    }
+  }
+  // reduce over the rpb row-threads of each column group: sh[rloc][col][2*VEC]
+  double *mine = sh + ((size_t)rloc * cq + col) * 2 * VEC;
+  if (active) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      mine[v] = sa[v];
+      mine[VEC + v] = sb[v];
+    }
+  }
+  __syncthreads();
+  // threads [0, cq*VEC*2) each own one output scalar and sum over rpb rows in order
+  const int outs = cq * VEC * 2;
+  for (int o = tid; o < outs; o += 256) {
+    const int which = o / (cq * VEC);            // 0: a, 1: b
+    const int ch = o % (cq * VEC);
+    const int cg = ch / VEC, v = ch % VEC;
+    double s = 0.0;
+    for (int rr = 0; rr < rpb; ++rr) s += sh[((size_t)rr * cq + cg) * 2 * VEC + which * VEC + v];
+    partial[((size_t)blockIdx.x * 2 + which) * c + ch] = s;
+  }
+}
+
+// one workgroup: fixed-order sum of block partials, then the per-channel statistics
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const double *__restrict__ partial, int nblk,
+                                                        int64_t n, int c, float eps, float momentum,
+                                                        float *__restrict__ running_mean,
+                                                        float *__restrict__ running_var,
+                                                        float *__restrict__ save_mean,
+                                                        float *__restrict__ save_invstd) {
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s += partial[((size_t)b * 2 + 0) * c + ch];
+      s2 += partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    const double mean = s / (double)n;
+    double var = s2 / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[ch] = momentum * running_mean[ch] + (1.f - momentum) * (float)mean;
+    if (running_var) {
+      const double unb = var * ((double)n / (double)(n > 1 ? n - 1 : 1));
+      running_var[ch] = momentum * running_var[ch] + (1.f - momentum) * (float)unb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__ running_mean,
+                                                      const float *__restrict__ running_var, int c, float eps,
+                                                      float *__restrict__ save_mean,
+                                                      float *__restrict__ save_invstd) {
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    save_mean[ch] = running_mean[ch];
+    save_invstd[ch] = 1.0f / sqrtf(running_var[ch] + eps);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t n, int c, int cq,
+                                                 const float *__restrict__ mean,
+                                                 const float *__restrict__ invstd,
+                                                 const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, float leak,
+                                                 float *__restrict__ y) {
+  // flat element-group index; channel group = g % cq
+  const int64_t groups = n * cq;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
+    const int col = (int)(g % cq);
+    float xv[VEC], yv[VEC];
+    load_vec<VEC>(x + g * VEC, xv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int ch = col * VEC + v;
+      const float xh = (xv[v] - mean[ch]) * invstd[ch];
+      const float t = fmaf(xh, gamma ? gamma[ch] : 1.f, beta ? beta[ch] : 0.f);
+      yv[v] = t > 0.f ? t : t * leak;
+    }
+    store_vec<VEC>(y + g * VEC, yv);
+  }
+}
+
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); also dgamma/dbeta
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restrict__ partial, int nblk,
+                                                        int64_t n, int c, float *__restrict__ dgamma,
+                                                        float *__restrict__ dbeta, float *__restrict__ coef) {
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s += partial[((size_t)b * 2 + 0) * c + ch];
+      s2 += partial[((size_t)b * 2 + 1) * c + ch];
+    }
+    if (dbeta) dbeta[ch] = (float)s;
+    if (dgamma) dgamma[ch] = (float)s2;
+    coef[ch] = (float)(s / (double)n);
+    coef[c + ch] = (float)(s2 / (double)n);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ dy,
+                                                     int64_t n, int c, int cq, const float *__restrict__ mean,
+                                                     const float *__restrict__ invstd,
+                                                     const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float leak, int training,
+                                                     const float *__restrict__ coef, float *__restrict__ dx) {
+  const int64_t groups = n * cq;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
+    const int col = (int)(g % cq);
+    float xv[VEC], dv[VEC], ov[VEC];
+    load_vec<VEC>(x + g * VEC, xv);
+    load_vec<VEC>(dy + g * VEC, dv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int ch = col * VEC + v;
+      const float gm = gamma ? gamma[ch] : 1.f;
+      const float xh = (xv[v] - mean[ch]) * invstd[ch];
+      const float t = fmaf(xh, gm, beta ? beta[ch] : 0.f);
+      const float dz = t > 0.f ? dv[v] : dv[v] * leak;
+      float d = dz;
+      if (training) d = dz - coef[ch] - xh * coef[c + ch];
+      ov[v] = d * gm * invstd[ch];
+    }
+    store_vec<VEC>(dx + g * VEC, ov);
+  }
+}
+
+SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                            float *running_mean, float *running_var, float eps, float momentum, int training,
+                            float leak, float *save_mean, float *save_invstd, float *y, void *ws,
+                            int64_t ws_bytes, sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && c <= 1024 && save_mean && save_invstd);
+  SGNN_CHECK_ARG(training || (running_mean && running_var));
+  const BnGeom g = bn_geom(c);
+  if (training && n > 0) {
+    SGNN_CHECK_ARG(x);
+    if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
+      sgnn_set_error("sgnn_bn_fwd: workspace too small");
+      return SGNN_ENOWS;
+    }
+    const int nblk = bn_blocks(n, g);
+    const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
+    if (g.vec == 4)
+      hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
+                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+    else
+      hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
+                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd);
+  } else if (training) {  // empty batch: identity statistics, nothing to normalise
+    SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
+    SGNN_HIP_TRY(hipMemsetAsync(save_invstd, 0, c * sizeof(float), s));
+  } else {
+    hipLaunchKernelGGL(k_bn_eval_stats, dim3(1), dim3(256), 0, s, (const float *)running_mean,
+                       (const float *)running_var, c, eps, save_mean, save_invstd);
+  }
+  if (n > 0) {
+    SGNN_CHECK_ARG(x && y);
+    const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
+    if (g.vec == 4)
+      hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
+                         (const float *)save_invstd, gamma, beta, leak, y);
+    else
+      hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
+                         (const float *)save_invstd, gamma, beta, leak, y);
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, const float *gamma,
+                            const float *beta, const float *save_mean, const float *save_invstd, int training,
+                            float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
+                            sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && c <= 1024 && save_mean && save_invstd);
+  if (n == 0) {
+    if (dgamma) SGNN_HIP_TRY(hipMemsetAsync(dgamma, 0, c * sizeof(float), s));
+    if (dbeta) SGNN_HIP_TRY(hipMemsetAsync(dbeta, 0, c * sizeof(float), s));
+    return SGNN_OK;
+  }
+  SGNN_CHECK_ARG(x && dy && dx);
+  if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
+    sgnn_set_error("sgnn_bn_bwd: workspace too small");
+    return SGNN_ENOWS;
+  }
+  const BnGeom g = bn_geom(c);
+  const int nblk = bn_blocks(n, g);
+  const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
+  double *partial = (double *)ws;
+  float *coef = (float *)((char *)ws + (size_t)BN_MAX_BLOCKS * 2 * c * sizeof(double));
+  if (g.vec == 4)
+    hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, partial);
+  else
+    hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, partial);
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
+                     coef);
+  const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
+  if (g.vec == 4)
+    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
+                       gamma, beta, leak, training, (const float *)coef, dx);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
+                       gamma, beta, leak, training, (const float *)coef, dx);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}

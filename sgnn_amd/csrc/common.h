@@ -1,0 +1,93 @@
+// Shared device/host helpers for libsgnn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sgnn_hip.h"
+
+#define SGNN_EXPORT extern "C" __attribute__((visibility("default")))
+
+void sgnn_set_error(const char *fmt, ...);
+
+#define SGNN_CHECK_ARG(cond)                                                    \
+  do {                                                                          \
+    if (!(cond)) {                                                              \
+      sgnn_set_error("%s: invalid argument: %s", __func__, #cond);              \
+      return SGNN_EINVAL;                                                       \
+    }                                                                           \
+  } while (0)
+
+#define SGNN_CHECK_LAUNCH()                                                     \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      sgnn_set_error("%s: HIP error: %s", __func__, hipGetErrorString(e_));     \
+      return SGNN_EHIP;                                                         \
+    }                                                                           \
+  } while (0)
+
+#define SGNN_HIP_TRY(expr)                                                      \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      sgnn_set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(e_)); \
+      return SGNN_EHIP;                                                         \
+    }                                                                           \
+  } while (0)
+
+static inline int sgnn_grid_for(int64_t work, int block, int cap = 1 << 20) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// voxel keys / hash
+// ---------------------------------------------------------------------------
+#define SGNN_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint64_t sgnn_pack_key(int z, int y, int x, int b) {
+  return ((uint64_t)(uint32_t)b << 48) | ((uint64_t)(uint32_t)z << 32) | ((uint64_t)(uint32_t)y << 16) |
+         (uint64_t)(uint32_t)x;
+}
+
+__device__ __forceinline__ uint64_t sgnn_hash64(uint64_t k) {
+  // murmur3 finaliser: spreads raster-adjacent keys over the table
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+__device__ __forceinline__ int32_t sgnn_hash_find(const uint64_t *__restrict__ keys,
+                                                  const int32_t *__restrict__ vals, uint64_t mask,
+                                                  uint64_t key) {
+  uint64_t slot = sgnn_hash64(key) & mask;
+  while (true) {
+    uint64_t k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == SGNN_EMPTY_KEY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// wave64 / block prefix sums over a 0/1 flag (ballot + popcount)
+// ---------------------------------------------------------------------------
+// Exclusive rank of `flag` among the 256 threads of the block and the block total.
+// `lds4` = 4 ints of shared memory.  Contains two barriers.
+__device__ __forceinline__ int sgnn_block_rank256(bool flag, int *lds4, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long bal = __ballot(flag);
+  int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) lds4[wave] = __popcll(bal);
+  __syncthreads();
+  int w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
+  __syncthreads();
+  int base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+  total = w0 + w1 + w2 + w3;
+  return base + prefix;
+}

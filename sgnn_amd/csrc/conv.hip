@@ -1,0 +1,385 @@
+// Sparse convolution on gfx950: output-stationary gather -> fp32 MFMA -> store.
+//
+// Serves scn.SubmanifoldConvolution (27 offsets) and scn.Convolution(...,2,2) (8 offsets)
+// forward and both gradients (reference call sites torch/model.py:32,38,40,44,179,186,254 and
+// the FullyConvolutionalNet bodies at :180,255).
+//
+// Design (MI355X-first, not upstream's per-offset gather/GEMM/scatter-add):
+//  * the rulebook is an offset-major neighbour table table[k][j] (int32, -1 = no rule), so a
+//    wave reads 64 consecutive rule entries of one offset as one coalesced 256-B run;
+//  * each wave owns 16*MREP output rows and walks all K offsets keeping the 16x16 output tiles
+//    in MFMA accumulators — no atomics, no scatter, deterministic summation order;
+//  * the active-site feature slab is row-major; lane (r = lane&15, q = lane>>4) fetches the
+//    q-th quarter of input row table[k][row r] with the widest aligned load, so the four lanes
+//    of a row cover one contiguous feature row;
+//  * the per-offset contraction is v_mfma_f32_16x16x4_f32: step s contracts the channel set
+//    {q*V+s | q=0..3}; the weight slice W[k] is staged in LDS transposed ([n][c]) so the B
+//    fragment of lane (n, q) is the same V contiguous floats;
+//  * weights are staged KC offsets at a time to keep LDS <= 32 KiB (>= 4 workgroups per CU).
+// Exact fp32 (MFMA f32 == fmaf chain), required for the 1e-4 logit tolerance.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CONV_MREP 4
+#define CONV_ROWS_PER_WAVE (16 * CONV_MREP)
+#define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)
+
+template <int CIN, int COUT>
+struct ConvCfg {
+  static constexpr int V = (CIN + 3) / 4;    // channels per lane quarter
+  static constexpr int CINP = 4 * V;         // padded input channels
+  static constexpr int NT = (COUT + 15) / 16;  // 16-wide output column tiles
+  static constexpr int PER_K = NT * 16 * CINP;  // LDS floats per offset
+  static constexpr int KC_RAW = 8192 / PER_K;   // <= 32 KiB of LDS
+  static constexpr int KC = KC_RAW < 1 ? 1 : (KC_RAW > 27 ? 27 : KC_RAW);
+  // widest load that is aligned for every (row, q)
+  static constexpr int ALIGN = ((CIN % 4 == 0) && (V % 4 == 0)) ? 16 : (((CIN % 2 == 0) && (V % 2 == 0)) ? 8 : 4);
+};
+
+template <int CIN, int V, int ALIGN>
+__device__ __forceinline__ void load_quarter(const float *__restrict__ x, int64_t row, int q, float (&a)[V]) {
+  const float *p = x + row * CIN + q * V;
+  if constexpr (ALIGN == 16) {
+#pragma unroll
+    for (int t = 0; t < V / 4; ++t) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[t];
+      a[4 * t + 0] = v.x;
+      a[4 * t + 1] = v.y;
+      a[4 * t + 2] = v.z;
+      a[4 * t + 3] = v.w;
+    }
+  } else if constexpr (ALIGN == 8) {
+#pragma unroll
+    for (int t = 0; t < V / 2; ++t) {
+      float2 v = make_float2(0.f, 0.f);
+      if (q * V + 2 * t < CIN) v = reinterpret_cast<const float2 *>(p)[t];
+      a[2 * t + 0] = v.x;
+      a[2 * t + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < V; ++s) a[s] = (q * V + s < CIN) ? p[s] : 0.f;
+  }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, const float *__restrict__ w,
+                                                 const int32_t *__restrict__ table, int64_t ld, int K,
+                                                 int64_t n_out, float *__restrict__ y, int flags,
+                                                 int in_shift) {
+  using C = ConvCfg<CIN, COUT>;
+  constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
+  __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * CONV_ROWS_PER_WAVE;
+  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
+
+  f32x4 acc[CONV_MREP][NT];
+#pragma unroll
+  for (int m = 0; m < CONV_MREP; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = (K - k0) < KC ? (K - k0) : KC;
+    __syncthreads();
+    for (int e = tid; e < kc * C::PER_K; e += 256) {
+      const int c = e % CINP;
+      const int n = (e / CINP) % (NT * 16);
+      const int kk = e / C::PER_K;
+      float v = 0.f;
+      if (c < CIN && n < COUT) {
+        const int ks = flip ? (K - 1 - (k0 + kk)) : (k0 + kk);
+        v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
+      }
+      wl[e] = v;
+    }
+    __syncthreads();
+
+    for (int kk = 0; kk < kc; ++kk) {
+      const int32_t *trow = table + (int64_t)(k0 + kk) * ld;
+      int32_t idx[CONV_MREP];
+      bool anyv = false;
+#pragma unroll
+      for (int m = 0; m < CONV_MREP; ++m) {
+        const int64_t row = row0 + m * 16 + r;
+        idx[m] = (row < n_out) ? trow[row] : -1;
+        anyv |= idx[m] >= 0;
+      }
+      if (!__any(anyv)) continue;  // wave-uniform: no rule of this offset in these 64 rows
+
+      float a[CONV_MREP][V];
+#pragma unroll
+      for (int m = 0; m < CONV_MREP; ++m) {
+        if (idx[m] >= 0) {
+          load_quarter<CIN, V, C::ALIGN>(x, (int64_t)(idx[m] >> in_shift), q, a[m]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < V; ++s) a[m][s] = 0.f;
+        }
+      }
+      float b[NT][V];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
+#pragma unroll
+        for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
+      }
+#pragma unroll
+      for (int s = 0; s < V; ++s)
+#pragma unroll
+        for (int m = 0; m < CONV_MREP; ++m)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
+    }
+  }
+
+  // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int m = 0; m < CONV_MREP; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + m * 16 + q * 4 + i;
+        if (row < n_out && col < COUT) y[row * COUT + col] = acc[m][nt][i];
+      }
+    }
+}
+
+// any (cin, cout): one thread per output element, plain FMA.  Correctness fallback for layer
+// widths outside the SG-NN set; not a performance path.
+__global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restrict__ x, int cin,
+                                                         const float *__restrict__ w, int K,
+                                                         const int32_t *__restrict__ table, int64_t ld,
+                                                         int64_t n_out, int cout, float *__restrict__ y,
+                                                         int flags, int in_shift) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out * cout) return;
+  const int64_t row = t / cout;
+  const int n = (int)(t - row * cout);
+  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int32_t idx = table[(int64_t)k * ld + row];
+    if (idx < 0) continue;
+    const float *xr = x + (int64_t)(idx >> in_shift) * cin;
+    const int ks = flip ? (K - 1 - k) : k;
+    for (int c = 0; c < cin; ++c) {
+      const float wv = transpose ? w[((int64_t)ks * cout + n) * cin + c] : w[((int64_t)ks * cin + c) * cout + n];
+      acc = fmaf(xr[c], wv, acc);
+    }
+  }
+  y[t] = acc;
+}
+
+#define CONV_FWD_CASES(X) \
+  X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
+  X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4)
+
+SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                              int64_t n_out, int cout, float *y, int flags, int in_shift,
+                              sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 27 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
+                 in_shift < 31);
+  if (n_out == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(x && w && table && y);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
+  bool done = false;
+#define X(CI, CO)                                                                                       \
+  if (!done && cin == CI && cout == CO) {                                                               \
+    hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, w, table, ld, K, n_out, y, \
+                       flags, in_shift);                                                                \
+    done = true;                                                                                        \
+  }
+  CONV_FWD_CASES(X)
+#undef X
+  if (!done) {
+    const int64_t total = n_out * cout;
+    hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
+                       table, ld, n_out, cout, y, flags, in_shift);
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]
+// MFMA with the site index on the contraction axis (4 rows per instruction):
+//   A[i=ci][kslot=q] = x[table[k][R+q]][ci],  B[kslot=q][j=co] = dy[R+q][co]
+// grid = (row blocks, offset groups of DW_KPB); every wave keeps DW_KPB*MT*NT accumulators.
+// Workgroup partials go to the workspace and are summed in fixed order by k_dw_reduce
+// (deterministic, no float atomics).
+// ---------------------------------------------------------------------------
+#define DW_KPB 9
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, const float *__restrict__ dy,
+                                                const int32_t *__restrict__ table, int64_t ld, int K,
+                                                int64_t n_out, float *__restrict__ partial,
+                                                int64_t rows_per_block, int in_shift) {
+  constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
+  __shared__ float red[DW_KPB * MT * 16 * NT * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.y * DW_KPB;
+  const int kc = (K - k0) < DW_KPB ? (K - k0) : DW_KPB;
+  const int64_t blk_row0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t blk_row1 = blk_row0 + rows_per_block;
+  if (blk_row1 > n_out) blk_row1 = n_out;
+
+  f32x4 acc[DW_KPB][MT][NT];
+#pragma unroll
+  for (int kk = 0; kk < DW_KPB; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[kk][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t base = blk_row0 + wave * 64; base < blk_row1; base += 256) {
+    int32_t idxv[DW_KPB];
+#pragma unroll
+    for (int kk = 0; kk < DW_KPB; ++kk) {
+      const int64_t row = base + lane;
+      idxv[kk] = (kk < kc && row < blk_row1) ? table[(int64_t)(k0 + kk) * ld + row] : -1;
+    }
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const int64_t R = base + 4 * t + q;
+      float b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + i16;
+        b[nt] = (R < blk_row1 && co < COUT) ? dy[R * COUT + co] : 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < DW_KPB; ++kk) {
+        const int32_t id = __shfl(idxv[kk], 4 * t + q);
+        float a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int ci = mt * 16 + i16;
+          a[mt] = (id >= 0 && ci < CIN) ? x[(int64_t)(id >> in_shift) * CIN + ci] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[kk][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[kk][mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // combine the four waves in fixed order through LDS
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int kk = 0; kk < DW_KPB; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ci = mt * 16 + q * 4 + i, co = nt * 16 + i16;
+              float *p = &red[(kk * MT * 16 + ci) * NT * 16 + co];
+              if (wv == 0)
+                *p = acc[kk][mt][nt][i];
+              else
+                *p += acc[kk][mt][nt][i];
+            }
+    }
+    __syncthreads();
+  }
+  float *out = partial + ((int64_t)blockIdx.x * K + k0) * CIN * COUT;
+  for (int e = tid; e < kc * CIN * COUT; e += 256) {
+    const int co = e % COUT, ci = (e / COUT) % CIN, kk = e / (CIN * COUT);
+    out[e] = red[(kk * MT * 16 + ci) * NT * 16 + co];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ partial, int64_t nblk,
+                                                  int64_t elems, float *__restrict__ dw) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < nblk; ++b) s += partial[b * elems + e];
+  dw[e] = s;
+}
+
+// generic fallback: one workgroup per (k, ci, co) triple would be wasteful; instead one thread per
+// weight element loops over all rows (slow, correctness only)
+__global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict__ x, int cin,
+                                                        const float *__restrict__ dy, int cout,
+                                                        const int32_t *__restrict__ table, int64_t ld, int K,
+                                                        int64_t n_out, float *__restrict__ dw, int in_shift) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)K * cin * cout) return;
+  const int co = (int)(e % cout), ci = (int)((e / cout) % cin), k = (int)(e / ((int64_t)cin * cout));
+  float s = 0.f;
+  for (int64_t j = 0; j < n_out; ++j) {
+    const int32_t id = table[(int64_t)k * ld + j];
+    if (id >= 0) s = fmaf(x[(int64_t)(id >> in_shift) * cin + ci], dy[j * cout + co], s);
+  }
+  dw[e] = s;
+}
+
+static int64_t dw_rows_per_block(int64_t n_out) {
+  int64_t rpb = (n_out + 255) / 256;           // <= 256 row blocks
+  rpb = ((rpb + 255) / 256) * 256;             // whole 256-row wave rounds
+  if (rpb < 256) rpb = 256;
+  return rpb;
+}
+
+SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin, int cout) {
+  if (n_out <= 0) return 0;
+  const int64_t rpb = dw_rows_per_block(n_out);
+  const int64_t nblk = (n_out + rpb - 1) / rpb;
+  return nblk * (int64_t)K * cin * cout * (int64_t)sizeof(float);
+}
+
+#define CONV_DW_CASES(X) \
+  X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16)
+
+SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, int cout, const int32_t *table,
+                                     int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
+                                     int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 27 && n_out >= 0 && ld >= n_out && dw &&
+                 in_shift >= 0 && in_shift < 31);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t elems = (int64_t)K * cin * cout;
+  if (n_out == 0) {
+    SGNN_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), s));
+    return SGNN_OK;
+  }
+  SGNN_CHECK_ARG(x && dy && table);
+  bool done = false;
+  const int64_t rpb = dw_rows_per_block(n_out);
+  const int64_t nblk = (n_out + rpb - 1) / rpb;
+#define X(CI, CO)                                                                                          \
+  if (!done && cin == CI && cout == CO) {                                                                  \
+    if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, K, cin, cout)) {                            \
+      sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
+      return SGNN_ENOWS;                                                                                   \
+    }                                                                                                      \
+    hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + DW_KPB - 1) / DW_KPB)),   \
+                       dim3(256), 0, s, x, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);           \
+    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,                \
+                       (const float *)ws, nblk, elems, dw);                                                \
+    done = true;                                                                                           \
+  }
+  CONV_DW_CASES(X)
+#undef X
+  if (!done) {
+    hipLaunchKernelGGL(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
+                       cout, table, ld, K, n_out, dw, in_shift);
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}

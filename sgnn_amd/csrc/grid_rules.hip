@@ -1,0 +1,523 @@
+// Voxel hash grid, rulebook construction and stable compaction for gfx950.
+//
+// Replaces the host-side hash maps / rulebook builders of the sparse-op library the
+// reference imports (torch/model.py:7).
+// Everything here is integer work bounded by HBM / L2 latency: one thread per site,
+// coalesced offset-major table writes, 64-bit keys in an open-addressing table that
+// stays L2/MALL resident, wave64 ballot + popcount prefix sums for the compactions.
+#include <stdarg.h>
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing (shared by all translation units)
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void sgnn_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+SGNN_EXPORT const char *sgnn_last_error(void) { return g_err; }
+SGNN_EXPORT int sgnn_version(void) { return 100; }
+SGNN_EXPORT const char *sgnn_arch(void) { return "gfx950"; }
+
+SGNN_EXPORT int64_t sgnn_hash_capacity(int64_t n) {
+  int64_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+// ---------------------------------------------------------------------------
+// coordinate conversion
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coords_from_i64(const int64_t *__restrict__ locs, int64_t n,
+                                                        int4 *__restrict__ coords, int32_t *status) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  bool bad = false;
+  for (; i < n; i += stride) {
+    const longlong2 a = reinterpret_cast<const longlong2 *>(locs)[2 * i];
+    const longlong2 b = reinterpret_cast<const longlong2 *>(locs)[2 * i + 1];
+    bad |= (a.x < 0 || a.x > 65535 || a.y < 0 || a.y > 65535 || b.x < 0 || b.x > 65535 || b.y < 0 ||
+            b.y > 32767);
+    coords[i] = make_int4((int)a.x, (int)a.y, (int)b.x, (int)b.y);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, SGNN_STATUS_COORD_RANGE);
+}
+
+__global__ __launch_bounds__(256) void k_coords_to_i64(const int4 *__restrict__ coords, int64_t n,
+                                                      int64_t *__restrict__ locs) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    const int4 c = coords[i];
+    reinterpret_cast<longlong2 *>(locs)[2 * i] = make_longlong2(c.x, c.y);
+    reinterpret_cast<longlong2 *>(locs)[2 * i + 1] = make_longlong2(c.z, c.w);
+  }
+}
+
+SGNN_EXPORT int sgnn_coords_from_i64(const int64_t *locs, int64_t n, int32_t *coords, int32_t *status,
+                                     sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && status != nullptr);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(locs && coords);
+  hipLaunchKernelGGL(k_coords_from_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, locs, n, (int4 *)coords, status);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(locs && coords);
+  hipLaunchKernelGGL(k_coords_to_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, (const int4 *)coords, n, locs);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// hash build / lookup
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hash_build(const int4 *__restrict__ coords, int64_t n,
+                                                   unsigned long long *__restrict__ keys,
+                                                   int32_t *__restrict__ vals, uint64_t mask,
+                                                   int32_t *status) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    const int4 c = coords[i];
+    const uint64_t key = sgnn_pack_key(c.x, c.y, c.z, c.w);
+    uint64_t slot = sgnn_hash64(key) & mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&keys[slot], SGNN_EMPTY_KEY, (unsigned long long)key);
+      if (prev == SGNN_EMPTY_KEY) {
+        vals[slot] = (int32_t)i;
+        break;
+      }
+      if (prev == key) {
+        atomicOr(status, SGNN_STATUS_DUPLICATE);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+
+SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals,
+                                int64_t cap, int32_t *status, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && keys && vals && status);
+  SGNN_CHECK_ARG(cap >= 2 * n && cap >= 2 && (cap & (cap - 1)) == 0);
+  if (n >= (1ll << 31)) {
+    sgnn_set_error("sgnn_hash_build: %lld sites exceed the 31-bit row index", (long long)n);
+    return SGNN_EOVERFLOW;
+  }
+  SGNN_HIP_TRY(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint64_t), (hipStream_t)stream));
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords);
+  hipLaunchKernelGGL(k_hash_build, dim3(sgnn_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const int4 *)coords, n, (unsigned long long *)keys, vals, (uint64_t)(cap - 1),
+                     status);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_hash_lookup(const uint64_t *__restrict__ keys,
+                                                    const int32_t *__restrict__ vals, uint64_t mask,
+                                                    const int4 *__restrict__ query, int64_t m,
+                                                    int32_t *__restrict__ rows) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < m; i += stride) {
+    const int4 c = query[i];
+    const bool ok = ((unsigned)c.x <= 65535u) && ((unsigned)c.y <= 65535u) && ((unsigned)c.z <= 65535u) &&
+                    ((unsigned)c.w <= 32767u);
+    rows[i] = ok ? sgnn_hash_find(keys, vals, mask, sgnn_pack_key(c.x, c.y, c.z, c.w)) : -1;
+  }
+}
+
+SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap,
+                                 const int32_t *query, int64_t m, int32_t *rows, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(m >= 0 && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(query && rows);
+  hipLaunchKernelGGL(k_hash_lookup, dim3(sgnn_grid_for(m, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     keys, vals, (uint64_t)(cap - 1), (const int4 *)query, m, rows);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 3x3x3 submanifold rulebook: nbr[k][j].  One thread per site, 26 probes; every
+// per-offset store is a coalesced 256-B run across the wave.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restrict__ keys,
+                                                       const int32_t *__restrict__ vals, uint64_t mask,
+                                                       const int4 *__restrict__ coords, int64_t n,
+                                                       int32_t *__restrict__ nbr, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int4 c = coords[j];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+    int32_t r;
+    if (k == 13) {
+      r = (int32_t)j;
+    } else {
+      const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
+      const bool ok = ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
+      r = ok ? sgnn_hash_find(keys, vals, mask, sgnn_pack_key(z, y, x, c.w)) : -1;
+    }
+    nbr[(int64_t)k * ld + j] = r;
+  }
+}
+
+SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
+                                    const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
+                                    sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords && nbr);
+  hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stable compaction machinery: count -> scan of block sums -> write
+// ---------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK (256 * SCAN_ITEMS)
+
+struct FlagSigmoid {
+  const float *logits;
+  int64_t stride;
+  __device__ __forceinline__ bool operator()(int64_t i) const {
+    // identical predicate to the reference's `nn.Sigmoid()(out) > 0.5` (torch/model.py:233,322)
+    const float x = logits[i * stride];
+    return (1.0f / (1.0f + expf(-x))) > 0.5f;
+  }
+};
+struct FlagMask {
+  const uint8_t *mask;
+  __device__ __forceinline__ bool operator()(int64_t i) const { return mask[i] != 0; }
+};
+struct FlagOwner {  // fine site i owns its parent iff it is the smallest row that touched it
+  const int32_t *slot_of;
+  const int32_t *cvals;
+  __device__ __forceinline__ bool operator()(int64_t i) const { return cvals[slot_of[i]] == (int32_t)i; }
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void k_scan_count(F flag, int64_t n, int32_t *__restrict__ block_sums) {
+  __shared__ int lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool f = (i < n) && flag(i);
+    cnt += __popcll(__ballot(f));
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// single workgroup: exclusive scan of block_sums in place, total -> *count
+__global__ __launch_bounds__(1024) void k_scan_block_sums(int32_t *__restrict__ block_sums, int64_t nblk,
+                                                         int64_t *__restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblk; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = (i < nblk) ? block_sums[i] : 0;
+    // wave inclusive scan
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(s, d);
+      if (lane >= d) s += t;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += wsum[w];
+    const int carry = carry_s;
+    if (i < nblk) block_sums[i] = carry + woff + s - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = (int64_t)carry_s;
+}
+
+template <class F, class Emit>
+__global__ __launch_bounds__(256) void k_scan_emit(F flag, Emit emit, int64_t n,
+                                                  const int32_t *__restrict__ block_offsets) {
+  __shared__ int lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+  int running = block_offsets[blockIdx.x];
+#pragma unroll 1
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool f = (i < n) && flag(i);
+    int total;
+    const int r = sgnn_block_rank256(f, lds, total);
+    if (f) emit(i, running + r);
+    running += total;
+  }
+}
+
+struct EmitSel {
+  int32_t *sel;
+  __device__ __forceinline__ void operator()(int64_t i, int rank) const { sel[rank] = (int32_t)i; }
+};
+
+SGNN_EXPORT int64_t sgnn_compact_ws_bytes(int64_t n) {
+  const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  return (nblk + 1) * (int64_t)sizeof(int32_t) + 64;
+}
+
+template <class F>
+static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes,
+                        hipStream_t s) {
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), s);
+    if (e != hipSuccess) {
+      sgnn_set_error("compact: memset failed: %s", hipGetErrorString(e));
+      return SGNN_EHIP;
+    }
+    return SGNN_OK;
+  }
+  if (ws_bytes < sgnn_compact_ws_bytes(n) || !ws) {
+    sgnn_set_error("compact: workspace too small (%lld < %lld)", (long long)ws_bytes,
+                   (long long)sgnn_compact_ws_bytes(n));
+    return SGNN_ENOWS;
+  }
+  const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  int32_t *block_sums = (int32_t *)ws;
+  hipLaunchKernelGGL((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count);
+  hipLaunchKernelGGL((k_scan_emit<F, EmitSel>), dim3((unsigned)nblk), dim3(256), 0, s, flag, EmitSel{sel}, n,
+                     (const int32_t *)block_sums);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    sgnn_set_error("compact: HIP error: %s", hipGetErrorString(e));
+    return SGNN_EHIP;
+  }
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_t n, int32_t *sel,
+                                     int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count && stride >= 1 && n < (1ll << 31));
+  SGNN_CHECK_ARG(n == 0 || (logits && sel));
+  return compact_impl(FlagSigmoid{logits, stride}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+}
+
+SGNN_EXPORT int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, int64_t *count, void *ws,
+                                  int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count && n < (1ll << 31));
+  SGNN_CHECK_ARG(n == 0 || (mask && sel));
+  return compact_impl(FlagMask{mask}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// stride-2 rulebook
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_down2_insert(const int4 *__restrict__ fine, int64_t nf,
+                                                     unsigned long long *__restrict__ ckeys,
+                                                     int32_t *__restrict__ cvals, uint64_t mask,
+                                                     int32_t *__restrict__ slot_of) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) {
+    const int4 c = fine[i];
+    const uint64_t key = sgnn_pack_key(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+    uint64_t slot = sgnn_hash64(key) & mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&ckeys[slot], SGNN_EMPTY_KEY, (unsigned long long)key);
+      if (prev == SGNN_EMPTY_KEY || prev == key) break;
+      slot = (slot + 1) & mask;
+    }
+    atomicMin(&cvals[slot], (int32_t)i);  // first-touch owner = smallest fine row
+    slot_of[i] = (int32_t)slot;
+  }
+}
+
+struct EmitOwner {  // owner i gets coarse row `rank`
+  const int4 *fine;
+  int4 *coarse;
+  int32_t *rank_at;
+  __device__ __forceinline__ void operator()(int64_t i, int rank) const {
+    const int4 c = fine[i];
+    coarse[rank] = make_int4(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+    rank_at[i] = rank;
+  }
+};
+
+__global__ __launch_bounds__(256) void k_down2_parent(int64_t nf, const int32_t *__restrict__ cvals,
+                                                     const int32_t *__restrict__ rank_at,
+                                                     const int32_t *__restrict__ slot_of,
+                                                     int32_t *__restrict__ parent) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) parent[i] = rank_at[cvals[slot_of[i]]];
+}
+
+// after every parent[] is known: turn the coarse table's values from "owner fine row"
+// into "coarse row" so it is an ordinary grid hash for the next level
+__global__ __launch_bounds__(256) void k_down2_fix_vals(int64_t nf, const int32_t *__restrict__ slot_of,
+                                                       const int32_t *__restrict__ parent,
+                                                       const int32_t *__restrict__ rank_at,
+                                                       int32_t *__restrict__ cvals) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) {
+    // exactly one fine row per coarse site is its owner: cvals[slot] == i before this kernel.
+    // Owners are identified through rank_at (written only for owners, -1 elsewhere).
+    if (rank_at[i] >= 0) cvals[slot_of[i]] = parent[i];
+  }
+}
+
+SGNN_EXPORT int64_t sgnn_down2_ws_bytes(int64_t nf) {
+  const int64_t nblk = (nf + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  // slot_of[nf] + rank_at[nf] + block sums
+  return 2 * nf * (int64_t)sizeof(int32_t) + (nblk + 1) * (int64_t)sizeof(int32_t) + 256;
+}
+
+SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint64_t *ckeys, int32_t *cvals,
+                                    int64_t ccap, int32_t *parent, int32_t *coarse_coords,
+                                    int64_t *n_coarse, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(nf >= 0 && n_coarse && ckeys && cvals);
+  SGNN_CHECK_ARG(ccap >= 2 * nf && ccap >= 2 && (ccap & (ccap - 1)) == 0 && ccap < (1ll << 31));
+  SGNN_HIP_TRY(hipMemsetAsync(ckeys, 0xFF, (size_t)ccap * sizeof(uint64_t), s));
+  if (nf == 0) {
+    SGNN_HIP_TRY(hipMemsetAsync(n_coarse, 0, sizeof(int64_t), s));
+    return SGNN_OK;
+  }
+  SGNN_CHECK_ARG(fine_coords && parent && coarse_coords);
+  if (!ws || ws_bytes < sgnn_down2_ws_bytes(nf)) {
+    sgnn_set_error("sgnn_rulebook_down2: workspace too small");
+    return SGNN_ENOWS;
+  }
+  const int64_t nblk = (nf + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  int32_t *slot_of = (int32_t *)ws;
+  int32_t *rank_at = slot_of + nf;
+  int32_t *block_sums = rank_at + nf;
+  // cvals := INT_MAX (0x7F7F7F7F is large enough: > any 31-bit row < 2^31-1? use explicit fill)
+  SGNN_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cvals, 0x7FFFFFFF, (size_t)ccap, s));
+  SGNN_HIP_TRY(hipMemsetAsync(rank_at, 0xFF, (size_t)nf * sizeof(int32_t), s));
+  const int g = sgnn_grid_for(nf, 256, 8192);
+  hipLaunchKernelGGL(k_down2_insert, dim3(g), dim3(256), 0, s, (const int4 *)fine_coords, nf,
+                     (unsigned long long *)ckeys, cvals, (uint64_t)(ccap - 1), slot_of);
+  FlagOwner flag{slot_of, cvals};
+  hipLaunchKernelGGL((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse);
+  hipLaunchKernelGGL((k_scan_emit<FlagOwner, EmitOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag,
+                     EmitOwner{(const int4 *)fine_coords, (int4 *)coarse_coords, rank_at}, nf,
+                     (const int32_t *)block_sums);
+  hipLaunchKernelGGL(k_down2_parent, dim3(g), dim3(256), 0, s, nf, (const int32_t *)cvals,
+                     (const int32_t *)rank_at, (const int32_t *)slot_of, parent);
+  hipLaunchKernelGGL(k_down2_fix_vals, dim3(g), dim3(256), 0, s, nf, (const int32_t *)slot_of,
+                     (const int32_t *)parent, (const int32_t *)rank_at, cvals);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ fine,
+                                                     const int32_t *__restrict__ parent, int64_t nf,
+                                                     int32_t *__restrict__ children, int64_t ldc,
+                                                     int32_t *__restrict__ ptable, int64_t ldf) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) {
+    const int4 c = fine[i];
+    const int off = ((c.x & 1) << 2) | ((c.y & 1) << 1) | (c.z & 1);
+    const int32_t p = parent[i];
+    children[(int64_t)off * ldc + p] = (int32_t)i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = (k == off) ? p : -1;
+  }
+}
+
+SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t nf,
+                                  int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
+                                  sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(nf >= 0 && nc >= 0 && ldc >= nc && ldf >= nf);
+  if (nc > 0) {
+    SGNN_CHECK_ARG(children);
+    SGNN_HIP_TRY(hipMemsetAsync(children, 0xFF, (size_t)(8 * ldc) * sizeof(int32_t), s));
+  }
+  if (nf == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(fine_coords && parent && ptable && children);
+  hipLaunchKernelGGL(k_down2_tables, dim3(sgnn_grid_for(nf, 256, 8192)), dim3(256), 0, s,
+                     (const int4 *)fine_coords, parent, nf, children, ldc, ptable, ldf);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generative glue: 8-child expansion, dense coordinate table
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand8(const int4 *__restrict__ coords, int64_t n,
+                                                int4 *__restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per child
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; t < 8 * n; t += stride) {
+    const int4 c = coords[t >> 3];
+    const int j = (int)(t & 7);
+    out[t] = make_int4(2 * c.x + (j >> 2), 2 * c.y + ((j >> 1) & 1), 2 * c.z + (j & 1), c.w);
+  }
+}
+
+SGNN_EXPORT int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords && out);
+  hipLaunchKernelGGL(k_expand8, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const int4 *)coords, n, (int4 *)out);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_dense_coords(int batch, int d0, int d1, int d2,
+                                                     int4 *__restrict__ out) {
+  const int64_t vol = (int64_t)d0 * d1 * d2, total = vol * batch;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; t < total; t += stride) {
+    const int b = (int)(t / vol);
+    int64_t v = t - (int64_t)b * vol;
+    const int x = (int)(v % d2);
+    v /= d2;
+    const int y = (int)(v % d1);
+    const int z = (int)(v / d1);
+    out[t] = make_int4(z, y, x, b);
+  }
+}
+
+SGNN_EXPORT int sgnn_dense_coords(int batch, int d0, int d1, int d2, int32_t *out, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
+  const int64_t total = (int64_t)batch * d0 * d1 * d2;
+  if (total == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(out);
+  hipLaunchKernelGGL(k_dense_coords, dim3(sgnn_grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     batch, d0, d1, d2, (int4 *)out);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}

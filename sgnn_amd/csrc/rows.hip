@@ -1,0 +1,330 @@
+// Row movement kernels (pure HBM-bound copies / short sums over fp32 feature rows).
+//
+// Serve scn.UnPooling, scn.JoinTable / AddTable, scn.SparseToDense, scn.OutputLayer-side
+// compactions and the generative glue of torch/model.py:192-207 (8-child replication),
+// :229-247 and :315-336 (mask compaction + concat) and :338-355 (skip join)
+// (SURVEY.md §8 rows a5, a7, a8, a11-a14).  One thread per 4-byte or 16-byte element of the
+// DESTINATION so that every store is coalesced; gathers read whole contiguous rows.
+#include "common.h"
+
+// vector width (floats) usable for rows of c floats
+static inline int row_vec(int c) { return (c % 4 == 0) ? 4 : 1; }
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> { typedef float4 T; };
+template <>
+struct VecT<1> { typedef float T; };
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::T vzero();
+template <>
+__device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <>
+__device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+
+#define ROWS_LAUNCH(KERNEL, c, total_groups, stream, ...)                                              \
+  do {                                                                                                 \
+    const int grid_ = sgnn_grid_for((total_groups), 256, 4096);                                        \
+    if (row_vec(c) == 4)                                                                               \
+      hipLaunchKernelGGL((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+    else                                                                                               \
+      hipLaunchKernelGGL((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+  } while (0)
+
+// dst[r] = src[idx[r]]  (idx < 0 -> zeros)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ src, int cq,
+                                                    const int32_t *__restrict__ idx, int64_t m,
+                                                    float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = m * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    const int32_t i = idx[r];
+    reinterpret_cast<T *>(dst)[g] = (i >= 0) ? reinterpret_cast<const T *>(src)[(int64_t)i * cq + col] : vzero<VEC>();
+  }
+}
+
+SGNN_EXPORT int sgnn_gather_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
+                                 sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && m >= 0);
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && idx && dst);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_gather_rows, c, m * cq, stream, src, cq, idx, m, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// dst[idx[r]] = src[r]
+template <int VEC>
+__global__ __launch_bounds__(256) void k_scatter_rows(const float *__restrict__ src, int cq,
+                                                     const int32_t *__restrict__ idx, int64_t m,
+                                                     float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = m * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    const int32_t i = idx[r];
+    if (i >= 0) reinterpret_cast<T *>(dst)[(int64_t)i * cq + col] = reinterpret_cast<const T *>(src)[g];
+  }
+}
+
+SGNN_EXPORT int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
+                                  int64_t n_dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && m >= 0 && n_dst >= 0);
+  if (n_dst > 0) {
+    SGNN_CHECK_ARG(dst);
+    SGNN_HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n_dst * c * sizeof(float), (hipStream_t)stream));
+  }
+  if (m == 0 || n_dst == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && idx);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_scatter_rows, c, m * cq, stream, src, cq, idx, m, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// dst[j] = sum_k src[table[k][j]]
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_sum(const float *__restrict__ src, int cq,
+                                                   const int32_t *__restrict__ table, int64_t ld, int K,
+                                                   int64_t n_out, float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = n_out * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    T acc = vzero<VEC>();
+    for (int k = 0; k < K; ++k) {
+      const int32_t i = table[(int64_t)k * ld + r];
+      if (i >= 0) acc = vadd(acc, reinterpret_cast<const T *>(src)[(int64_t)i * cq + col]);
+    }
+    reinterpret_cast<T *>(dst)[g] = acc;
+  }
+}
+
+SGNN_EXPORT int sgnn_gather_sum(const float *src, int c, const int32_t *table, int64_t ld, int K,
+                                int64_t n_out, float *dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && n_out >= 0 && K >= 1 && ld >= n_out);
+  if (n_out == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && table && dst);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_gather_sum, c, n_out * cq, stream, src, cq, table, ld, K, n_out, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_repeat_rows(const float *__restrict__ src, int cq, int64_t n, int rep,
+                                                    float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = n * rep * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    reinterpret_cast<T *>(dst)[g] = reinterpret_cast<const T *>(src)[(r / rep) * cq + col];
+  }
+}
+
+SGNN_EXPORT int sgnn_repeat_rows(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && n >= 0 && rep >= 1);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && dst);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_repeat_rows, c, n * rep * cq, stream, src, cq, n, rep, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_sum_groups(const float *__restrict__ src, int cq, int64_t n, int rep,
+                                                   float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = n * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    T acc = vzero<VEC>();
+    for (int t = 0; t < rep; ++t) acc = vadd(acc, reinterpret_cast<const T *>(src)[(r * rep + t) * cq + col]);
+    reinterpret_cast<T *>(dst)[g] = acc;
+  }
+}
+
+SGNN_EXPORT int sgnn_sum_groups(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && n >= 0 && rep >= 1);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && dst);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_sum_groups, c, n * cq, stream, src, cq, n, rep, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// dst[r] = [a[ia?ia[r]:r] | b[ib?ib[r]:r] (0 if ib[r] < 0)]   — scalar elements (ca, cb arbitrary)
+__global__ __launch_bounds__(256) void k_concat_rows(const float *__restrict__ a, int ca,
+                                                    const int32_t *__restrict__ ia,
+                                                    const float *__restrict__ b, int cb,
+                                                    const int32_t *__restrict__ ib, int64_t m,
+                                                    float *__restrict__ dst) {
+  const int c = ca + cb;
+  const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / c;
+    const int col = (int)(g - r * c);
+    float v = 0.f;
+    if (col < ca) {
+      const int64_t i = ia ? (int64_t)ia[r] : r;
+      if (i >= 0) v = a[i * ca + col];
+    } else {
+      const int64_t i = ib ? (int64_t)ib[r] : r;
+      if (i >= 0) v = b[i * cb + (col - ca)];
+    }
+    dst[g] = v;
+  }
+}
+
+SGNN_EXPORT int sgnn_concat_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb,
+                                 const int32_t *ib, int64_t m, float *dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0);
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b));
+  hipLaunchKernelGGL(k_concat_rows, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, a, ca, ia, b, cb, ib, m, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_concat_rows_bwd(const float *__restrict__ ddst, int ca,
+                                                        const int32_t *__restrict__ ia, int cb,
+                                                        const int32_t *__restrict__ ib, int64_t m,
+                                                        float *__restrict__ da, float *__restrict__ db) {
+  const int c = ca + cb;
+  const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / c;
+    const int col = (int)(g - r * c);
+    const float v = ddst[g];
+    if (col < ca) {
+      if (da) {
+        const int64_t i = ia ? (int64_t)ia[r] : r;
+        if (i >= 0) da[i * ca + col] = v;
+      }
+    } else if (db) {
+      const int64_t i = ib ? (int64_t)ib[r] : r;
+      if (i >= 0) db[i * cb + (col - ca)] = v;
+    }
+  }
+}
+
+SGNN_EXPORT int sgnn_concat_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib,
+                                     int64_t m, float *da, int64_t na, float *db, int64_t nb,
+                                     sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0 && na >= 0 && nb >= 0);
+  if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
+  if (db && ib && nb > 0 && cb > 0) SGNN_HIP_TRY(hipMemsetAsync(db, 0, (size_t)nb * cb * sizeof(float), s));
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(ddst);
+  SGNN_CHECK_ARG(ia || !da || na >= m);
+  SGNN_CHECK_ARG(ib || !db || nb >= m);
+  hipLaunchKernelGGL(k_concat_rows_bwd, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0, s, ddst, ca,
+                     ia, cb, ib, m, da, db);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const float *__restrict__ b,
+                                            int64_t count, float *__restrict__ y) {
+  const int64_t n4 = count / 4, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n4; g += stride) {
+    const float4 u = reinterpret_cast<const float4 *>(a)[g], v = reinterpret_cast<const float4 *>(b)[g];
+    reinterpret_cast<float4 *>(y)[g] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = n4 * 4 + threadIdx.x;
+    if (t < count) y[t] = a[t] + b[t];
+  }
+}
+
+SGNN_EXPORT int sgnn_add(const float *a, const float *b, int64_t count, float *y, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(count >= 0);
+  if (count == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(a && b && y);
+  hipLaunchKernelGGL(k_add, dim3(sgnn_grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     count, y);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// dense (B, C, d0, d1, d2) <-> rows.  Thread per (row, channel); channel-major over the row
+// index so that consecutive lanes touch consecutive x of the same channel plane when the sites
+// are raster ordered.
+__global__ __launch_bounds__(256) void k_sparse_to_dense(const float *__restrict__ feats,
+                                                        const int4 *__restrict__ coords, int64_t n, int c,
+                                                        float *__restrict__ dense, int batch, int d0, int d1,
+                                                        int d2) {
+  const int64_t total = n * c, stride = (int64_t)gridDim.x * 256;
+  const int64_t vol = (int64_t)d0 * d1 * d2;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int ch = (int)(g / n);
+    const int64_t r = g - (int64_t)ch * n;
+    const int4 p = coords[r];
+    if ((unsigned)p.x < (unsigned)d0 && (unsigned)p.y < (unsigned)d1 && (unsigned)p.z < (unsigned)d2 &&
+        (unsigned)p.w < (unsigned)batch)
+      dense[((int64_t)p.w * c + ch) * vol + ((int64_t)p.x * d1 + p.y) * d2 + p.z] = feats[r * c + ch];
+  }
+}
+
+SGNN_EXPORT int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, int c, float *dense,
+                                     int batch, int d0, int d1, int d2, sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
+  const int64_t total = (int64_t)batch * c * d0 * d1 * d2;
+  if (total > 0) {
+    SGNN_CHECK_ARG(dense);
+    SGNN_HIP_TRY(hipMemsetAsync(dense, 0, (size_t)total * sizeof(float), s));
+  }
+  if (n == 0 || total == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(feats && coords);
+  hipLaunchKernelGGL(k_sparse_to_dense, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, s, feats,
+                     (const int4 *)coords, n, c, dense, batch, d0, d1, d2);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+__global__ __launch_bounds__(256) void k_dense_to_sparse(const float *__restrict__ dense,
+                                                        const int4 *__restrict__ coords, int64_t n, int c,
+                                                        float *__restrict__ feats, int batch, int d0, int d1,
+                                                        int d2) {
+  const int64_t total = n * c, stride = (int64_t)gridDim.x * 256;
+  const int64_t vol = (int64_t)d0 * d1 * d2;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int ch = (int)(g / n);
+    const int64_t r = g - (int64_t)ch * n;
+    const int4 p = coords[r];
+    float v = 0.f;
+    if ((unsigned)p.x < (unsigned)d0 && (unsigned)p.y < (unsigned)d1 && (unsigned)p.z < (unsigned)d2 &&
+        (unsigned)p.w < (unsigned)batch)
+      v = dense[((int64_t)p.w * c + ch) * vol + ((int64_t)p.x * d1 + p.y) * d2 + p.z];
+    feats[r * c + ch] = v;
+  }
+}
+
+SGNN_EXPORT int sgnn_dense_to_sparse(const float *dense, const int32_t *coords, int64_t n, int c, float *feats,
+                                     int batch, int d0, int d1, int d2, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(dense && coords && feats);
+  hipLaunchKernelGGL(k_dense_to_sparse, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     dense, (const int4 *)coords, n, c, feats, batch, d0, d1, d2);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}

@@ -1,0 +1,307 @@
+"""torch.autograd wrappers around the C ABI (include/sgnn_hip.h).
+
+Each Function allocates outputs with torch (device memory plumbing) and hands raw device
+pointers to libsgnn_hip.so on the current HIP stream.  No arithmetic happens in Python/torch.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from .._lib import ptr
+from .metadata import runtime
+
+CONV_TRANSPOSE_W = 1
+CONV_FLIP_K = 2
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError('sgnn_amd operators are float32 (got %s)' % t.dtype)
+    return t.contiguous()
+
+
+def conv_fwd_raw(x, cin, w, K, table, ld, n_out, cout, flags=0, in_shift=0):
+    y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    _lib.call('sgnn_conv_fwd', ptr(x), cin, ptr(w), K, ptr(table), ld, n_out, cout, ptr(y), flags, in_shift)
+    return y
+
+
+def conv_dw_raw(x, cin, dy, cout, table, ld, K, n_out, in_shift=0):
+    rt = runtime(x.device)
+    dw = torch.empty(K, cin, cout, dtype=torch.float32, device=x.device)
+    wsb = _lib.query('sgnn_conv_bwd_weight_ws_bytes', n_out, K, cin, cout)
+    ws = rt.workspace(wsb)
+    _lib.call('sgnn_conv_bwd_weight', ptr(x), cin, ptr(dy), cout, ptr(table), ld, K, n_out, ptr(dw), in_shift,
+              ptr(ws), wsb)
+    return dw
+
+
+class SparseConv(Function):
+    """y[j] = sum_k W[k]^T x[table_f[k][j]]; gradients through table_b (see sgnn_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, table_f, ld_f, n_out, table_b, ld_b, n_in, flags_b, in_shift):
+        x, weight = _f32c(x), _f32c(weight)
+        K, cin, cout = weight.shape
+        assert x.shape[1] == cin, 'feature width %d != nIn %d' % (x.shape[1], cin)
+        y = conv_fwd_raw(x, cin, weight, K, table_f, ld_f, n_out, cout, 0, in_shift)
+        ctx.save_for_backward(x, weight)
+        ctx.tables = (table_f, ld_f, n_out, table_b, ld_b, n_in, flags_b, in_shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        table_f, ld_f, n_out, table_b, ld_b, n_in, flags_b, in_shift = ctx.tables
+        K, cin, cout = weight.shape
+        dy = _f32c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if in_shift:
+                # gradient w.r.t. the virtual (replicated) rows, then summed over each group
+                dfull = conv_fwd_raw(dy, cout, weight, K, table_b, ld_b, n_in, cin, flags_b, 0)
+                dx = sum_groups_raw(dfull, cin, n_in >> in_shift, 1 << in_shift)
+            else:
+                dx = conv_fwd_raw(dy, cout, weight, K, table_b, ld_b, n_in, cin, flags_b, 0)
+        if ctx.needs_input_grad[1]:
+            dw = conv_dw_raw(x, cin, dy, cout, table_f, ld_f, K, n_out, in_shift)
+        return dx, dw, None, None, None, None, None, None, None, None
+
+
+class BatchNormLeaky(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, leak):
+        x = _f32c(x)
+        n, c = x.shape
+        rt = runtime(x.device)
+        y = torch.empty_like(x)
+        save = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        wsb = _lib.query('sgnn_bn_ws_bytes', n, c)
+        ws = rt.workspace(wsb)
+        _lib.call('sgnn_bn_fwd', ptr(x), n, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                  float(eps), float(momentum), int(bool(training)), float(leak), ptr(save[0]), ptr(save[1]), ptr(y),
+                  ptr(ws), wsb)
+        ctx.save_for_backward(x, gamma, beta, save)
+        ctx.cfg = (bool(training), float(leak))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, save = ctx.saved_tensors
+        training, leak = ctx.cfg
+        n, c = x.shape
+        dy = _f32c(dy)
+        rt = runtime(x.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        wsb = _lib.query('sgnn_bn_ws_bytes', n, c)
+        ws = rt.workspace(wsb)
+        _lib.call('sgnn_bn_bwd', ptr(x), ptr(dy), n, c, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                  int(training), leak, ptr(dx), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), wsb)
+        dgamma = dgb[0] if gamma is not None else None
+        dbeta = dgb[1] if beta is not None else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def gather_rows_raw(src, c, idx, m):
+    dst = torch.empty(m, c, dtype=torch.float32, device=src.device)
+    _lib.call('sgnn_gather_rows', ptr(src), c, ptr(idx), m, ptr(dst))
+    return dst
+
+
+def scatter_rows_raw(src, c, idx, m, n_dst):
+    dst = torch.empty(n_dst, c, dtype=torch.float32, device=src.device)
+    _lib.call('sgnn_scatter_rows', ptr(src), c, ptr(idx), m, ptr(dst), n_dst)
+    return dst
+
+
+def sum_groups_raw(src, c, n, rep):
+    dst = torch.empty(n, c, dtype=torch.float32, device=src.device)
+    _lib.call('sgnn_sum_groups', ptr(src), c, n, rep, ptr(dst))
+    return dst
+
+
+class GatherRows(Function):
+    """dst[r] = src[idx[r]] with unique idx (mask compaction)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, m):
+        src = _f32c(src)
+        ctx.save_for_backward(idx)
+        ctx.shape = (src.shape[0], src.shape[1], m)
+        return gather_rows_raw(src, src.shape[1], idx, m)
+
+    @staticmethod
+    def backward(ctx, d):
+        (idx,) = ctx.saved_tensors
+        n, c, m = ctx.shape
+        return scatter_rows_raw(_f32c(d), c, idx, m, n), None, None
+
+
+class UnPool(Function):
+    """fine[i] = coarse[parent[i]]; backward = sum over the (<= 8) children."""
+
+    @staticmethod
+    def forward(ctx, coarse, parent, nf, children, ldc):
+        coarse = _f32c(coarse)
+        ctx.save_for_backward(children)
+        ctx.shape = (coarse.shape[0], coarse.shape[1], ldc)
+        return gather_rows_raw(coarse, coarse.shape[1], parent, nf)
+
+    @staticmethod
+    def backward(ctx, d):
+        (children,) = ctx.saved_tensors
+        nc, c, ldc = ctx.shape
+        d = _f32c(d)
+        out = torch.empty(nc, c, dtype=torch.float32, device=d.device)
+        _lib.call('sgnn_gather_sum', ptr(d), c, ptr(children), ldc, 8, nc, ptr(out))
+        return out, None, None, None, None
+
+
+class RepeatRows(Function):
+    @staticmethod
+    def forward(ctx, src, rep):
+        src = _f32c(src)
+        n, c = src.shape
+        ctx.cfg = (n, c, rep)
+        dst = torch.empty(n * rep, c, dtype=torch.float32, device=src.device)
+        _lib.call('sgnn_repeat_rows', ptr(src), c, n, rep, ptr(dst))
+        return dst
+
+    @staticmethod
+    def backward(ctx, d):
+        n, c, rep = ctx.cfg
+        return sum_groups_raw(_f32c(d), c, n, rep), None
+
+
+class ConcatRows(Function):
+    """dst[r] = [a[ia[r]] | b[ib[r]]] (None index = identity, negative ib = zeros)."""
+
+    @staticmethod
+    def forward(ctx, a, ia, b, ib, m):
+        a, b = _f32c(a), _f32c(b)
+        ca, cb = a.shape[1], b.shape[1]
+        dst = torch.empty(m, ca + cb, dtype=torch.float32, device=a.device)
+        _lib.call('sgnn_concat_rows', ptr(a), ca, ptr(ia), ptr(b), cb, ptr(ib), m, ptr(dst))
+        ctx.idx = (ia, ib)
+        ctx.shape = (a.shape[0], ca, b.shape[0], cb, m)
+        return dst
+
+    @staticmethod
+    def backward(ctx, d):
+        ia, ib = ctx.idx
+        na, ca, nb, cb, m = ctx.shape
+        d = _f32c(d)
+        da = torch.empty(na, ca, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty(nb, cb, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[2] else None
+        _lib.call('sgnn_concat_rows_bwd', ptr(d), ca, ptr(ia), cb, ptr(ib), m, ptr(da), na, ptr(db), nb)
+        return da, None, db, None, None
+
+
+class AddRows(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        y = torch.empty_like(a)
+        _lib.call('sgnn_add', ptr(a), ptr(b), a.numel(), ptr(y))
+        return y
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+class SparseToDenseFn(Function):
+    @staticmethod
+    def forward(ctx, feats, coords, batch, d0, d1, d2):
+        feats = _f32c(feats)
+        n, c = feats.shape
+        dense = torch.empty(batch, c, d0, d1, d2, dtype=torch.float32, device=feats.device)
+        _lib.call('sgnn_sparse_to_dense', ptr(feats), ptr(coords), n, c, ptr(dense), batch, d0, d1, d2)
+        ctx.save_for_backward(coords)
+        ctx.cfg = (n, c, batch, d0, d1, d2)
+        return dense
+
+    @staticmethod
+    def backward(ctx, d):
+        (coords,) = ctx.saved_tensors
+        n, c, batch, d0, d1, d2 = ctx.cfg
+        d = _f32c(d)
+        df = torch.empty(n, c, dtype=torch.float32, device=d.device)
+        _lib.call('sgnn_dense_to_sparse', ptr(d), ptr(coords), n, c, ptr(df), batch, d0, d1, d2)
+        return df, None, None, None, None, None
+
+
+class DenseToSparseFn(Function):
+    """rows[r][ch] = dense[b][ch][z][y][x] at coords[r] (coords unique)."""
+
+    @staticmethod
+    def forward(ctx, dense, coords):
+        dense = _f32c(dense)
+        batch, c, d0, d1, d2 = dense.shape
+        n = coords.shape[0]
+        rows = torch.empty(n, c, dtype=torch.float32, device=dense.device)
+        _lib.call('sgnn_dense_to_sparse', ptr(dense), ptr(coords), n, c, ptr(rows), batch, d0, d1, d2)
+        ctx.save_for_backward(coords)
+        ctx.cfg = (n, c, batch, d0, d1, d2)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d):
+        (coords,) = ctx.saved_tensors
+        n, c, batch, d0, d1, d2 = ctx.cfg
+        d = _f32c(d)
+        dd = torch.empty(batch, c, d0, d1, d2, dtype=torch.float32, device=d.device)
+        _lib.call('sgnn_sparse_to_dense', ptr(d), ptr(coords), n, c, ptr(dd), batch, d0, d1, d2)
+        return dd, None
+
+
+# ---------------------------------------------------------------------------
+# non-differentiable index helpers
+# ---------------------------------------------------------------------------
+def compact_sigmoid(logits, stride, n):
+    """Stable list of rows with sigmoid(logit) > 0.5 -> (sel int32[count], count).  One host sync."""
+    rt = runtime(logits.device)
+    sel = torch.empty(max(n, 1), dtype=torch.int32, device=logits.device)
+    wsb = _lib.query('sgnn_compact_ws_bytes', n)
+    ws = rt.workspace(wsb)
+    _lib.call('sgnn_compact_sigmoid', ptr(logits), stride, n, ptr(sel), ptr(rt.state), ptr(ws), wsb)
+    count = rt.read_count()
+    return sel[:count], count
+
+
+def compact_mask(mask_u8, n):
+    rt = runtime(mask_u8.device)
+    sel = torch.empty(max(n, 1), dtype=torch.int32, device=mask_u8.device)
+    wsb = _lib.query('sgnn_compact_ws_bytes', n)
+    ws = rt.workspace(wsb)
+    _lib.call('sgnn_compact_mask', ptr(mask_u8), n, ptr(sel), ptr(rt.state), ptr(ws), wsb)
+    count = rt.read_count()
+    return sel[:count], count
+
+
+def gather_coords(coords32, sel, m):
+    """coords rows are 16-byte rows: reuse the fp32 row gather as a pure bit copy."""
+    out = torch.empty(m, 4, dtype=torch.int32, device=coords32.device)
+    _lib.call('sgnn_gather_rows', ptr(coords32), 4, ptr(sel), m, ptr(out))
+    return out
+
+
+def expand8_coords(coords32):
+    n = coords32.shape[0]
+    out = torch.empty(8 * n, 4, dtype=torch.int32, device=coords32.device)
+    _lib.call('sgnn_expand8_coords', ptr(coords32), n, ptr(out))
+    return out
+
+
+def dense_coords(batch, d0, d1, d2, device):
+    out = torch.empty(batch * d0 * d1 * d2, 4, dtype=torch.int32, device=device)
+    _lib.call('sgnn_dense_coords', batch, d0, d1, d2, ptr(out))
+    return out
+
+
+def coords_to_i64(coords32):
+    n = coords32.shape[0]
+    out = torch.empty(n, 4, dtype=torch.int64, device=coords32.device)
+    _lib.call('sgnn_coords_to_i64', ptr(coords32), n, ptr(out))
+    return out

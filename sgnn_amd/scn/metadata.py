@@ -1,0 +1,174 @@
+"""Device-resident voxel grids and rulebooks (host-side bookkeeping only).
+
+Counterpart of upstream's `Metadata_3` object that the reference reaches through
+`x.metadata.getSpatialLocations(x.spatial_size)` (torch/model.py:380) and that every scn op
+shares.  All hashing / rulebook arithmetic happens in libsgnn_hip.so; this module only owns the
+torch tensors that back the tables and caches them per (spatial size, filter) like upstream does.
+"""
+import torch
+
+from .. import _lib
+from .._lib import ptr
+
+
+class _Runtime(object):
+    """Per-device scratch: grow-only workspace + an 8-word state block (count, status)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+        self.state = torch.zeros(4, dtype=torch.int64, device=device)
+        self.status32 = self.state[1:2].view(torch.int32)  # two int32 words, first one used
+
+    def workspace(self, nbytes):
+        if self.ws.numel() < nbytes:
+            self.ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def read_count(self):
+        """One D2H copy: returns the count word and raises on pending input errors."""
+        host = self.state.cpu()
+        status = int(host[1].item()) & 0xFFFFFFFF
+        if status:
+            self.state[1] = 0
+            msgs = []
+            if status & 1:
+                msgs.append('coordinate outside [0,65535] (batch outside [0,32767])')
+            if status & 2:
+                msgs.append('InputLayer(mode=0): duplicate coordinates are a caller error')
+            raise _lib.SgnnError('; '.join(msgs))
+        return int(host[0].item())
+
+
+_runtimes = {}
+
+
+def runtime(device=None):
+    _lib.require_gpu()
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    rt = _runtimes.get(idx)
+    if rt is None:
+        rt = _runtimes[idx] = _Runtime(torch.device('cuda', idx))
+    return rt
+
+
+def _round_up(n, m):
+    return ((n + m - 1) // m) * m
+
+
+class Grid(object):
+    """Active sites of one resolution level: int32 coords (n,4) [z,y,x,b]; row i <-> site i."""
+
+    def __init__(self, coords32, keys=None, vals=None, cap=0):
+        assert coords32.dtype == torch.int32 and coords32.dim() == 2 and coords32.shape[1] == 4
+        self.coords = coords32.contiguous()
+        self.n = int(coords32.shape[0])
+        self.device = coords32.device
+        self.keys, self.vals, self.cap = keys, vals, cap
+        self._nbr = None
+        self.ld = _round_up(max(self.n, 1), 64)
+
+    def hash(self):
+        if self.keys is None:
+            rt = runtime(self.device)
+            self.cap = _lib.query('sgnn_hash_capacity', self.n)
+            self.keys = torch.empty(self.cap, dtype=torch.int64, device=self.device)
+            self.vals = torch.empty(self.cap, dtype=torch.int32, device=self.device)
+            _lib.call('sgnn_hash_build', ptr(self.coords), self.n, ptr(self.keys), ptr(self.vals), self.cap,
+                      ptr(rt.status32))
+        return self.keys, self.vals, self.cap
+
+    def lookup(self, query32):
+        """Row of each query site in this grid, or -1 (int32 tensor)."""
+        keys, vals, cap = self.hash()
+        m = int(query32.shape[0])
+        rows = torch.empty(m, dtype=torch.int32, device=self.device)
+        _lib.call('sgnn_hash_lookup', ptr(keys), ptr(vals), cap, ptr(query32), m, ptr(rows))
+        return rows
+
+    def subm_table(self):
+        """3x3x3 neighbour table, int32 [27][ld] (cached; one build serves every conv of the level)."""
+        if self._nbr is None:
+            keys, vals, cap = self.hash()
+            self._nbr = torch.empty(27 * self.ld, dtype=torch.int32, device=self.device)
+            _lib.call('sgnn_rulebook_subm3', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, ptr(self._nbr),
+                      self.ld)
+        return self._nbr
+
+    def locations_i64(self):
+        out = torch.empty(self.n, 4, dtype=torch.int64, device=self.device)
+        _lib.call('sgnn_coords_to_i64', ptr(self.coords), self.n, ptr(out))
+        return out
+
+
+class Down2(object):
+    """Stride-2 rulebook between a fine and a coarse grid."""
+
+    def __init__(self, fine, coarse, parent, children, ldc, ptable, ldf):
+        self.fine, self.coarse = fine, coarse
+        self.parent, self.children, self.ldc, self.ptable, self.ldf = parent, children, ldc, ptable, ldf
+
+
+def build_down2(fine):
+    rt = runtime(fine.device)
+    nf, dev = fine.n, fine.device
+    ccap = _lib.query('sgnn_hash_capacity', nf)
+    ckeys = torch.empty(ccap, dtype=torch.int64, device=dev)
+    cvals = torch.empty(ccap, dtype=torch.int32, device=dev)
+    parent = torch.empty(max(nf, 1), dtype=torch.int32, device=dev)
+    ccoords = torch.empty(max(nf, 1), 4, dtype=torch.int32, device=dev)
+    wsb = _lib.query('sgnn_down2_ws_bytes', nf)
+    ws = rt.workspace(wsb)
+    _lib.call('sgnn_rulebook_down2', ptr(fine.coords), nf, ptr(ckeys), ptr(cvals), ccap, ptr(parent), ptr(ccoords),
+              ptr(rt.state), ptr(ws), wsb)
+    nc = rt.read_count()  # host sync: the coarse row count sizes every downstream buffer
+    coarse = Grid(ccoords[:nc], ckeys, cvals, ccap)
+    ldc, ldf = coarse.ld, fine.ld
+    children = torch.empty(8 * ldc, dtype=torch.int32, device=dev)
+    ptable = torch.empty(8 * ldf, dtype=torch.int32, device=dev)  # rows >= nf are never read
+    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf)
+    return Down2(fine, coarse, parent[:nf], children, ldc, ptable, ldf)
+
+
+class Metadata(object):
+    def __init__(self, dimension=3):
+        self.dimension = dimension
+        self.grids = {}
+        self.down = {}
+
+    @staticmethod
+    def key(spatial_size):
+        return tuple(int(s) for s in spatial_size)
+
+    def set_input(self, spatial_size, grid):
+        self.grids[self.key(spatial_size)] = grid
+
+    def grid(self, spatial_size):
+        return self.grids[self.key(spatial_size)]
+
+    def getSpatialLocations(self, spatial_size):
+        """(N,4) int64 [z,y,x,batch] in active-row order (torch/model.py:380)."""
+        return self.grid(spatial_size).locations_i64()
+
+    def down2(self, in_size, out_size):
+        k = (self.key(in_size), self.key(out_size))
+        if k not in self.down:
+            d = build_down2(self.grid(in_size))
+            if self.key(out_size) not in self.grids:
+                self.grids[self.key(out_size)] = d.coarse
+            self.down[k] = d
+        return self.down[k]
+
+
+def coords_from_locs(locs, device):
+    """Reference-style LongTensor (N,4) [z,y,x,b] (any device) -> device int32 rows."""
+    rt = runtime(device)
+    if locs.dtype == torch.int32:
+        return locs.to(device).contiguous()
+    locs = locs.to(device=device, dtype=torch.int64).contiguous()
+    n = int(locs.shape[0])
+    out = torch.empty(n, 4, dtype=torch.int32, device=device)
+    _lib.call('sgnn_coords_from_i64', ptr(locs), n, ptr(out), ptr(rt.status32))
+    return out

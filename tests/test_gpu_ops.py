@@ -1,0 +1,197 @@
+"""HIP operators vs the CPU oracle on identical seeded inputs.
+Indices / rulebooks must be bit-identical; fp32 features within 1e-4 (north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+import scn_oracle as oscn
+from util import random_sites, copy_params, triples_from_table
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _hip():
+    import sgnn_amd.scn as scn
+    return scn
+
+
+def _pair(locs, feats, size):
+    scn = _hip()
+    xo = oscn.InputLayer(3, size, mode=0)([locs, feats])
+    xh = scn.InputLayer(3, size, mode=0)([locs.cuda(), feats.cuda()])
+    return xo, xh
+
+
+@pytest.mark.parametrize('surface', [False, True])
+def test_subm_rulebook_bit_identical(surface):
+    locs = random_sites(3, 24, 0.08, 1, surface)
+    feats = torch.zeros(locs.shape[0], 1)
+    xo, xh = _pair(locs, feats, [24, 24, 24])
+    g = xh.grid()
+    got = triples_from_table(g.subm_table(), 27, g.ld, g.n)
+    nbr = xo.metadata.grid(xo.spatial_size).subm_rules(3)
+    k, j = np.nonzero(nbr >= 0)
+    want = np.stack([k, nbr[k, j], j], 1)
+    want = want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))]
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_down2_sites_and_rules_bit_identical():
+    locs = random_sites(2, 16, 0.15, 2)
+    feats = torch.zeros(locs.shape[0], 1)
+    xo, xh = _pair(locs, feats, [16, 16, 16])
+    d = xh.metadata.down2(xh.spatial_size, xh.spatial_size // 2)
+    parent_o, off_o = xo.metadata.down2(xo.spatial_size, xo.spatial_size // 2)
+    coarse_o = xo.metadata.grid(xo.spatial_size // 2).coords
+    assert d.coarse.n == coarse_o.shape[0]
+    assert np.array_equal(d.coarse.coords.cpu().numpy().astype(np.int64), coarse_o)  # first-touch order, exact
+    assert np.array_equal(d.parent.cpu().numpy().astype(np.int64), parent_o)
+    ch = d.children.view(8, d.ldc)[:, :d.coarse.n].cpu().numpy()
+    want = np.full_like(ch, -1)
+    want[off_o, parent_o] = np.arange(len(parent_o))
+    assert np.array_equal(ch, want)
+    # the coarse hash must resolve every coarse site to its own row
+    rows = d.coarse.lookup(d.coarse.coords)
+    assert np.array_equal(rows.cpu().numpy(), np.arange(d.coarse.n))
+
+
+CONV_CASES = [(1, 8), (8, 8), (8, 12), (12, 12), (12, 16), (16, 16), (34, 16), (30, 16), (26, 16), (48, 16), (5, 7)]
+
+
+@pytest.mark.parametrize('cin,cout', CONV_CASES)
+def test_subm_conv_fwd_bwd(cin, cout):
+    scn = _hip()
+    torch.manual_seed(cin * 100 + cout)
+    locs = random_sites(2, 20, 0.2, cin + cout, surface=(cin % 2 == 0))
+    feats = torch.randn(locs.shape[0], cin)
+    fo = feats.clone().requires_grad_(True)
+    fh = feats.clone().cuda().requires_grad_(True)
+    mo = oscn.SubmanifoldConvolution(3, cin, cout, 3, False)
+    mh = scn.SubmanifoldConvolution(3, cin, cout, 3, False).cuda()
+    copy_params(mo, mh)
+    yo = mo(oscn.InputLayer(3, [20] * 3, mode=0)([locs, fo])).features
+    yh = mh(scn.InputLayer(3, [20] * 3, mode=0)([locs.cuda(), fh])).features
+    assert (yo - yh.cpu()).abs().max().item() < TOL
+    go = torch.randn_like(yo)
+    yo.backward(go)
+    yh.backward(go.cuda())
+    assert (fo.grad - fh.grad.cpu()).abs().max().item() < TOL
+    scale = max(1.0, mo.weight.grad.abs().max().item())
+    assert (mo.weight.grad - mh.weight.grad.cpu()).abs().max().item() < TOL * scale
+
+
+@pytest.mark.parametrize('c', [8, 12, 16, 7])
+def test_strided_conv_unpool_fwd_bwd(c):
+    scn = _hip()
+    torch.manual_seed(c)
+    locs = random_sites(2, 16, 0.2, 7 + c)
+    feats = torch.randn(locs.shape[0], c)
+    fo = feats.clone().requires_grad_(True)
+    fh = feats.clone().cuda().requires_grad_(True)
+    mo, mh = oscn.Convolution(3, c, c, 2, 2, False), scn.Convolution(3, c, c, 2, 2, False).cuda()
+    copy_params(mo, mh)
+    xo = oscn.InputLayer(3, [16] * 3, mode=0)([locs, fo])
+    xh = scn.InputLayer(3, [16] * 3, mode=0)([locs.cuda(), fh])
+    zo, zh = mo(xo), mh(xh)
+    assert zo.features.shape == zh.features.shape
+    assert (zo.features - zh.features.cpu()).abs().max().item() < TOL
+    uo, uh = oscn.UnPooling(3, 2, 2)(zo).features, scn.UnPooling(3, 2, 2)(zh).features
+    assert torch.equal(uo, uo) and (uo - uh.cpu()).abs().max().item() < TOL
+    go = torch.randn_like(uo)
+    (uo * go).sum().backward()
+    (uh * go.cuda()).sum().backward()
+    assert (fo.grad - fh.grad.cpu()).abs().max().item() < TOL
+    assert (mo.weight.grad - mh.weight.grad.cpu()).abs().max().item() < TOL * max(1.0, mo.weight.grad.abs().max().item())
+
+
+def test_deconvolution_matches_oracle():
+    scn = _hip()
+    torch.manual_seed(3)
+    locs = random_sites(2, 16, 0.2, 11)
+    feats = torch.randn(locs.shape[0], 8)
+    fo, fh = feats.clone().requires_grad_(True), feats.clone().cuda().requires_grad_(True)
+    co, ch = oscn.Convolution(3, 8, 8, 2, 2, False), scn.Convolution(3, 8, 8, 2, 2, False).cuda()
+    do, dh = oscn.Deconvolution(3, 8, 12, 2, 2, False), scn.Deconvolution(3, 8, 12, 2, 2, False).cuda()
+    copy_params(co, ch)
+    copy_params(do, dh)
+    yo = do(co(oscn.InputLayer(3, [16] * 3, mode=0)([locs, fo]))).features
+    yh = dh(ch(scn.InputLayer(3, [16] * 3, mode=0)([locs.cuda(), fh]))).features
+    assert (yo - yh.cpu()).abs().max().item() < TOL
+    g = torch.randn_like(yo)
+    yo.backward(g)
+    yh.backward(g.cuda())
+    assert (fo.grad - fh.grad.cpu()).abs().max().item() < TOL
+    assert (do.weight.grad - dh.weight.grad.cpu()).abs().max().item() < TOL * max(1.0, do.weight.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('c,train', [(8, True), (12, True), (16, True), (48, True), (16, False), (5, True)])
+def test_batchnorm_relu(c, train):
+    scn = _hip()
+    torch.manual_seed(c)
+    locs = random_sites(2, 16, 0.3, c)
+    feats = torch.randn(locs.shape[0], c) * 2 + 0.5
+    fo, fh = feats.clone().requires_grad_(True), feats.clone().cuda().requires_grad_(True)
+    mo, mh = oscn.BatchNormReLU(c), scn.BatchNormReLU(c).cuda()
+    with torch.no_grad():
+        mo.weight.uniform_(0.5, 1.5)
+        mo.bias.uniform_(-0.5, 0.5)
+        mo.running_mean.uniform_(-0.2, 0.7)
+        mo.running_var.uniform_(2.0, 5.0)
+    copy_params(mo, mh)
+    mo.train(train)
+    mh.train(train)
+    yo = mo(oscn.InputLayer(3, [16] * 3, mode=0)([locs, fo])).features
+    yh = mh(scn.InputLayer(3, [16] * 3, mode=0)([locs.cuda(), fh])).features
+    assert (yo - yh.cpu()).abs().max().item() < TOL
+    assert (mo.running_mean - mh.running_mean.cpu()).abs().max().item() < 1e-5
+    assert (mo.running_var - mh.running_var.cpu()).abs().max().item() < 1e-5
+    g = torch.randn_like(yo)
+    yo.backward(g)
+    yh.backward(g.cuda())
+    assert (fo.grad - fh.grad.cpu()).abs().max().item() < TOL
+    assert (mo.weight.grad - mh.weight.grad.cpu()).abs().max().item() < 1e-3
+    assert (mo.bias.grad - mh.bias.grad.cpu()).abs().max().item() < 1e-3
+
+
+def test_fully_convolutional_net_and_sparse_to_dense():
+    scn = _hip()
+    torch.manual_seed(5)
+    locs = random_sites(2, 16, 0.25, 5, surface=True)
+    feats = torch.randn(locs.shape[0], 16)
+    fo, fh = feats.clone().requires_grad_(True), feats.clone().cuda().requires_grad_(True)
+    mo = oscn.Sequential().add(oscn.FullyConvolutionalNet(3, 1, [16, 16, 16], True)).add(oscn.BatchNormReLU(48))
+    mh = scn.Sequential().add(scn.FullyConvolutionalNet(3, 1, [16, 16, 16], True)).add(scn.BatchNormReLU(48)).cuda()
+    assert list(mo.state_dict().keys()) == list(mh.state_dict().keys())
+    copy_params(mo, mh)
+    xo = mo(oscn.InputLayer(3, [16] * 3, mode=0)([locs, fo]))
+    xh = mh(scn.InputLayer(3, [16] * 3, mode=0)([locs.cuda(), fh]))
+    assert (xo.features - xh.features.cpu()).abs().max().item() < TOL
+    do, dh = oscn.SparseToDense(3, 48)(xo), scn.SparseToDense(3, 48)(xh)
+    assert do.shape == dh.shape and (do - dh.cpu()).abs().max().item() < TOL
+    g = torch.randn_like(do)
+    (do * g).sum().backward()
+    (dh * g.cuda()).sum().backward()
+    assert (fo.grad - fh.grad.cpu()).abs().max().item() < 5 * TOL
+    for (ko, po), (kh, ph) in zip(mo.named_parameters(), mh.named_parameters()):
+        assert ko == kh
+        assert (po.grad - ph.grad.cpu()).abs().max().item() < 1e-3 * max(1.0, po.grad.abs().max().item()), ko
+
+
+def test_duplicate_sites_raise():
+    scn = _hip()
+    from sgnn_amd._lib import SgnnError
+    locs = torch.tensor([[1, 2, 3, 0], [1, 2, 3, 0], [2, 2, 2, 0]])
+    x = scn.InputLayer(3, [8] * 3, mode=0)([locs.cuda(), torch.zeros(3, 1).cuda()])
+    x.grid().hash()
+    with pytest.raises(SgnnError):
+        scn.runtime().read_count()
+
+
+def test_empty_input_is_legal():
+    scn = _hip()
+    x = scn.InputLayer(3, [8] * 3, mode=0)([torch.zeros(0, 4, dtype=torch.long).cuda(), torch.zeros(0, 4).cuda()])
+    y = scn.SubmanifoldConvolution(3, 4, 16, 3, False).cuda()(x)
+    assert y.features.shape == (0, 16)
+    z = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(y)
+    assert z.features.shape == (0, 16)

@@ -1,0 +1,37 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+import torch
+
+
+def random_sites(batch, size, occupancy, seed, surface=False):
+    """(N,4) int64 [z,y,x,b] unique sites, batch-major raster order like scene_dataloader.collate."""
+    rng = np.random.default_rng(seed)
+    s = size if hasattr(size, '__len__') else (size, size, size)
+    locs = []
+    for b in range(batch):
+        if surface:
+            zz, yy, xx = np.meshgrid(np.arange(s[0]), np.arange(s[1]), np.arange(s[2]), indexing='ij')
+            c = rng.uniform(0.3, 0.7, 3) * np.array(s)
+            r = rng.uniform(0.2, 0.35) * min(s)
+            d = np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) - r
+            occ = np.abs(d) < 1.5
+        else:
+            occ = rng.random(s) < occupancy
+        z, y, x = np.nonzero(occ)
+        locs.append(np.stack([z, y, x, np.full_like(z, b)], 1))
+    return torch.from_numpy(np.concatenate(locs, 0).astype(np.int64))
+
+
+def copy_params(src, dst):
+    """Copy parameters/buffers between structurally identical modules (oracle <-> HIP)."""
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    missing = dst.load_state_dict(sd, strict=True)
+    return missing
+
+
+def triples_from_table(table, K, ld, n):
+    """Sorted (k, in, out) triples of an offset-major neighbour table (host numpy)."""
+    t = table.view(K, ld)[:, :n].cpu().numpy()
+    k, j = np.nonzero(t >= 0)
+    tri = np.stack([k, t[k, j], j], 1).astype(np.int64)
+    return tri[np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0]))]

@@ -1,0 +1,81 @@
+"""Synthetic TSDF blocks in exactly the layout `scene_dataloader.collate` emits
+(torch/scene_dataloader.py:13-36, 60-116; file semantics torch/data_util.py:63-108):
+
+  input      [locs (sumN,4) int64 [z,y,x,b] batch-major raster order, feats (sumN,1) f32 TSDF in voxels]
+  sdf        (B,1,D0,D1,D2) f32, -inf where no target surface was stored
+  known      (B,1,D0,D1,D2) u8: 0 known-empty, 1 known-occupied, >=2 unknown (depth behind surface + 1)
+  hierarchy  [3] dense (B,1,D/8..), (B,1,D/4..), (B,1,D/2..) coarse -> fine, -inf off-surface
+
+Primary distribution "surface" (SURVEY.md §8d): per block a union of 1..3 random spheres plus
+optionally a plane, signed distance in voxels, active iff |sdf| < truncation; the input is the
+target with a random half-space removed (self-supervised completion flavour).  Seeds:
+numpy default_rng(1000*cfg + block_idx).  Secondary "iid": Bernoulli(p) sites, sdf ~ U(-3,3).
+There is no network in the build environment, so real Matterport chunks are never used.
+"""
+import numpy as np
+import torch
+
+
+def _block_sdf(dims, rng, occupancy):
+    zz, yy, xx = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing='ij')
+    pts = np.stack([zz, yy, xx], -1).astype(np.float32)
+    dmin = float(min(dims))
+    # a single sphere of r ~ 0.206*D gives ~5 % of |sdf|<3 sites at 64^3; scale r with the requested occupancy
+    base_r = 0.206 * dmin * np.sqrt(max(occupancy, 1e-3) / 0.05)
+    k = int(rng.integers(1, 4))
+    sdf = np.full(dims, 1e6, dtype=np.float32)
+    for _ in range(k):
+        c = rng.uniform(0.25, 0.75, 3) * np.array(dims)
+        r = base_r / np.sqrt(k) * rng.uniform(0.85, 1.15)
+        d = np.sqrt(((pts - c) ** 2).sum(-1)) - r
+        sdf = np.minimum(sdf, d)
+    return sdf
+
+
+def make_block(dims, seed, occupancy=0.05, truncation=3.0, dist='surface'):
+    """One block -> (input_locs (N,3) int64 zyx, input_sdf (N,), target dense, known dense, hierarchy[3])."""
+    rng = np.random.default_rng(seed)
+    dims = tuple(int(d) for d in dims)
+    if dist == 'iid':
+        occ = rng.random(dims) < occupancy
+        sdf = np.where(occ, rng.uniform(-truncation, truncation, dims), 1e6).astype(np.float32)
+    else:
+        sdf = _block_sdf(dims, rng, occupancy)
+    band = np.abs(sdf) < truncation
+    target = np.where(band, sdf, -np.inf).astype(np.float32)
+    known = np.where(sdf > 0, 0, np.where(band, 1, np.minimum(255, np.ceil(-sdf) + 1))).astype(np.uint8)
+    # input: drop everything behind a random plane through the block
+    nrm = rng.normal(size=3)
+    nrm /= np.linalg.norm(nrm)
+    zz, yy, xx = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing='ij')
+    side = ((zz - dims[0] / 2) * nrm[0] + (yy - dims[1] / 2) * nrm[1] + (xx - dims[2] / 2) * nrm[2]) < 0.25 * min(dims)
+    keep = band & side
+    z, y, x = np.nonzero(keep)
+    in_locs = np.stack([z, y, x], 1).astype(np.int64)
+    in_sdf = sdf[z, y, x].astype(np.float32)
+    hierarchy = []
+    for f in (8, 4, 2):  # coarse -> fine, values in that level's voxel units
+        sub = sdf[f // 2::f, f // 2::f, f // 2::f] / f
+        hierarchy.append(np.where(np.abs(sub) < truncation, sub, -np.inf).astype(np.float32))
+    return in_locs, in_sdf, target, known, hierarchy
+
+
+def make_batch(batch_size, dims=(64, 64, 64), cfg=2, first_block=0, occupancy=0.05, truncation=3.0, dist='surface'):
+    """Collated batch (CPU tensors), same keys/dtypes as scene_dataloader.collate."""
+    if not hasattr(dims, '__len__'):
+        dims = (dims, dims, dims)
+    locs, feats, sdfs, knowns, hier = [], [], [], [], [[], [], []]
+    for b in range(batch_size):
+        il, isdf, tgt, knw, hr = make_block(dims, 1000 * cfg + first_block + b, occupancy, truncation, dist)
+        locs.append(np.concatenate([il, np.full((il.shape[0], 1), b, np.int64)], 1))
+        feats.append(isdf[:, None])
+        sdfs.append(tgt[None])
+        knowns.append(knw[None])
+        for h in range(3):
+            hier[h].append(hr[h][None])
+    return {
+        'input': [torch.from_numpy(np.concatenate(locs, 0)), torch.from_numpy(np.concatenate(feats, 0))],
+        'sdf': torch.from_numpy(np.stack(sdfs, 0)),
+        'known': torch.from_numpy(np.stack(knowns, 0)),
+        'hierarchy': [torch.from_numpy(np.stack(h, 0)) for h in hier],
+    }

@@ -1,0 +1,102 @@
+"""Generates tests/golden/*.npz by running the REAL reference code (read-only /root/reference) in the
+authoring container.  Not run on the GPU box (the reference does not travel); the fixtures do.
+
+What is executed unmodified:  /root/reference/torch/model.py (GenModel and all sub-modules),
+/root/reference/torch/loss.py (compute_targets, compute_loss), data_util.preprocess_sdf_pt.
+What is substituted: `sparseconvnet` := oracle/scn_oracle (the reference's sparse-op dependency is not
+vendored); `plyfile` / `marching_cubes_cpp` := empty stubs (visualisation only, imported
+at module import time by data_util.py:7,9); torch.Tensor.cuda := identity (loss.py:41 hard-codes .cuda()).
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import scn_oracle  # noqa: E402
+
+sys.modules['sparseconvnet'] = scn_oracle
+sys.modules['plyfile'] = types.ModuleType('plyfile')
+sys.modules['marching_cubes_cpp'] = types.ModuleType('marching_cubes_cpp')
+torch.Tensor.cuda = lambda self, *a, **k: self
+sys.path.insert(0, '/root/reference/torch')
+import model as ref_model  # noqa: E402
+import loss as ref_loss  # noqa: E402
+
+from util import param_fill  # noqa: E402
+from sgnn_amd import synth  # noqa: E402
+
+
+def to_np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def run_case(name, dims, batch, cfg, occupancy, train, weight_missing_geo, scene_mode=False):
+    torch.manual_seed(0)
+    model_dim = dims if not scene_mode else (32, 32, 32)
+    m = ref_model.GenModel(8, model_dim, 1, 16, 16, 4, True, True, 1, 1)
+    param_fill(m, seed=cfg)
+    m.train(train)
+    data = synth.make_batch(batch, dims, cfg=cfg, occupancy=occupancy)
+    locs, feats = data['input']
+    out = {'dims': np.array(dims), 'batch': batch, 'cfg': cfg, 'occupancy': occupancy, 'train': int(train),
+           'weight_missing_geo': weight_missing_geo, 'scene_mode': int(scene_mode),
+           'in_locs': to_np(locs), 'in_feats': to_np(feats)}
+    loss_weights = np.ones(5, dtype=np.float32)
+    if scene_mode:
+        m.update_sizes(np.array(dims), np.array(dims) // 8)   # test_scene.py:78
+        with torch.no_grad():
+            output_sdf, output_occs = m([locs, feats], loss_weights)
+    else:
+        sdf, known, hier = data['sdf'].clone(), data['known'], [h.clone() for h in data['hierarchy']]
+        tgt_sdf, tgt_occs, tgt_hier = ref_loss.compute_targets(sdf, hier, 4, 3, True, known)
+        output_sdf, output_occs = m([locs, feats], loss_weights)
+        loss, losses = ref_loss.compute_loss(output_sdf, output_occs, tgt_sdf, tgt_occs, tgt_hier, loss_weights, 3,
+                                             True, weight_missing_geo, locs, True, known)
+        loss.backward()
+        out['loss'] = np.float64(loss.item())
+        out['losses'] = np.array(losses, dtype=np.float64)
+        names, gsum, gabs = [], [], []
+        for n, p in m.named_parameters():
+            names.append(n)
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            gsum.append(g.double().sum().item())
+            gabs.append(g.double().abs().sum().item())
+        out['grad_names'] = np.array(names)
+        out['grad_sum'] = np.array(gsum)
+        out['grad_abssum'] = np.array(gabs)
+        for n in ['encoder.process_sparse.0.p1.weight', 'encoder.process_sparse.2.p3.0.weight',
+                  'refinement.0.p1.weight', 'refinement.2.n1.weight', 'refinement.1.p2.2.1.1.weight',
+                  'surfacepred.linear.weight', 'refinement.2.linear.weight', 'surfacepred.p3.weight',
+                  'encoder.occpred.0.weight']:
+            gr = dict(m.named_parameters())[n].grad
+            if gr is not None:   # unreached levels (empty prediction) leave no gradient
+                out['grad::' + n] = to_np(gr)
+        for n, b in m.named_buffers():
+            if n.endswith('running_mean') and ('refinement.1.p3' in n or 'process_sparse.0.p2.2' in n):
+                out['buf::' + n] = to_np(b)
+    for h, (l, v) in enumerate(output_occs):
+        out['occ%d_locs' % h] = to_np(l).astype(np.int64)
+        out['occ%d_vals' % h] = to_np(v).astype(np.float32)
+    out['sdf_locs'] = to_np(output_sdf[0]).astype(np.int64)
+    out['sdf_vals'] = to_np(output_sdf[1]).astype(np.float32)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(name, 'sites', locs.shape[0], [out['occ%d_locs' % h].shape[0] for h in range(4)], out['sdf_locs'].shape[0],
+          'loss' in out and out['loss'], os.path.getsize(path) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    run_case('genmodel_train_32', (32, 32, 32), 2, 11, 0.08, True, 5.0)
+    run_case('genmodel_train_empty', (64, 32, 32), 2, 12, 0.06, True, 1.0)   # coarse mask empty: every later level is []
+    run_case('genmodel_train_rect', (64, 32, 32), 2, 14, 0.06, True, 1.0)
+    run_case('genmodel_scene_eval', (32, 64, 32), 1, 13, 0.06, False, 1.0, scene_mode=True)

@@ -35,3 +35,37 @@ def triples_from_table(table, K, ld, n):
     k, j = np.nonzero(t >= 0)
     tri = np.stack([k, t[k, j], j], 1).astype(np.int64)
     return tri[np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0]))]
+
+
+def param_fill(model, seed=0):
+    """Deterministic, name-keyed parameter/buffer values so that the reference model (in the authoring
+    container), the oracle model and the HIP model can all be given identical weights without storing a
+    state dict in the fixtures.  Scales follow the modules' own initialisers."""
+    import zlib
+    sd = model.state_dict()
+    new = {}
+    for name, t in sd.items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        shp = tuple(t.shape)
+        leaf = name.rsplit('.', 1)[-1]
+        if leaf == 'num_batches_tracked':
+            v = np.zeros(shp)
+        elif leaf == 'running_mean':
+            v = rng.uniform(-0.1, 0.1, shp)
+        elif leaf == 'running_var':
+            v = rng.uniform(0.5, 1.5, shp)
+        elif leaf == 'bias':
+            v = rng.uniform(-0.2, 0.2, shp)
+        elif len(shp) == 1:            # BN scale
+            v = rng.uniform(0.5, 1.5, shp)
+        elif len(shp) == 3:            # sparse conv (K, nIn, nOut)
+            v = rng.normal(0, (2.0 / (shp[0] * shp[1])) ** 0.5, shp)
+        elif len(shp) == 5:            # dense conv
+            v = rng.normal(0, (2.0 / (shp[1] * shp[2] * shp[3] * shp[4])) ** 0.5, shp)
+        elif len(shp) == 2:            # linear (out, in)
+            v = rng.normal(0, (1.0 / shp[1]) ** 0.5, shp)
+        else:
+            raise ValueError('unexpected parameter %s %s' % (name, shp))
+        new[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
+    model.load_state_dict(new, strict=True)
+    return model

@@ -1,0 +1,113 @@
+"""Targets and hierarchical loss — counterpart of torch/loss.py:15-32 (compute_targets), :35-48
+(compute_weights_missing_geo), :58-82 (BCE sparse-vs-dense), :122-157 (log-L1), :160-199 (compute_loss),
+and torch/data_util.py:151-154 (preprocess_sdf_pt).  batched=True semantics only (what train.py:262-266
+uses).  Device-agnostic torch ops: this is the caller of the hot path (SURVEY.md §8 row a-H); fusing it
+into HIP kernels is row f1 ("next").
+"""
+import torch
+import torch.nn.functional as F
+
+UNK_THRESH = 2
+UNK_ID = -1
+
+
+def preprocess_sdf_pt(sdf, truncation):
+    return sdf.clamp_(-truncation, truncation)
+
+
+def compute_targets(target, hierarchy, num_hierarchy_levels, truncation, use_loss_masking, known):
+    assert target.dim() == 5
+    L = num_hierarchy_levels
+    target_for_occs, target_for_hier = [None] * L, [None] * L
+    target_for_sdf = preprocess_sdf_pt(target, truncation)
+    target_for_hier[-1] = target.clone()
+    occ = (torch.abs(target_for_sdf) < truncation).float()
+    if use_loss_masking:
+        occ[known >= UNK_THRESH] = UNK_ID
+    target_for_occs[-1] = occ
+    for h in range(L - 2, -1, -1):
+        target_for_occs[h] = F.max_pool3d(target_for_occs[h + 1], kernel_size=2)
+        target_for_hier[h] = preprocess_sdf_pt(hierarchy[h], truncation)
+    return target_for_sdf, target_for_occs, target_for_hier
+
+
+def _flat(locs, dims):
+    return ((locs[:, 3] * dims[0] + locs[:, 0]) * dims[1] + locs[:, 1]) * dims[2] + locs[:, 2]
+
+
+def compute_weights_missing_geo(weight_missing_geo, input_locs, target_for_occs, truncation):
+    L = len(target_for_occs)
+    weights = [None] * L
+    dims = target_for_occs[-1].shape[2:]
+    w = torch.ones(target_for_occs[-1].shape, dtype=torch.int32, device=target_for_occs[-1].device)
+    w.view(-1)[_flat(input_locs.to(w.device), dims)] += 1
+    w[torch.abs(target_for_occs[-1]) <= truncation] += 3
+    weights[-1] = (w == 4).float() * (weight_missing_geo - 1) + 1
+    for h in range(L - 2, -1, -1):
+        weights[h] = weights[h + 1][:, :, ::2, ::2, ::2].contiguous()
+    return weights
+
+
+def apply_log_transform(sdf):
+    return torch.sign(sdf) * torch.log(torch.abs(sdf) + 1)
+
+
+def compute_bce_sparse_dense(sparse_pred_locs, sparse_pred_vals, dense_tgts, weights, use_loss_masking):
+    assert dense_tgts.dim() == 5 and dense_tgts.shape[1] == 1
+    fl = _flat(sparse_pred_locs, dense_tgts.shape[2:])
+    pred, tgt = sparse_pred_vals.reshape(-1), dense_tgts.view(-1)[fl]
+    w = None if weights is None else weights.view(-1)[fl]
+    if use_loss_masking:
+        m = tgt != UNK_ID
+        pred, tgt = pred[m], tgt[m]
+        w = None if w is None else w[m]
+    else:
+        tgt = torch.where(tgt == UNK_ID, torch.zeros_like(tgt), tgt)
+    return F.binary_cross_entropy_with_logits(pred, tgt, weight=w)
+
+
+def compute_l1_predsurf_sparse_dense(sparse_pred_locs, sparse_pred_vals, dense_tgts, weights, use_log_transform,
+                                     use_loss_masking, known):
+    assert dense_tgts.dim() == 5 and dense_tgts.shape[1] == 1
+    fl = _flat(sparse_pred_locs, dense_tgts.shape[2:])
+    pred, tgt = sparse_pred_vals.reshape(-1), dense_tgts.view(-1)[fl]
+    w = None if weights is None else weights.view(-1)[fl]
+    if use_loss_masking:
+        m = (known < UNK_THRESH).view(-1)[fl]
+        pred, tgt = pred[m], tgt[m]
+        w = None if w is None else w[m]
+    if use_log_transform:
+        pred, tgt = apply_log_transform(pred), apply_log_transform(tgt)
+    d = torch.abs(pred - tgt)
+    return torch.mean(d * w) if w is not None else torch.mean(d)
+
+
+def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights, truncation,
+                 use_log_transform=True, weight_missing_geo=1, input_locs=None, use_loss_masking=True, known=None):
+    """Returns (loss tensor, per-level loss tensors or -1).  Unlike loss.py:185 the per-level values are
+    left on the device (no .item() sync inside the step); callers convert when they log."""
+    assert len(output_occs) == len(target_for_occs)
+    loss, losses = 0.0, []
+    weights = [None] * len(target_for_occs)
+    if weight_missing_geo > 1:
+        weights = compute_weights_missing_geo(weight_missing_geo, input_locs, target_for_occs, truncation)
+    for h in range(len(output_occs)):
+        if len(output_occs[h][0]) == 0 or loss_weights[h] == 0:
+            losses.append(-1)
+            continue
+        locs, vals = output_occs[h]
+        l_occ = compute_bce_sparse_dense(locs, vals[:, 0], target_for_occs[h], weights[h], use_loss_masking)
+        cur_known = None if not use_loss_masking else (target_for_occs[h] == UNK_ID) * UNK_THRESH
+        l_sdf = compute_l1_predsurf_sparse_dense(locs, vals[:, 1], target_for_hier[h], weights[h], use_log_transform,
+                                                 use_loss_masking, cur_known)
+        cur = l_occ + l_sdf
+        loss = loss + float(loss_weights[h]) * cur
+        losses.append(cur.detach())
+    if len(output_sdf[0]) > 0 and loss_weights[-1] > 0:
+        cur = compute_l1_predsurf_sparse_dense(output_sdf[0], output_sdf[1], target_for_sdf, weights[-1],
+                                               use_log_transform, use_loss_masking, known)
+        loss = loss + float(loss_weights[-1]) * cur
+        losses.append(cur.detach())
+    else:
+        losses.append(-1)
+    return loss, losses

@@ -1,0 +1,143 @@
+"""End-to-end parity of the HIP GenModel (sgnn_amd/model.py) against
+  (1) golden vectors produced by the real reference model.py/loss.py (tests/golden), and
+  (2) the CPU oracle model on fresh seeded inputs (forward + loss + every parameter gradient).
+Site lists (active-site indices) must be bit-identical; logits within 1e-4 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import model_oracle as mo
+from util import param_fill
+from sgnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-4
+
+
+def hip_model(dims, cfg, train):
+    from sgnn_amd.model import GenModel
+    m = GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1)
+    param_fill(m, seed=cfg)
+    m.train(train)
+    return m.cuda()
+
+
+def check_levels(oocc, osdf, g_occ, g_sdf):
+    for h in range(4):
+        gl, gv = g_occ[h]
+        if len(gl) == 0:
+            assert len(oocc[h][0]) == 0, 'level %d should be empty' % h
+            continue
+        assert np.array_equal(oocc[h][0].cpu().numpy(), gl), 'level %d site list differs' % h
+        assert np.abs(oocc[h][1].detach().cpu().numpy() - gv).max() < TOL, 'level %d logits' % h
+    gl, gv = g_sdf
+    if len(gl):
+        assert np.array_equal(osdf[0].cpu().numpy(), gl)
+        assert np.abs(osdf[1].detach().cpu().numpy() - gv).max() < TOL
+    else:
+        assert len(osdf[0]) == 0
+
+
+@pytest.mark.parametrize('name', ['genmodel_train_32', 'genmodel_train_rect', 'genmodel_train_empty',
+                                  'genmodel_scene_eval'])
+def test_hip_model_matches_reference_golden(name):
+    from sgnn_amd import loss as L
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    dims = tuple(int(d) for d in g['dims'])
+    scene = bool(g['scene_mode'])
+    m = hip_model((32, 32, 32) if scene else dims, int(g['cfg']), bool(g['train']))
+    data = synth.make_batch(int(g['batch']), dims, cfg=int(g['cfg']), occupancy=float(g['occupancy']))
+    locs, feats = data['input']
+    lw = np.ones(5, dtype=np.float32)
+    g_occ = [(g['occ%d_locs' % h], g['occ%d_vals' % h]) for h in range(4)]
+    g_sdf = (g['sdf_locs'], g['sdf_vals'])
+    if scene:
+        m.update_sizes(np.array(dims), np.array(dims) // 8)
+        with torch.no_grad():
+            osdf, oocc = m([locs, feats.cuda()], lw)   # coords may stay on the host (test_scene.py:80-82)
+        check_levels(oocc, osdf, g_occ, g_sdf)
+        return
+    sdf, known = data['sdf'].cuda(), data['known'].cuda()
+    hier = [h.cuda() for h in data['hierarchy']]
+    t_sdf, t_occ, t_hier = L.compute_targets(sdf, hier, 4, 3, True, known)
+    osdf, oocc = m([locs.cuda(), feats.cuda()], lw)
+    check_levels(oocc, osdf, g_occ, g_sdf)
+    loss, losses = L.compute_loss(osdf, oocc, t_sdf, t_occ, t_hier, lw, 3, True, float(g['weight_missing_geo']),
+                                  locs.cuda(), True, known)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss'])))
+    params = dict(m.named_parameters())
+    for n, a in zip(g['grad_names'], g['grad_abssum']):
+        gr = params[str(n)].grad
+        got = 0.0 if gr is None else gr.double().abs().sum().item()
+        assert abs(got - a) <= 2e-3 * max(1.0, a), (str(n), got, a)
+    for k in g.files:
+        if k.startswith('grad::'):
+            gr = params[k[6:]].grad.cpu().numpy()
+            assert np.abs(gr - g[k]).max() <= 2e-4 * max(1.0, np.abs(g[k]).max()), k
+        if k.startswith('buf::'):
+            assert np.abs(dict(m.named_buffers())[k[5:]].cpu().numpy() - g[k]).max() < 1e-5, k
+
+
+def test_hip_model_vs_oracle_fresh_inputs_all_grads():
+    from sgnn_amd import loss as L
+    dims, cfg, B = (32, 32, 32), 21, 3
+    data = synth.make_batch(B, dims, cfg=cfg, occupancy=0.07)
+    locs, feats = data['input']
+    lw = np.ones(5, dtype=np.float32)
+    # oracle
+    om = mo.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1)
+    param_fill(om, seed=cfg)
+    om.train()
+    t = mo.compute_targets(data['sdf'].clone(), [h.clone() for h in data['hierarchy']], 4, 3, True, data['known'])
+    osdf, oocc = om([locs, feats], lw)
+    oloss, _ = mo.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, locs, True, data['known'])
+    oloss.backward()
+    # HIP
+    hm = hip_model(dims, cfg, True)
+    th = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
+                           data['known'].cuda())
+    hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw)
+    hloss, _ = L.compute_loss(hsdf, hocc, th[0], th[1], th[2], lw, 3, True, 5.0, locs.cuda(), True,
+                              data['known'].cuda())
+    hloss.backward()
+    check_levels(hocc, hsdf, [(o[0].numpy(), o[1].detach().numpy()) for o in oocc],
+                 (osdf[0].numpy(), osdf[1].detach().numpy()))
+    assert abs(hloss.item() - oloss.item()) < 1e-4 * max(1.0, abs(oloss.item()))
+    hp = dict(hm.named_parameters())
+    for n, p in om.named_parameters():
+        assert p.grad is not None and hp[n].grad is not None, n
+        scale = max(1.0, p.grad.abs().max().item())
+        assert (p.grad - hp[n].grad.cpu()).abs().max().item() < 5e-4 * scale, n
+    ob = dict(om.named_buffers())
+    for n, b in hm.named_buffers():
+        if b.dtype.is_floating_point:
+            assert (ob[n] - b.cpu()).abs().max().item() < 1e-4, n
+
+
+def test_state_dict_interchangeable_with_oracle_layout():
+    from sgnn_amd.model import GenModel
+    hm = GenModel(8, (64, 64, 64), 1, 16, 16, 4, True, True, 1, 1)
+    om = mo.GenModel(8, (64, 64, 64), 1, 16, 16, 4, True, True, 1, 1)
+    assert list(hm.state_dict().keys()) == list(om.state_dict().keys())
+    hm.load_state_dict(om.state_dict(), strict=True)
+    assert sum(p.numel() for p in hm.parameters()) == 643735
+
+
+def test_train_step_decreases_loss():
+    from sgnn_amd.train import train_step, to_device
+    torch.manual_seed(0)
+    from sgnn_amd.model import GenModel
+    m = GenModel(8, (32, 32, 32), 1, 16, 16, 4, True, True, 1, 1).cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    batch = to_device(synth.make_batch(2, (32, 32, 32), cfg=31, occupancy=0.08), 'cuda')
+    lw = np.ones(5, dtype=np.float32)
+    first = last = None
+    for it in range(8):
+        loss, _, _ = train_step(m, opt, batch, lw)
+        last = loss.item()
+        first = last if first is None else first
+    assert np.isfinite(last) and last < first

@@ -89,6 +89,21 @@ def run_case(name, dims, batch, cfg, occupancy, train, weight_missing_geo, scene
         out['occ%d_vals' % h] = to_np(v).astype(np.float32)
     out['sdf_locs'] = to_np(output_sdf[0]).astype(np.int64)
     out['sdf_vals'] = to_np(output_sdf[1]).astype(np.float32)
+    # the same reference code evaluated in float64 = the exact value of the reference's function; the fp32
+    # run above is itself up to ~1e-4 away from it, so GPU parity is judged against these (tolerance 1e-4)
+    m64 = ref_model.GenModel(8, model_dim, 1, 16, 16, 4, True, True, 1, 1)
+    param_fill(m64, seed=cfg)
+    m64.train(train)
+    m64 = m64.double()
+    if scene_mode:
+        m64.update_sizes(np.array(dims), np.array(dims) // 8)
+    with torch.no_grad():
+        sdf64, occs64 = m64([locs, feats.double()], loss_weights)
+    for h, (l, v) in enumerate(occs64):
+        assert np.array_equal(to_np(l).astype(np.int64), out['occ%d_locs' % h]), 'fp32/fp64 masks differ at level %d' % h
+        out['occ%d_vals64' % h] = to_np(v).astype(np.float64)
+    assert np.array_equal(to_np(sdf64[0]).astype(np.int64), out['sdf_locs'])
+    out['sdf_vals64'] = to_np(sdf64[1]).astype(np.float64)
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print(name, 'sites', locs.shape[0], [out['occ%d_locs' % h].shape[0] for h in range(4)], out['sdf_locs'].shape[0],

@@ -25,18 +25,21 @@ def hip_model(dims, cfg, train):
     return m.cuda()
 
 
-def check_levels(oocc, osdf, g_occ, g_sdf):
+def check_levels(oocc, osdf, g_occ, g_sdf, tol=TOL):
+    """Site lists bit-exact; logits within `tol` of the expected values."""
     for h in range(4):
         gl, gv = g_occ[h]
         if len(gl) == 0:
             assert len(oocc[h][0]) == 0, 'level %d should be empty' % h
             continue
         assert np.array_equal(oocc[h][0].cpu().numpy(), gl), 'level %d site list differs' % h
-        assert np.abs(oocc[h][1].detach().cpu().numpy() - gv).max() < TOL, 'level %d logits' % h
+        err = np.abs(oocc[h][1].detach().cpu().numpy().astype(np.float64) - gv).max()
+        assert err < tol, 'level %d logits: %g' % (h, err)
     gl, gv = g_sdf
     if len(gl):
         assert np.array_equal(osdf[0].cpu().numpy(), gl)
-        assert np.abs(osdf[1].detach().cpu().numpy() - gv).max() < TOL
+        err = np.abs(osdf[1].detach().cpu().numpy().astype(np.float64) - gv).max()
+        assert err < tol, 'final sdf: %g' % err
     else:
         assert len(osdf[0]) == 0
 
@@ -52,19 +55,25 @@ def test_hip_model_matches_reference_golden(name):
     data = synth.make_batch(int(g['batch']), dims, cfg=int(g['cfg']), occupancy=float(g['occupancy']))
     locs, feats = data['input']
     lw = np.ones(5, dtype=np.float32)
-    g_occ = [(g['occ%d_locs' % h], g['occ%d_vals' % h]) for h in range(4)]
-    g_sdf = (g['sdf_locs'], g['sdf_vals'])
+    # float64 evaluation of the reference code = exact value of its function: tolerance 1e-4 (north_star).
+    # The reference's own fp32 run is up to ~1e-4 from that (see make_golden.py), so against it 2e-4.
+    g_occ = [(g['occ%d_locs' % h], g['occ%d_vals64' % h]) for h in range(4)]
+    g_sdf = (g['sdf_locs'], g['sdf_vals64'])
+    g_occ32 = [(g['occ%d_locs' % h], g['occ%d_vals' % h]) for h in range(4)]
+    g_sdf32 = (g['sdf_locs'], g['sdf_vals'])
     if scene:
         m.update_sizes(np.array(dims), np.array(dims) // 8)
         with torch.no_grad():
             osdf, oocc = m([locs, feats.cuda()], lw)   # coords may stay on the host (test_scene.py:80-82)
         check_levels(oocc, osdf, g_occ, g_sdf)
+        check_levels(oocc, osdf, g_occ32, g_sdf32, 2 * TOL)
         return
     sdf, known = data['sdf'].cuda(), data['known'].cuda()
     hier = [h.cuda() for h in data['hierarchy']]
     t_sdf, t_occ, t_hier = L.compute_targets(sdf, hier, 4, 3, True, known)
     osdf, oocc = m([locs.cuda(), feats.cuda()], lw)
     check_levels(oocc, osdf, g_occ, g_sdf)
+    check_levels(oocc, osdf, g_occ32, g_sdf32, 2 * TOL)
     loss, losses = L.compute_loss(osdf, oocc, t_sdf, t_occ, t_hier, lw, 3, True, float(g['weight_missing_geo']),
                                   locs.cuda(), True, known)
     loss.backward()
@@ -88,12 +97,14 @@ def test_hip_model_vs_oracle_fresh_inputs_all_grads():
     data = synth.make_batch(B, dims, cfg=cfg, occupancy=0.07)
     locs, feats = data['input']
     lw = np.ones(5, dtype=np.float32)
-    # oracle
+    # oracle, evaluated in float64 (exact value of the reference function; tolerance 1e-4 on logits)
     om = mo.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1)
     param_fill(om, seed=cfg)
     om.train()
-    t = mo.compute_targets(data['sdf'].clone(), [h.clone() for h in data['hierarchy']], 4, 3, True, data['known'])
-    osdf, oocc = om([locs, feats], lw)
+    om = om.double()
+    t = mo.compute_targets(data['sdf'].clone().double(), [h.clone().double() for h in data['hierarchy']], 4, 3, True,
+                           data['known'])
+    osdf, oocc = om([locs, feats.double()], lw)
     oloss, _ = mo.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, locs, True, data['known'])
     oloss.backward()
     # HIP
@@ -111,11 +122,11 @@ def test_hip_model_vs_oracle_fresh_inputs_all_grads():
     for n, p in om.named_parameters():
         assert p.grad is not None and hp[n].grad is not None, n
         scale = max(1.0, p.grad.abs().max().item())
-        assert (p.grad - hp[n].grad.cpu()).abs().max().item() < 5e-4 * scale, n
+        assert (p.grad - hp[n].grad.cpu().double()).abs().max().item() < 5e-4 * scale, n
     ob = dict(om.named_buffers())
     for n, b in hm.named_buffers():
         if b.dtype.is_floating_point:
-            assert (ob[n] - b.cpu()).abs().max().item() < 1e-4, n
+            assert (ob[n] - b.cpu().double()).abs().max().item() < 1e-4, n
 
 
 def test_state_dict_interchangeable_with_oracle_layout():

@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py — headline metric of BASELINE.json on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input: compute_targets + GenModel forward +
+hierarchical loss + backward + Adam step (train.py:245-268) on 32 synthetic 64^3 TSDF blocks at ~5 %
+occupancy PER GPU (BASELINE.json configs[1]; weak scaling: N GPUs process N*32 independent blocks, the
+only exchange is one flat fp32 gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+FP32_MFMA_PEAK_TF = 157.3    # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='blocks per GPU')
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--occupancy', type=float, default=0.05)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
+    return ap.parse_args()
+
+
+def conv_alg_bytes(kind, n_out, cin, cout, K):
+    """Algorithmic HBM bytes of one conv launch: feature slab read once, output written once,
+    the K x n_out int32 rule table, the weights.  dW reads x and dy and writes K*cin*cout."""
+    if kind == 0:
+        return 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
+    return 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
+
+
+def collect_prof(lib):
+    n = lib.sgnn_prof_count()
+    kind, cin, cout, K, flags = (ctypes.c_int() for _ in range(5))
+    n_out = ctypes.c_int64()
+    ms = ctypes.c_float()
+    agg = {}
+    for i in range(n):
+        rc = lib.sgnn_prof_get(i, ctypes.byref(kind), ctypes.byref(n_out), ctypes.byref(cin), ctypes.byref(cout),
+                               ctypes.byref(K), ctypes.byref(flags), ctypes.byref(ms))
+        if rc != 0:
+            continue
+        key = (kind.value, cin.value, cout.value, K.value)
+        a = agg.setdefault(key, {'launches': 0, 'ms': 0.0, 'bytes': 0.0, 'flops': 0.0})
+        a['launches'] += 1
+        a['ms'] += ms.value
+        a['bytes'] += conv_alg_bytes(kind.value, n_out.value, cin.value, cout.value, K.value)
+        a['flops'] += 2.0 * n_out.value * K.value * cin.value * cout.value
+    return agg
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference algorithm: per-offset gather -> mm -> index_add, torch CPU)
+    timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import model_oracle as mo
+    from sgnn_amd import synth
+    torch.manual_seed(0)
+    nthreads = torch.get_num_threads()
+    nb = args.cpu_blocks
+    m = mo.GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    data = synth.make_batch(nb, (args.dim,) * 3, cfg=2, occupancy=args.occupancy)
+    lw = np.ones(5, dtype=np.float32)
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        t = mo.compute_targets(data['sdf'].clone(), [h.clone() for h in data['hierarchy']], 4, 3, True, data['known'])
+        opt.zero_grad()
+        osdf, oocc = m(data['input'], lw)
+        loss, _ = mo.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, data['input'][0], True, data['known'])
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {'value': nb / best, 'unit': 'blocks/s', 'cores': nthreads, 'kind': 'port',
+            'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel fwd+bwd+Adam on the torch-CPU oracle, '
+                      'best of 2 timed steps after 1 warm-up (%.2f s/step)' % (nb, args.dim, best)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from sgnn_amd import _lib, synth
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce
+    lib = _lib.load()
+    _lib.require_gpu()
+
+    torch.manual_seed(1234)  # same initial weights on every rank
+    model = GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sync = FlatGradAllReduce(model.parameters()) if world > 1 else None
+    lw = np.ones(5, dtype=np.float32)
+    # two distinct resident batches per rank, alternated, so no step sees cached results
+    batches = [to_device(synth.make_batch(args.batch, (args.dim,) * 3, cfg=2,
+                                          first_block=(rank * 2 + j) * args.batch, occupancy=args.occupancy), dev)
+               for j in range(2)]
+    n_sites = [int(b['input'][0].shape[0]) for b in batches]
+
+    def step(i):
+        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.sgnn_prof_enable(1 << 15)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = None
+    for i in range(args.steps):
+        _, _, outs = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.sgnn_prof_disable()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        agg = collect_prof(lib)
+        dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
+        roof = None
+        kernels = []
+        for key, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+            kernels.append({'kernel': '%s<%d,%d>K%d' % ('conv_fwd' if key[0] == 0 else 'conv_dw', key[1], key[2], key[3]),
+                            'launches': a['launches'], 'ms_total': round(a['ms'], 3),
+                            'GBps': round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1) if a['ms'] > 0 else None,
+                            'TFLOPs': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2) if a['ms'] > 0 else None})
+        if dom is not None and dom['ms'] > 0:
+            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'kernel': kernels[0]['kernel'], 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2), 'launches': dom['launches'],
+                    'mfma_TFLOPs': kernels[0]['TFLOPs'], 'mfma_frac_of_fp32_peak': round(kernels[0]['TFLOPs'] / FP32_MFMA_PEAK_TF, 4),
+                    'conv_ms_per_step': round(sum(a['ms'] for a in agg.values()) / args.steps, 3),
+                    'top_kernels': kernels[:6]}
+        levels = None
+        if outs is not None:
+            levels = [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs[1]] + [int(outs[0][0].shape[0]) if len(outs[0][0]) else 0]
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(args)
+        total_blocks = args.batch * world * args.steps
+        res = {
+            'metric': 'TSDF blocks/sec fwd+bwd (64^3@5% occ, bs32)', 'value': round(total_blocks / elapsed, 2),
+            'unit': 'blocks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: full SG-NN 4-level GenModel (643735 params, random init), %d synthetic '
+                                   '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam'
+                                   % (args.batch, args.dim, 100 * args.occupancy),
+                       'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
+                       'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        if cpu:
+            res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

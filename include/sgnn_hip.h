@@ -201,6 +201,17 @@ int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, i
 int sgnn_dense_to_sparse(const float *dense, const int32_t *coords, int64_t n, int c, float *feats,
                          int batch, int d0, int d1, int d2, sgnn_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
+ * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
+ * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.
+ * ------------------------------------------------------------------------- */
+int sgnn_prof_enable(int max_records);
+int sgnn_prof_disable(void);
+int sgnn_prof_count(void);
+int sgnn_prof_dropped(void);
+int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *cout, int *K, int *flags, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

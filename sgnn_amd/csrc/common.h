@@ -8,6 +8,9 @@
 #define SGNN_EXPORT extern "C" __attribute__((visibility("default")))
 
 void sgnn_set_error(const char *fmt, ...);
+// prof.hip: optional HIP-event timing of conv launches (slot < 0 = not recording)
+int sgnn_prof_begin_launch(int kind, int64_t n_out, int cin, int cout, int K, int flags, hipStream_t s);
+void sgnn_prof_end_launch(int slot, hipStream_t s);
 
 #define SGNN_CHECK_ARG(cond)                                                    \
   do {                                                                          \

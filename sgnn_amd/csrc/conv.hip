@@ -192,6 +192,7 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, co
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
   bool done = false;
+  const int prof = sgnn_prof_begin_launch(0, n_out, cin, cout, K, flags, s);
 #define X(CI, CO)                                                                                       \
   if (!done && cin == CI && cout == CO) {                                                               \
     hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, w, table, ld, K, n_out, y, \
@@ -205,6 +206,7 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, co
     hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
                        table, ld, n_out, cout, y, flags, in_shift);
   }
+  sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -368,8 +370,10 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, i
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
       return SGNN_ENOWS;                                                                                   \
     }                                                                                                      \
+    const int prof = sgnn_prof_begin_launch(1, n_out, cin, cout, K, 0, s);                                 \
     hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + DW_KPB - 1) / DW_KPB)),   \
                        dim3(256), 0, s, x, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);           \
+    sgnn_prof_end_launch(prof, s);                                                                         \
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,                \
                        (const float *)ws, nblk, elems, dw);                                                \
     done = true;                                                                                           \

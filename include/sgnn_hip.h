@@ -202,6 +202,18 @@ int sgnn_dense_to_sparse(const float *dense, const int32_t *coords, int64_t n, i
                          int batch, int d0, int d1, int d2, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Per-site linear heads y[r] = W x[r] + b, W (cout, cin) row-major, cout <= 2
+ * (nn.Linear(nf,1) x2 fused, torch/model.py:190-191,230-231; SurfacePrediction.linear :258,271).
+ * bwd: dx (may be NULL), dw (cout, cin), dbias (may be NULL); deterministic reduction via ws.
+ * ------------------------------------------------------------------------- */
+int64_t sgnn_linear_ws_bytes(int64_t n, int cin, int cout);
+int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float *w, const float *bias, int cout,
+                    float *y, sgnn_stream_t stream);
+int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int cin, const float *w, int cout,
+                    float *dx, float *dw, float *dbias, void *ws, int64_t ws_bytes,
+                    sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
  * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
  * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.

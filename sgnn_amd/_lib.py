@@ -49,6 +49,9 @@ PROTOTYPES = {
     'sgnn_compact_mask': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_sparse_to_dense': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_dense_to_sparse': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'sgnn_linear_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
+    'sgnn_linear_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    'sgnn_linear_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_prof_enable': (c_i32, [c_i32]),
     'sgnn_prof_disable': (c_i32, []),
     'sgnn_prof_count': (c_i32, []),

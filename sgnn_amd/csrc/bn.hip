@@ -146,19 +146,39 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
   }
 }
 
-// one workgroup: fixed-order sum of block partials, then the per-channel statistics
+// fixed-order tree sum of the block partials of one channel: one workgroup per channel, 256 lanes
+__device__ __forceinline__ void bn_reduce_channel(const double *__restrict__ partial, int nblk, int c, int ch,
+                                                  double *sh, double &s, double &s2) {
+  double a = 0.0, b = 0.0;
+  for (int blk = threadIdx.x; blk < nblk; blk += 256) {
+    a += partial[((size_t)blk * 2 + 0) * c + ch];
+    b += partial[((size_t)blk * 2 + 1) * c + ch];
+  }
+  sh[threadIdx.x] = a;
+  sh[256 + threadIdx.x] = b;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) {
+      sh[threadIdx.x] += sh[threadIdx.x + d];
+      sh[256 + threadIdx.x] += sh[256 + threadIdx.x + d];
+    }
+    __syncthreads();
+  }
+  s = sh[0];
+  s2 = sh[256];
+}
+
 __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const double *__restrict__ partial, int nblk,
                                                         int64_t n, int c, float eps, float momentum,
                                                         float *__restrict__ running_mean,
                                                         float *__restrict__ running_var,
                                                         float *__restrict__ save_mean,
                                                         float *__restrict__ save_invstd) {
-  for (int ch = threadIdx.x; ch < c; ch += 256) {
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s += partial[((size_t)b * 2 + 0) * c + ch];
-      s2 += partial[((size_t)b * 2 + 1) * c + ch];
-    }
+  __shared__ double sh[512];
+  const int ch = blockIdx.x;
+  double s, s2;
+  bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
+  if (threadIdx.x == 0) {
     const double mean = s / (double)n;
     double var = s2 / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -207,16 +227,15 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
   }
 }
 
-// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); also dgamma/dbeta
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); also dgamma/dbeta.  One workgroup per channel.
 __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restrict__ partial, int nblk,
                                                         int64_t n, int c, float *__restrict__ dgamma,
                                                         float *__restrict__ dbeta, float *__restrict__ coef) {
-  for (int ch = threadIdx.x; ch < c; ch += 256) {
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s += partial[((size_t)b * 2 + 0) * c + ch];
-      s2 += partial[((size_t)b * 2 + 1) * c + ch];
-    }
+  __shared__ double sh[512];
+  const int ch = blockIdx.x;
+  double s, s2;
+  bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
+  if (threadIdx.x == 0) {
     if (dbeta) dbeta[ch] = (float)s;
     if (dgamma) dgamma[ch] = (float)s2;
     coef[ch] = (float)(s / (double)n);
@@ -258,7 +277,7 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
                             float leak, float *save_mean, float *save_invstd, float *y, void *ws,
                             int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  SGNN_CHECK_ARG(n >= 0 && c >= 1 && c <= 1024 && save_mean && save_invstd);
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
   const BnGeom g = bn_geom(c);
   if (training && n > 0) {
@@ -275,7 +294,7 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
     else
       hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
                          nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
@@ -303,7 +322,7 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
                             float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
                             sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  SGNN_CHECK_ARG(n >= 0 && c >= 1 && c <= 1024 && save_mean && save_invstd);
+  SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   if (n == 0) {
     if (dgamma) SGNN_HIP_TRY(hipMemsetAsync(dgamma, 0, c * sizeof(float), s));
     if (dbeta) SGNN_HIP_TRY(hipMemsetAsync(dbeta, 0, c * sizeof(float), s));
@@ -325,7 +344,7 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
   else
     hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
                        save_invstd, gamma, beta, leak, partial);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(1), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
                      coef);
   const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
   if (g.vec == 4)

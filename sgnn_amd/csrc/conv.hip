@@ -180,12 +180,13 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 
 #define CONV_FWD_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
-  X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4)
+  X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
+  X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
 SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                               int64_t n_out, int cout, float *y, int flags, int in_shift,
                               sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 27 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
+  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
                  in_shift < 31);
   if (n_out == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && table && y);
@@ -219,7 +220,12 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, co
 // Workgroup partials go to the workspace and are summed in fixed order by k_dw_reduce
 // (deterministic, no float atomics).
 // ---------------------------------------------------------------------------
-#define DW_KPB 9
+// offsets per workgroup: bounded by accumulator registers (KPB*MT*NT*4 VGPRs) and the LDS combine buffer
+template <int CIN, int COUT>
+struct DwCfg {
+  static constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
+  static constexpr int KPB = (MT * NT <= 3) ? 9 : ((MT * NT <= 6) ? 4 : 3);
+};
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, const float *__restrict__ dy,
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
                                                 int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift) {
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
+  constexpr int DW_KPB = DwCfg<CIN, COUT>::KPB;
   __shared__ float red[DW_KPB * MT * 16 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, q = lane >> 4;
@@ -306,13 +313,24 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
   }
 }
 
+// dw[e] = sum_b partial[b][e]: 32 consecutive elements per workgroup x 8 interleaved partial streams,
+// combined in fixed order through LDS (deterministic)
 __global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ partial, int64_t nblk,
                                                   int64_t elems, float *__restrict__ dw) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= elems) return;
+  __shared__ float red[8][32];
+  const int part = threadIdx.x >> 5, le = threadIdx.x & 31;
+  const int64_t e = (int64_t)blockIdx.x * 32 + le;
   float s = 0.f;
-  for (int64_t b = 0; b < nblk; ++b) s += partial[b * elems + e];
-  dw[e] = s;
+  if (e < elems)
+    for (int64_t b = part; b < nblk; b += 8) s += partial[b * elems + e];
+  red[part][le] = s;
+  __syncthreads();
+  if (part == 0 && e < elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][le];
+    dw[e] = t;
+  }
 }
 
 // generic fallback: one workgroup per (k, ci, co) triple would be wasteful; instead one thread per
@@ -347,12 +365,13 @@ SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin,
 }
 
 #define CONV_DW_CASES(X) \
-  X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16)
+  X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16) \
+  X(16, 24) X(24, 32) X(64, 32) X(56, 28)
 
 SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, int cout, const int32_t *table,
                                      int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
                                      int64_t ws_bytes, sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 27 && n_out >= 0 && ld >= n_out && dw &&
+  SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
                  in_shift >= 0 && in_shift < 31);
   hipStream_t s = (hipStream_t)stream;
   const int64_t elems = (int64_t)K * cin * cout;
@@ -371,10 +390,11 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, i
       return SGNN_ENOWS;                                                                                   \
     }                                                                                                      \
     const int prof = sgnn_prof_begin_launch(1, n_out, cin, cout, K, 0, s);                                 \
-    hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + DW_KPB - 1) / DW_KPB)),   \
+    constexpr int kpb_ = DwCfg<CI, CO>::KPB;                                                               \
+    hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)),       \
                        dim3(256), 0, s, x, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);           \
     sgnn_prof_end_launch(prof, s);                                                                         \
-    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s,                \
+    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                  \
                        (const float *)ws, nblk, elems, dw);                                                \
     done = true;                                                                                           \
   }

@@ -10,8 +10,11 @@ and the same module/attribute names, so a reference checkpoint's state_dict load
     (model.py:195-207, 233-247, 319-336) becomes expand8 / ballot-prefix-sum compaction kernels;
   * concat_skip's two dense int64 indicator volumes (model.py:338-355) become a hash-grid lookup on
     the encoder level's existing grid followed by one fused gather+concat;
-  * the dense 8^3 bottleneck (model.py:89-136) stays on torch.nn (MIOpen/rocBLAS): a plain dense
-    contraction where the vendor library is the right tool.
+  * the dense 8^3 bottleneck (model.py:89-136) keeps its nn.Conv3d / BatchNorm3d
+    modules as parameter holders (state-dict layout) but executes on the same HIP kernels: a dense volume
+    is a fully-active level, the k4/s2 (transposed) convolutions are rulebooks with 64 offsets, BatchNorm3d
+    is the row BatchNorm.  (MIOpen fell back to naive 3D kernels here: ~45 % of the step in
+    profiles/r01a_bench_kernel_stats_first.csv.)  Only the 1x1x1 convolutions remain plain rocBLAS GEMMs.
 """
 import numpy as np
 import torch
@@ -47,14 +50,14 @@ class SparseEncoderLayer(nn.Module):
         if not return_sparsetensor:
             self.p4 = scn.SparseToDense(3, nf)
 
-    def forward(self, x, batch_size=None):
+    def forward(self, x, batch_size=None, densify=True):
         if not self.input_sparsetensor:
             x = self.p0(x)
         skip = self.p2(self.p1(x))
         x = self.p3(skip)
         if self.return_sparsetensor:
             return x, [skip]
-        return self.p4(x, batch_size), [skip, x]
+        return (self.p4(x, batch_size) if densify else x), [skip, x]
 
 
 class TSDFEncoder(nn.Module):
@@ -86,20 +89,122 @@ class TSDFEncoder(nn.Module):
         self.sdfpred = nn.Sequential(nn.Conv3d(nf_out, 1, kernel_size=1, bias=False))
 
     def forward(self, x, batch_size=None):
+        """Returns (feat_rows (B*V, nf_out), out_rows (B*V, 2) [occ logit, sdf], skips, dense geometry);
+        rows are the dense coarse volume in batch-major raster order (== permute(0,2,3,4,1).view(-1, C))."""
         skips = []
-        for layer in self.process_sparse:
-            x, ft = layer(x, batch_size)
+        n_layers = len(self.process_sparse)
+        for i, layer in enumerate(self.process_sparse):
+            x, ft = layer(x, batch_size, densify=(i < n_layers - 1))
             if self.use_skip_sparse:
                 skips.extend(ft)
-        enc0 = self.encode_dense0(x)
-        enc1 = self.encode_dense1(enc0)
-        bott = self.bottleneck_dense2(enc1)
-        dec0 = self.decode_dense3(torch.cat([bott, enc1], 1) if self.use_skip_dense else bott)
-        x = self.decode_dense4(torch.cat([dec0, enc0], 1) if self.use_skip_dense else dec0)
-        x = self.final(x)
-        # both 1x1 heads in one pass; channel 0 = occupancy logit, 1 = sdf (model.py:163-165)
-        out = F.conv3d(x, torch.cat([self.occpred[0].weight, self.sdfpred[0].weight], 0))
-        return x, out, skips
+        g = x.grid()
+        dims = tuple(int(v) for v in x.spatial_size)
+        if batch_size is None:  # upstream SparseToDense semantics: B = max batch index + 1 (one host read)
+            batch_size = int(g.coords[:, 3].max().item()) + 1 if g.n else 0
+        geo = dense_geometry(batch_size, dims, x.features.device)
+        rows = F_.ScatterRows.apply(x.features, geo.grid.lookup(g.coords), geo.grid.n)
+        t0, t1 = geo.level(0), geo.level(1)
+        enc0 = _bn3d_relu(self.encode_dense0[1], _dense_conv(rows, self.encode_dense0[0], t0, down=True))
+        enc1 = _bn3d_relu(self.encode_dense1[1], _dense_conv(enc0, self.encode_dense1[0], t1, down=True))
+        bott = _bn3d_relu(self.bottleneck_dense2[1], _conv1x1(enc1, self.bottleneck_dense2[0]))
+        d_in = _join(bott, enc1) if self.use_skip_dense else bott
+        dec0 = _bn3d_relu(self.decode_dense3[1], _dense_conv(d_in, self.decode_dense3[0], t1, down=False))
+        d_in = _join(dec0, enc0) if self.use_skip_dense else dec0
+        xr = _bn3d_relu(self.decode_dense4[1], _dense_conv(d_in, self.decode_dense4[0], t0, down=False))
+        xr = _bn3d_relu(self.final[1], _conv1x1(xr, self.final[0]))
+        # both 1x1 heads in one pass; column 0 = occupancy logit, 1 = sdf (model.py:163-165)
+        w = torch.cat([self.occpred[0].weight.view(1, -1), self.sdfpred[0].weight.view(1, -1)], 0)
+        return xr, F_.RowLinear.apply(xr, w, None), skips, geo
+
+
+# ---- dense bottleneck on the sparse-conv kernels ------------------------------------------------------------
+class _DenseGeometry(object):
+    """Fully-active grid of a dense (B, d0, d1, d2) volume plus the k4/s2/p1 rulebooks between its pyramid
+    levels.  Depends only on the shape, so it is built once and cached."""
+
+    def __init__(self, batch, dims, device):
+        self.batch, self.dims, self.device = batch, dims, device
+        self.coords = F_.dense_coords(batch, dims[0], dims[1], dims[2], device)
+        self.grid = scn.Grid(self.coords)
+        self._levels = {}
+
+    def level(self, lv):
+        """Tables between pyramid level lv (dims / 2^lv) and lv+1: (down [64][ld_c], ld_c, n_c, up [64][ld_f],
+        ld_f, n_f).  down[k][o] = fine row feeding coarse voxel o through tap k = (kz*4+ky)*4+kx
+        (input index 2*o - 1 + k, zero padding 1); up[k][i] = coarse row that fine voxel i feeds through tap k."""
+        if lv not in self._levels:
+            fd = [d >> lv for d in self.dims]
+            if any(d % 2 for d in fd):
+                raise ValueError('dense level dims %s are not even' % (fd,))
+            cd = [d // 2 for d in fd]
+            dev, B = self.device, self.batch
+            k = torch.arange(64, device=dev)
+            kz, ky, kx = (k // 16).view(64, 1), ((k // 4) % 4).view(64, 1), (k % 4).view(64, 1)
+
+            def unravel(n, d):
+                r = torch.arange(n, device=dev)
+                x_ = r % d[2]
+                y_ = (r // d[2]) % d[1]
+                z_ = (r // (d[1] * d[2])) % d[0]
+                b_ = r // (d[0] * d[1] * d[2])
+                return b_.view(1, -1), z_.view(1, -1), y_.view(1, -1), x_.view(1, -1)
+
+            n_c, n_f = B * cd[0] * cd[1] * cd[2], B * fd[0] * fd[1] * fd[2]
+            ld_c, ld_f = ((max(n_c, 1) + 63) // 64) * 64, ((max(n_f, 1) + 63) // 64) * 64
+            b_, z_, y_, x_ = unravel(n_c, cd)
+            iz, iy, ix = 2 * z_ - 1 + kz, 2 * y_ - 1 + ky, 2 * x_ - 1 + kx
+            ok = (iz >= 0) & (iz < fd[0]) & (iy >= 0) & (iy < fd[1]) & (ix >= 0) & (ix < fd[2])
+            down = torch.full((64, ld_c), -1, dtype=torch.int32, device=dev)
+            down[:, :n_c] = torch.where(ok, ((b_ * fd[0] + iz) * fd[1] + iy) * fd[2] + ix, -1).to(torch.int32)
+            b_, z_, y_, x_ = unravel(n_f, fd)
+            tz, ty, tx = z_ + 1 - kz, y_ + 1 - ky, x_ + 1 - kx
+            ok = ((tz >= 0) & (tz % 2 == 0) & (tz // 2 < cd[0]) & (ty >= 0) & (ty % 2 == 0) & (ty // 2 < cd[1]) &
+                  (tx >= 0) & (tx % 2 == 0) & (tx // 2 < cd[2]))
+            up = torch.full((64, ld_f), -1, dtype=torch.int32, device=dev)
+            up[:, :n_f] = torch.where(ok, ((b_ * cd[0] + tz // 2) * cd[1] + ty // 2) * cd[2] + tx // 2, -1).to(torch.int32)
+            self._levels[lv] = (down.contiguous().view(-1), ld_c, n_c, up.contiguous().view(-1), ld_f, n_f)
+        return self._levels[lv]
+
+
+_dense_cache = {}
+
+
+def dense_geometry(batch, dims, device):
+    key = (int(batch), tuple(int(d) for d in dims), str(device))
+    geo = _dense_cache.get(key)
+    if geo is None:
+        if len(_dense_cache) > 8:
+            _dense_cache.clear()
+        geo = _dense_cache[key] = _DenseGeometry(key[0], key[1], device)
+    return geo
+
+
+def _dense_conv(rows, conv, tables, down):
+    """nn.Conv3d(k4,s2,p1) (down=True) or nn.ConvTranspose3d(k4,s2,p1) (down=False) on channel-last rows."""
+    tdown, ld_c, n_c, tup, ld_f, n_f = tables
+    w = conv.weight
+    if down:   # weight (Cout, Cin, 4,4,4) -> (64, Cin, Cout)
+        wk = w.permute(2, 3, 4, 1, 0).reshape(64, w.shape[1], w.shape[0])
+        return F_.SparseConv.apply(rows, wk, tdown, ld_c, n_c, tup, ld_f, n_f, F_.CONV_TRANSPOSE_W, 0)
+    wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])   # (Cin, Cout, 4,4,4) -> (64, Cin, Cout)
+    return F_.SparseConv.apply(rows, wk, tup, ld_f, n_f, tdown, ld_c, n_c, F_.CONV_TRANSPOSE_W, 0)
+
+
+def _conv1x1(rows, conv):
+    return rows @ conv.weight.view(conv.weight.shape[0], -1).t()   # plain GEMM (rocBLAS)
+
+
+def _bn3d_relu(bn, rows):
+    """nn.BatchNorm3d + ReLU on channel-last rows (statistics over all B*V voxels, like BatchNorm3d)."""
+    y = F_.BatchNormLeaky.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                1.0 - bn.momentum, bn.training, 0.0)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return y
+
+
+def _join(a, b):
+    return F_.ConcatRows.apply(a, None, b, None, a.shape[0])
 
 
 class Refinement(nn.Module):
@@ -129,8 +234,8 @@ class Refinement(nn.Module):
         feats_next = F_.RepeatRows.apply(f, 8)
         y = self.n3(self.n2(self.n1(self.n0([coords_next, feats_next]))))
         # occupancy + sdf heads as one (nf -> 2) product; column 0 = occ logit, 1 = sdf (model.py:230-231,240)
-        out = F.linear(y, torch.cat([self.linear.weight, self.linearsdf.weight], 0),
-                       torch.cat([self.linear.bias, self.linearsdf.bias], 0))
+        out = F_.RowLinear.apply(y, torch.cat([self.linear.weight, self.linearsdf.weight], 0),
+                                 torch.cat([self.linear.bias, self.linearsdf.bias], 0))
         n_all = out.shape[0]
         sel, cnt = F_.compact_sigmoid(out.detach(), 2, n_all)          # stable, == torch boolean indexing order
         locs = F_.gather_coords(coords_next, sel, cnt)
@@ -160,7 +265,8 @@ class SurfacePrediction(nn.Module):
     def forward(self, x):
         if len(x[0]) == 0:
             return [], []
-        return self.linear(self.p4(self.p3(self.p2(self.p1(self.p0(x))))))
+        f = self.p4(self.p3(self.p2(self.p1(self.p0(x)))))
+        return F_.RowLinear.apply(f, self.linear.weight, self.linear.bias)
 
 
 class GenModel(nn.Module):
@@ -192,23 +298,19 @@ class GenModel(nn.Module):
         self.surfacepred = SurfacePrediction(c, nf, 1, self.refine_sizes[-1])
 
     # -- generative glue ---------------------------------------------------------------------------------
-    def dense_coarse_to_sparse(self, coarse_feats, coarse_occ, truncation=3):
-        """model.py:315-336: every coarse voxel is a candidate; keep sigmoid(occ) > 0.5 in raster order."""
-        B, nf, d0, d1, d2 = coarse_feats.shape
-        coords_all = F_.dense_coords(B, d0, d1, d2, coarse_feats.device)
-        occ_rows = F_.DenseToSparseFn.apply(coarse_occ, coords_all)       # == permute(0,2,3,4,1).view(-1,2)
+    def dense_coarse_to_sparse(self, feat_rows, occ_rows, geo, truncation=3):
+        """model.py:315-336: every coarse voxel is a candidate; keep sigmoid(occ) > 0.5 in raster order.
+        feat_rows / occ_rows are the dense volume as rows (what the reference builds with permute+view)."""
         n_all = occ_rows.shape[0]
         sel, cnt = F_.compact_sigmoid(occ_rows.detach(), 2, n_all)
-        locs = F_.gather_coords(coords_all, sel, cnt)
-        if self.pass_feats:
-            feat_rows = F_.DenseToSparseFn.apply(coarse_feats, coords_all)
+        locs = F_.gather_coords(geo.coords, sel, cnt)
         if self.pass_occ and self.pass_feats:
             feats = F_.ConcatRows.apply(occ_rows, sel, feat_rows, sel, cnt)  # [occ,sdf | feats] (model.py:330)
         elif self.pass_occ:
             feats = F_.GatherRows.apply(occ_rows, sel, cnt)
         else:
             feats = F_.GatherRows.apply(feat_rows, sel, cnt)
-        return locs, feats, [F_.coords_to_i64(coords_all), occ_rows]
+        return locs, feats, [F_.coords_to_i64(geo.coords), occ_rows]
 
     @staticmethod
     def concat_skip(x_from, x_to, spatial_size=None, batch_size=None):
@@ -238,10 +340,10 @@ class GenModel(nn.Module):
     def forward(self, x, loss_weights, batch_size=None):
         outputs = []
         x = [coords_from_locs(x[0], x[1].device), x[1]]
-        xd, out, skips = self.encoder(x, batch_size)
+        feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
         if self.use_skip_sparse:
             skips = [(t.grid(), t.features) for t in skips]
-        locs, feats, out0 = self.dense_coarse_to_sparse(xd, out, truncation=3)
+        locs, feats, out0 = self.dense_coarse_to_sparse(feat_rows, occ_rows, geo, truncation=3)
         outputs.append(out0)
         xs = [locs, feats]
         R = len(self.refinement)

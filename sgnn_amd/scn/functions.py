@@ -138,6 +138,53 @@ class GatherRows(Function):
         return scatter_rows_raw(_f32c(d), c, idx, m, n), None, None
 
 
+class ScatterRows(Function):
+    """dst (n_dst rows, zeros elsewhere); dst[idx[r]] = src[r] with unique idx."""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_dst):
+        src = _f32c(src)
+        ctx.save_for_backward(idx)
+        ctx.shape = (src.shape[0], src.shape[1])
+        return scatter_rows_raw(src, src.shape[1], idx, src.shape[0], n_dst)
+
+    @staticmethod
+    def backward(ctx, d):
+        (idx,) = ctx.saved_tensors
+        m, c = ctx.shape
+        return gather_rows_raw(_f32c(d), c, idx, m), None, None
+
+
+class RowLinear(Function):
+    """y = x W^T + b for the 1-2 output per-site heads (W (cout, cin), b (cout) or None)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        n, cin = x.shape
+        cout = w.shape[0]
+        y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+        _lib.call('sgnn_linear_fwd', ptr(x), n, cin, ptr(w), ptr(b), cout, ptr(y))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        n, cin = x.shape
+        cout = w.shape[0]
+        dy = _f32c(dy)
+        rt = runtime(x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        wsb = _lib.query('sgnn_linear_ws_bytes', n, cin, cout)
+        ws = rt.workspace(wsb)
+        _lib.call('sgnn_linear_bwd', ptr(x), ptr(dy), n, cin, ptr(w), cout, ptr(dx), ptr(dw), ptr(db), ptr(ws), wsb)
+        return dx, dw, db
+
+
 class UnPool(Function):
     """fine[i] = coarse[parent[i]]; backward = sum over the (<= 8) children."""
 

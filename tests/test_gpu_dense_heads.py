@@ -1,0 +1,88 @@
+"""The dense 8^3 bottleneck and the per-site heads run on the HIP kernels too (sgnn_amd/model.py):
+checked here against torch's own dense ops evaluated in float64 on the CPU."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize('cin,cout,dims', [(16, 24, (8, 8, 8)), (24, 32, (4, 4, 4)), (16, 24, (4, 8, 4))])
+def test_dense_k4s2_conv_and_transpose_match_torch(cin, cout, dims):
+    """torch/model.py:89-136: nn.Conv3d / nn.ConvTranspose3d (k4, s2, p1) as 64-offset rulebooks."""
+    from sgnn_amd import model as M
+    torch.manual_seed(cin + cout)
+    B = 3
+    x = torch.randn(B, cin, *dims)
+    cd = nn.Conv3d(cin, cout, 4, 2, 1, bias=False).double()
+    ctd = nn.ConvTranspose3d(cout, cin, 4, 2, 1, bias=False).double()
+    xd = x.double().requires_grad_(True)
+    y_ref = cd(xd)
+    z_ref = ctd(y_ref)
+    g = torch.randn_like(z_ref)
+    z_ref.backward(g)
+    geo = M.dense_geometry(B, dims, torch.device('cuda'))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, cin).cuda().requires_grad_(True)
+    ch = nn.Conv3d(cin, cout, 4, 2, 1, bias=False).cuda()
+    cth = nn.ConvTranspose3d(cout, cin, 4, 2, 1, bias=False).cuda()
+    ch.weight.data.copy_(cd.weight.data.float())
+    cth.weight.data.copy_(ctd.weight.data.float())
+    y = M._dense_conv(rows, ch, geo.level(0), down=True)
+    z = M._dense_conv(y, cth, geo.level(0), down=False)
+    y_want = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(-1, cout)
+    z_want = z_ref.detach().permute(0, 2, 3, 4, 1).reshape(-1, cin)
+    assert (y.detach().cpu().double() - y_want).abs().max().item() < TOL
+    assert (z.detach().cpu().double() - z_want).abs().max().item() < TOL
+    z.backward(g.permute(0, 2, 3, 4, 1).reshape(-1, cin).float().cuda())
+    gx = xd.grad.permute(0, 2, 3, 4, 1).reshape(-1, cin)
+    assert (rows.grad.cpu().double() - gx).abs().max().item() < TOL * max(1.0, gx.abs().max().item())
+    for a, b in ((ch.weight.grad, cd.weight.grad), (cth.weight.grad, ctd.weight.grad)):
+        assert (a.cpu().double() - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize('cin,cout,bias', [(16, 2, True), (48, 1, True), (16, 2, False)])
+def test_row_linear_heads(cin, cout, bias):
+    from sgnn_amd.scn import functions as F_
+    torch.manual_seed(cin)
+    n = 5000
+    x = torch.randn(n, cin, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(cout, dtype=torch.float64, requires_grad=True) if bias else None
+    y = torch.nn.functional.linear(x, w, b)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xh = x.detach().float().cuda().requires_grad_(True)
+    wh = w.detach().float().cuda().requires_grad_(True)
+    bh = b.detach().float().cuda().requires_grad_(True) if bias else None
+    yh = F_.RowLinear.apply(xh, wh, bh)
+    yh.backward(g.float().cuda())
+    assert (yh.detach().cpu().double() - y.detach()).abs().max().item() < TOL
+    assert (xh.grad.cpu().double() - x.grad).abs().max().item() < TOL
+    assert (wh.grad.cpu().double() - w.grad).abs().max().item() < 1e-3 * max(1.0, w.grad.abs().max().item())
+    if bias:
+        assert (bh.grad.cpu().double() - b.grad).abs().max().item() < 1e-3 * max(1.0, b.grad.abs().max().item())
+
+
+def test_batchnorm3d_on_rows_matches_torch():
+    from sgnn_amd import model as M
+    torch.manual_seed(9)
+    x = torch.randn(4, 24, 4, 4, 4) * 2 + 1
+    bn_ref = nn.BatchNorm3d(24).double()
+    bn_hip = nn.BatchNorm3d(24).cuda()
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5)
+        bn_ref.bias.uniform_(-0.3, 0.3)
+    bn_hip.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in bn_ref.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    y_ref = torch.relu(bn_ref(xd))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, 24).cuda().requires_grad_(True)
+    y = M._bn3d_relu(bn_hip, rows)
+    want = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(-1, 24)
+    assert (y.detach().cpu().double() - want).abs().max().item() < TOL
+    assert (bn_hip.running_var.cpu().double() - bn_ref.running_var).abs().max().item() < 1e-5
+    assert int(bn_hip.num_batches_tracked) == 1
+    g = torch.randn_like(y_ref)
+    y_ref.backward(g)
+    y.backward(g.permute(0, 2, 3, 4, 1).reshape(-1, 24).float().cuda())
+    assert (rows.grad.cpu().double() - xd.grad.permute(0, 2, 3, 4, 1).reshape(-1, 24)).abs().max().item() < TOL

@@ -80,7 +80,7 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
 
 /* 3x3x3 submanifold rulebook (scn.SubmanifoldConvolution, torch/model.py:32,38,40,179,186,254):
  * nbr[k*ld + j] = row of the site at p_j + d_k, k = (dz+1)*9+(dy+1)*3+(dx+1), else -1.
- * ld >= n. */
+ * ld >= n; entries j in [n, ld) are written as -1. */
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         sgnn_stream_t stream);
@@ -101,6 +101,7 @@ int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint64_t *ckeys,
  *   children[k*ldc + c] = fine row whose parent is c and whose offset
  *                         (z&1)*4+(y&1)*2+(x&1) is k, else -1        (8 x ldc)
  *   ptable[k*ldf + i]   = parent[i] if offset(i)==k else -1          (8 x ldf)
+ * (padding entries up to ldc / ldf are written as -1)
  * children drives the forward conv / unpool-backward, ptable the data-gradient. */
 int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t nf,
                       int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
@@ -116,11 +117,14 @@ int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t
  * call's cin/cout are (c_out_layer, c_in_layer).
  * in_shift: feature row = table value >> in_shift (3 = features live on the
  * parents of an 8-child expansion, torch/model.py:192-207; 0 otherwise).
+ * n_in = rows of x.  Table layout contract for the conv entry points: ld is a multiple of 256
+ * and the padding entries table[k][n_out .. ld) are -1 (every table this library builds is so);
+ * K <= 64; each slab (x, y, table) must be smaller than 4 GiB (raw-buffer addressing).
  * ------------------------------------------------------------------------- */
 #define SGNN_CONV_TRANSPOSE_W 1
 #define SGNN_CONV_FLIP_K 2
-int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, const int32_t *table, int64_t ld,
-                  int64_t n_out, int cout, float *y, int flags, int in_shift,
+int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
+                  int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                   sgnn_stream_t stream);
 
 /* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic

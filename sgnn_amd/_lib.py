@@ -28,7 +28,7 @@ PROTOTYPES = {
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
     'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
-    'sgnn_conv_fwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    'sgnn_conv_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),

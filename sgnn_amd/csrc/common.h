@@ -46,6 +46,16 @@ static inline int sgnn_grid_for(int64_t work, int block, int cap = 1 << 20) {
 }
 
 // ---------------------------------------------------------------------------
+// XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only);
+// each XCD has a private 4 MiB L2.  Consecutive row tiles gather overlapping feature rows, so give every
+// XCD one contiguous range of tiles: tile = (b % 8) * chunk + b / 8 (bijective for any grid size).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sgnn_xcd_tile(unsigned b, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, i = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// ---------------------------------------------------------------------------
 // voxel keys / hash
 // ---------------------------------------------------------------------------
 #define SGNN_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull

@@ -37,117 +37,149 @@ struct ConvCfg {
   static constexpr int ALIGN = ((CIN % 4 == 0) && (V % 4 == 0)) ? 16 : (((CIN % 2 == 0) && (V % 2 == 0)) ? 8 : 4);
 };
 
-template <int CIN, int V, int ALIGN>
-__device__ __forceinline__ void load_quarter(const float *__restrict__ x, int64_t row, int q, float (&a)[V]) {
-  const float *p = x + row * CIN + q * V;
-  if constexpr (ALIGN == 16) {
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// V consecutive floats at byte offset `off` of a raw buffer; an out-of-range offset (rule entry -1 maps to
+// 0xFFFFFFxx) returns zeros, so missing neighbours need neither a branch nor a select.  Multi-dword
+// buffer loads only need dword alignment on gfx950.
+template <int V>
+__device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint32_t off, float (&a)[V]) {
+  int s = 0;
 #pragma unroll
-    for (int t = 0; t < V / 4; ++t) {
-      const float4 v = reinterpret_cast<const float4 *>(p)[t];
-      a[4 * t + 0] = v.x;
-      a[4 * t + 1] = v.y;
-      a[4 * t + 2] = v.z;
-      a[4 * t + 3] = v.w;
-    }
-  } else if constexpr (ALIGN == 8) {
-#pragma unroll
-    for (int t = 0; t < V / 2; ++t) {
-      float2 v = make_float2(0.f, 0.f);
-      if (q * V + 2 * t < CIN) v = reinterpret_cast<const float2 *>(p)[t];
-      a[2 * t + 0] = v.x;
-      a[2 * t + 1] = v.y;
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < V; ++s) a[s] = (q * V + s < CIN) ? p[s] : 0.f;
+  for (; s + 4 <= V; s += 4) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 4 * s, 0, 0);
+    a[s] = __uint_as_float(v.x); a[s + 1] = __uint_as_float(v.y);
+    a[s + 2] = __uint_as_float(v.z); a[s + 3] = __uint_as_float(v.w);
+  }
+  if constexpr (V % 4 == 3) {
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off + 4 * (V - 3), 0, 0);
+    a[V - 3] = __uint_as_float(v.x); a[V - 2] = __uint_as_float(v.y); a[V - 1] = __uint_as_float(v.z);
+  } else if constexpr (V % 4 == 2) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 4 * (V - 2), 0, 0);
+    a[V - 2] = __uint_as_float(v.x); a[V - 1] = __uint_as_float(v.y);
+  } else if constexpr (V % 4 == 1) {
+    a[V - 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * (V - 1), 0, 0));
   }
 }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, const float *__restrict__ w,
-                                                 const int32_t *__restrict__ table, int64_t ld, int K,
-                                                 int64_t n_out, float *__restrict__ y, int flags,
+__global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
+                                                 const float *__restrict__ w, const int32_t *__restrict__ table,
+                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ y, int flags,
                                                  int in_shift) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
+  constexpr int M = CONV_MREP;
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * CONV_ROWS_PER_WAVE;
+  const unsigned tile = sgnn_xcd_tile(blockIdx.x, gridDim.x);
+  const int64_t row0 = ((int64_t)tile * 4 + wave) * CONV_ROWS_PER_WAVE;  // < ld (ld is a multiple of 256)
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
-  f32x4 acc[CONV_MREP][NT];
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * COUT * 4));
+  uint32_t row_off[M];
 #pragma unroll
-  for (int m = 0; m < CONV_MREP; ++m)
+  for (int m = 0; m < M; ++m) row_off[m] = (uint32_t)(row0 + m * 16 + r) * 4u;
+  const uint32_t ld4 = (uint32_t)ld * 4u;
+
+  f32x4 acc[M][NT];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    const int kc = (K - k0) < KC ? (K - k0) : KC;
+  auto load_idx = [&](int k, int32_t(&idx)[M]) {   // padding rows of the table hold -1
+#pragma unroll
+    for (int m = 0; m < M; ++m) idx[m] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, row_off[m], k * ld4, 0);
+  };
+  auto gather = [&](const int32_t(&idx)[M], float(&a)[M][V]) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      buf_load_floats<V>(rs_x, (uint32_t)(idx[m] >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
+      if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+          if (3 * V + s >= CIN) a[m][s] = (q == 3) ? 0.f : a[m][s];
+      }
+    }
+  };
+  auto stage = [&](int k) {  // (re)stage KC weight slices as wl[kk][n][c]; in-flight global loads stay in flight
+    const int kc = (K - k) < KC ? (K - k) : KC;
     __syncthreads();
     for (int e = tid; e < kc * C::PER_K; e += 256) {
       const int c = e % CINP;
       const int n = (e / CINP) % (NT * 16);
-      const int kk = e / C::PER_K;
+      const int ko = e / C::PER_K;
       float v = 0.f;
       if (c < CIN && n < COUT) {
-        const int ks = flip ? (K - 1 - (k0 + kk)) : (k0 + kk);
+        const int ks = flip ? (K - 1 - (k + ko)) : (k + ko);
         v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
       }
       wl[e] = v;
     }
     __syncthreads();
-
-    for (int kk = 0; kk < kc; ++kk) {
-      const int32_t *trow = table + (int64_t)(k0 + kk) * ld;
-      int32_t idx[CONV_MREP];
-      bool anyv = false;
+  };
+  auto mma = [&](int kk, const float(&a)[M][V]) {
+    float b[NT][V];
 #pragma unroll
-      for (int m = 0; m < CONV_MREP; ++m) {
-        const int64_t row = row0 + m * 16 + r;
-        idx[m] = (row < n_out) ? trow[row] : -1;
-        anyv |= idx[m] >= 0;
-      }
-      if (!__any(anyv)) continue;  // wave-uniform: no rule of this offset in these 64 rows
-
-      float a[CONV_MREP][V];
+    for (int nt = 0; nt < NT; ++nt) {
+      const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
 #pragma unroll
-      for (int m = 0; m < CONV_MREP; ++m) {
-        if (idx[m] >= 0) {
-          load_quarter<CIN, V, C::ALIGN>(x, (int64_t)(idx[m] >> in_shift), q, a[m]);
-        } else {
-#pragma unroll
-          for (int s = 0; s < V; ++s) a[m][s] = 0.f;
-        }
-      }
-      float b[NT][V];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
-#pragma unroll
-        for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
-      }
-#pragma unroll
-      for (int s = 0; s < V; ++s)
-#pragma unroll
-        for (int m = 0; m < CONV_MREP; ++m)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
+      for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
     }
+#pragma unroll
+    for (int s = 0; s < V; ++s)
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
+  };
+
+  // software pipeline, unrolled by two with ping-pong registers: rule entries are fetched two offsets ahead,
+  // gathered rows one offset ahead of the MFMAs that consume them (counted vmcnt waits, no copies)
+  int32_t i0[M], i1[M];
+  float a0[M][V], a1[M][V];
+  load_idx(0, i0);
+  if (K > 1) load_idx(1, i1);
+  gather(i0, a0);
+  int k = 0;
+  for (; k + 1 < K; k += 2) {
+    if (k % KC == 0) stage(k);
+    gather(i1, a1);
+    if (k + 2 < K) load_idx(k + 2, i0);
+    mma(k % KC, a0);
+    if ((k + 1) % KC == 0) stage(k + 1);
+    if (k + 2 < K) gather(i0, a0);
+    if (k + 3 < K) load_idx(k + 3, i1);
+    mma((k + 1) % KC, a1);
+  }
+  if (k < K) {
+    if (k % KC == 0) stage(k);
+    mma(k % KC, a0);
   }
 
-  // C/D layout: col = lane&15, row = (lane>>4)*4 + reg
+  // C/D layout: col = lane&15, row = (lane>>4)*4 + reg; out-of-range rows/cols are dropped by the buffer bounds
 #pragma unroll
-  for (int m = 0; m < CONV_MREP; ++m)
+  for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = nt * 16 + r;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + m * 16 + q * 4 + i;
-        if (row < n_out && col < COUT) y[row * COUT + col] = acc[m][nt][i];
+        const uint32_t off = (col < COUT && row < n_out) ? (uint32_t)(row * COUT + col) * 4u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nt][i]), rs_y, off, 0, 0);
       }
     }
 }
@@ -183,21 +215,27 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
   X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
   X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
-SGNN_EXPORT int sgnn_conv_fwd(const float *x, int cin, const float *w, int K, const int32_t *table, int64_t ld,
-                              int64_t n_out, int cout, float *y, int flags, int in_shift,
+SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
+                              int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                               sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
                  in_shift < 31);
   if (n_out == 0) return SGNN_OK;
-  SGNN_CHECK_ARG(x && w && table && y);
+  SGNN_CHECK_ARG(x && w && table && y && n_in >= 1);
+  SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);  // and table[k][n_out..ld) must be -1 (see sgnn_hip.h)
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * cout * 4 > 0xFFFFF000ll || (int64_t)K * ld * 4 > 0xFFFFF000ll) {
+    sgnn_set_error("sgnn_conv_fwd: a slab exceeds the 4 GiB raw-buffer window (n_in=%lld cin=%d n_out=%lld cout=%d)",
+                   (long long)n_in, cin, (long long)n_out, cout);
+    return SGNN_EOVERFLOW;
+  }
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out, cin, cout, K, flags, s);
 #define X(CI, CO)                                                                                       \
   if (!done && cin == CI && cout == CO) {                                                               \
-    hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, w, table, ld, K, n_out, y, \
-                       flags, in_shift);                                                                \
+    hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, K,     \
+                       n_out, y, flags, in_shift);                                                      \
     done = true;                                                                                        \
   }
   CONV_FWD_CASES(X)
@@ -237,9 +275,13 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
   __shared__ float red[DW_KPB * MT * 16 * NT * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, q = lane >> 4;
-  const int k0 = blockIdx.y * DW_KPB;
+  // linear workgroup id -> (row block, offset group) with all offset groups of a row block and neighbouring
+  // row blocks on the same XCD (they gather the same feature rows)
+  const unsigned lin = sgnn_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const unsigned bx = lin / gridDim.y, by = lin % gridDim.y;
+  const int k0 = by * DW_KPB;
   const int kc = (K - k0) < DW_KPB ? (K - k0) : DW_KPB;
-  const int64_t blk_row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t blk_row0 = (int64_t)bx * rows_per_block;
   int64_t blk_row1 = blk_row0 + rows_per_block;
   if (blk_row1 > n_out) blk_row1 = n_out;
 
@@ -306,7 +348,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
     }
     __syncthreads();
   }
-  float *out = partial + ((int64_t)blockIdx.x * K + k0) * CIN * COUT;
+  float *out = partial + ((int64_t)bx * K + k0) * CIN * COUT;
   for (int e = tid; e < kc * CIN * COUT; e += 256) {
     const int co = e % COUT, ci = (e / COUT) % CIN, kk = e / (CIN * COUT);
     out[e] = red[(kk * MT * 16 + ci) * NT * 16 + co];

@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
                                                        const int4 *__restrict__ coords, int64_t n,
                                                        int32_t *__restrict__ nbr, int64_t ld) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  if (j >= ld) return;
+  if (j >= n) {  // padding entries: the conv kernels rely on them being -1
+#pragma unroll
+    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
+    return;
+  }
   const int4 c = coords[j];
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -183,7 +188,7 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && nbr);
-  hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -444,7 +449,12 @@ __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ f
                                                      int32_t *__restrict__ ptable, int64_t ldf) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (; i < nf; i += stride) {
+  for (; i < ldf; i += stride) {
+    if (i >= nf) {  // padding
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = -1;
+      continue;
+    }
     const int4 c = fine[i];
     const int off = ((c.x & 1) << 2) | ((c.y & 1) << 1) | (c.z & 1);
     const int32_t p = parent[i];
@@ -465,7 +475,7 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
   }
   if (nf == 0) return SGNN_OK;
   SGNN_CHECK_ARG(fine_coords && parent && ptable && children);
-  hipLaunchKernelGGL(k_down2_tables, dim3(sgnn_grid_for(nf, 256, 8192)), dim3(256), 0, s,
+  hipLaunchKernelGGL(k_down2_tables, dim3(sgnn_grid_for(ldf, 256, 8192)), dim3(256), 0, s,
                      (const int4 *)fine_coords, parent, nf, children, ldc, ptable, ldf);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -150,7 +150,7 @@ class _DenseGeometry(object):
                 return b_.view(1, -1), z_.view(1, -1), y_.view(1, -1), x_.view(1, -1)
 
             n_c, n_f = B * cd[0] * cd[1] * cd[2], B * fd[0] * fd[1] * fd[2]
-            ld_c, ld_f = ((max(n_c, 1) + 63) // 64) * 64, ((max(n_f, 1) + 63) // 64) * 64
+            ld_c, ld_f = ((max(n_c, 1) + 255) // 256) * 256, ((max(n_f, 1) + 255) // 256) * 256
             b_, z_, y_, x_ = unravel(n_c, cd)
             iz, iy, ix = 2 * z_ - 1 + kz, 2 * y_ - 1 + ky, 2 * x_ - 1 + kx
             ok = (iz >= 0) & (iz < fd[0]) & (iy >= 0) & (iy < fd[1]) & (ix >= 0) & (ix < fd[2])

@@ -22,7 +22,8 @@ def _f32c(t):
 
 def conv_fwd_raw(x, cin, w, K, table, ld, n_out, cout, flags=0, in_shift=0):
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    _lib.call('sgnn_conv_fwd', ptr(x), cin, ptr(w), K, ptr(table), ld, n_out, cout, ptr(y), flags, in_shift)
+    _lib.call('sgnn_conv_fwd', ptr(x), x.shape[0], cin, ptr(w), K, ptr(table), ld, n_out, cout, ptr(y), flags,
+              in_shift)
     return y
 
 

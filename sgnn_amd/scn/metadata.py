@@ -68,7 +68,7 @@ class Grid(object):
         self.device = coords32.device
         self.keys, self.vals, self.cap = keys, vals, cap
         self._nbr = None
-        self.ld = _round_up(max(self.n, 1), 64)
+        self.ld = _round_up(max(self.n, 1), 256)   # table leading dimension (conv kernels: multiple of 256)
 
     def hash(self):
         if self.keys is None:

@@ -130,8 +130,8 @@ int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, 
 /* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic
  * two-stage reduction through the workspace. */
 int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin, int cout);
-int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, int cout, const int32_t *table,
-                         int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
+int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy, int cout,
+                         const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
                          int64_t ws_bytes, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------

@@ -30,7 +30,7 @@ PROTOTYPES = {
     'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_conv_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
-    'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),
     'sgnn_bn_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_bn_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -88,24 +88,34 @@ def require_gpu():
                         'the HIP operators have no CPU fallback')
 
 
+_fn_cache = {}
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on error."""
-    lib = load()
-    rc = getattr(lib, name)(*args, stream())
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*args, stream())
     if rc != 0:
-        raise SgnnError('%s failed (%d): %s' % (name, rc, lib.sgnn_last_error().decode()))
+        raise SgnnError('%s failed (%d): %s' % (name, rc, load().sgnn_last_error().decode()))
 
 
 def query(name, *args):
-    return getattr(load(), name)(*args)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    return fn(*args)
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on the current device (as an integer handle)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    """Device pointer of a (contiguous) tensor, or NULL for None."""
-    if t is None:
-        return None
-    return ctypes.c_void_p(t.data_ptr())
+    """Device address of a (contiguous) tensor as an integer, or None (NULL)."""
+    return None if t is None else t.data_ptr()

@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
   const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * COUT * 4));
-  uint32_t row_off[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) row_off[m] = (uint32_t)(row0 + m * 16 + r) * 4u;
+  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;   // this lane's rule entry within an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
+  int perm[M];                                               // ds_bpermute byte address of tile m's entry
+#pragma unroll
+  for (int m = 0; m < M; ++m) perm[m] = (m * 16 + r) * 4;
 
   f32x4 acc[M][NT];
 #pragma unroll
@@ -98,14 +99,16 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto load_idx = [&](int k, int32_t(&idx)[M]) {   // padding rows of the table hold -1
-#pragma unroll
-    for (int m = 0; m < M; ++m) idx[m] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, row_off[m], k * ld4, 0);
+  // one coalesced 256-B load fetches the 64 rule entries of an offset; lanes pick theirs with ds_bpermute
+  // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
+  auto load_idx = [&](int k) -> int32_t {   // padding rows of the table hold -1
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0);
   };
-  auto gather = [&](const int32_t(&idx)[M], float(&a)[M][V]) {
+  auto gather = [&](int32_t iv, float(&a)[M][V]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      buf_load_floats<V>(rs_x, (uint32_t)(idx[m] >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
+      const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
+      buf_load_floats<V>(rs_x, (uint32_t)(id >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
       if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
 #pragma unroll
         for (int s = 0; s < V; ++s)
@@ -146,22 +149,21 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
   };
 
-  // software pipeline, unrolled by two with ping-pong registers: rule entries are fetched two offsets ahead,
+  // software pipeline, unrolled by two with ping-pong registers: rule entries run three offsets ahead,
   // gathered rows one offset ahead of the MFMAs that consume them (counted vmcnt waits, no copies)
-  int32_t i0[M], i1[M];
+  int32_t iv0 = load_idx(0), iv1 = (K > 1) ? load_idx(1) : -1, iv2 = (K > 2) ? load_idx(2) : -1;
   float a0[M][V], a1[M][V];
-  load_idx(0, i0);
-  if (K > 1) load_idx(1, i1);
-  gather(i0, a0);
+  gather(iv0, a0);
   int k = 0;
   for (; k + 1 < K; k += 2) {
     if (k % KC == 0) stage(k);
-    gather(i1, a1);
-    if (k + 2 < K) load_idx(k + 2, i0);
+    gather(iv1, a1);                          // rows of offset k+1
+    iv0 = (k + 3 < K) ? load_idx(k + 3) : -1;
     mma(k % KC, a0);
     if ((k + 1) % KC == 0) stage(k + 1);
-    if (k + 2 < K) gather(i0, a0);
-    if (k + 3 < K) load_idx(k + 3, i1);
+    if (k + 2 < K) gather(iv2, a0);           // rows of offset k+2
+    iv1 = iv0;                                // entries of k+3
+    iv2 = (k + 4 < K) ? load_idx(k + 4) : -1;
     mma((k + 1) % KC, a1);
   }
   if (k < K) {
@@ -262,17 +264,23 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float
 template <int CIN, int COUT>
 struct DwCfg {
   static constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
-  static constexpr int KPB = (MT * NT <= 3) ? 9 : ((MT * NT <= 6) ? 4 : 3);
+  static constexpr int KPB = (MT * NT == 1) ? 9 : ((MT * NT <= 3) ? 5 : 3);
 };
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, const float *__restrict__ dy,
-                                                const int32_t *__restrict__ table, int64_t ld, int K,
-                                                int64_t n_out, float *__restrict__ partial,
+__global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
+                                                const float *__restrict__ dy, const int32_t *__restrict__ table,
+                                                int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift) {
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
   constexpr int DW_KPB = DwCfg<CIN, COUT>::KPB;
-  __shared__ float red[DW_KPB * MT * 16 * NT * 16];
+  constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
+  constexpr int W = (COUT + 3) / 4, COUTP = 4 * W;      // dy quarter-row width
+  constexpr int XS = 64 * CINP, YS = 64 * COUTP;        // per-wave LDS tiles (64 rows)
+  constexpr int RED = DW_KPB * MT * 16 * NT * 16;
+  constexpr int LDS_FLOATS = (4 * (XS + YS) > RED) ? 4 * (XS + YS) : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, q = lane >> 4;
   // linear workgroup id -> (row block, offset group) with all offset groups of a row block and neighbouring
@@ -285,6 +293,13 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
   int64_t blk_row1 = blk_row0 + rows_per_block;
   if (blk_row1 > n_out) blk_row1 = n_out;
 
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * COUT * 4));
+  const uint32_t ld4 = (uint32_t)ld * 4u;
+  float *xs = lds + wave * (XS + YS);   // [64][CINP]  gathered feature rows of the current offset
+  float *ys = xs + XS;                  // [64][COUTP] output-gradient rows of the chunk
+
   f32x4 acc[DW_KPB][MT][NT];
 #pragma unroll
   for (int kk = 0; kk < DW_KPB; ++kk)
@@ -293,41 +308,105 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, co
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[kk][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // wide (16 B / lane) gathers like the forward kernel, transposed through LDS so that the site index lands on
+  // the MFMA contraction axis: A[i = ci][kslot = j] = x[table[k][R + j]][ci], B[kslot = j][co] = dy[R + j][co]
+  auto gather = [&](int32_t iv, float(&g)[4][V]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int32_t id = __builtin_amdgcn_ds_bpermute((m * 16 + i16) * 4, iv);
+      buf_load_floats<V>(rs_x, (uint32_t)(id >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), g[m]);
+      if constexpr (CINP != CIN) {
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+          if (3 * V + s >= CIN) g[m][s] = (q == 3) ? 0.f : g[m][s];
+      }
+    }
+  };
+  auto mma_chunk = [&](int kk, const float(&b)[16][NT]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int ch = mt * 16 + i16;
+        a[mt] = (ch < CINP) ? xs[(4 * t + q) * CINP + ch] : 0.f;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[kk][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[t][nt], acc[kk][mt][nt], 0, 0, 0);
+    }
+  };
+
   for (int64_t base = blk_row0 + wave * 64; base < blk_row1; base += 256) {
+    // rule entries of this wave's 64 rows for every offset of the group (table padding rows hold -1)
     int32_t idxv[DW_KPB];
 #pragma unroll
-    for (int kk = 0; kk < DW_KPB; ++kk) {
-      const int64_t row = base + lane;
-      idxv[kk] = (kk < kc && row < blk_row1) ? table[(int64_t)(k0 + kk) * ld + row] : -1;
+    for (int kk = 0; kk < DW_KPB; ++kk)
+      idxv[kk] = (kk < kc) ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u,
+                                                                          (k0 + kk) * ld4, 0)
+                           : -1;
+    // dy tile -> LDS -> B fragments kept in registers for all offsets (rows >= n_out read as zeros)
+    {
+      float g[4][W];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = base + m * 16 + i16;
+        const uint32_t off = (row < blk_row1) ? (uint32_t)(row * COUT + q * W) * 4u : 0xFFFFFFFFu;
+        buf_load_floats<W>(rs_dy, off, g[m]);
+        if constexpr (COUTP != COUT) {
+#pragma unroll
+          for (int s = 0; s < W; ++s)
+            if (3 * W + s >= COUT) g[m][s] = (q == 3) ? 0.f : g[m][s];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float *p = ys + (m * 16 + i16) * COUTP + q * W;
+#pragma unroll
+        for (int s = 0; s < W; ++s) p[s] = g[m][s];
+      }
     }
-#pragma unroll 4
-    for (int t = 0; t < 16; ++t) {
-      const int64_t R = base + 4 * t + q;
-      float b[NT];
+    float b[16][NT];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + i16;
-        b[nt] = (R < blk_row1 && co < COUT) ? dy[R * COUT + co] : 0.f;
+        b[t][nt] = (co < COUTP) ? ys[(4 * t + q) * COUTP + co] : 0.f;
       }
+
+    float g0[4][V], g1[4][V];
+    gather(idxv[0], g0);
 #pragma unroll
-      for (int kk = 0; kk < DW_KPB; ++kk) {
-        const int32_t id = __shfl(idxv[kk], 4 * t + q);
-        float a[MT];
+    for (int kk = 0; kk < DW_KPB; kk += 2) {
+      if (kk < kc) {
+        if (kk + 1 < kc) gather(idxv[kk + 1 < DW_KPB ? kk + 1 : kk], g1);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int ci = mt * 16 + i16;
-          a[mt] = (id >= 0 && ci < CIN) ? x[(int64_t)(id >> in_shift) * CIN + ci] : 0.f;
+        for (int m = 0; m < 4; ++m) {
+          float *p = xs + (m * 16 + i16) * CINP + q * V;
+#pragma unroll
+          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
         }
+        mma_chunk(kk, b);
+      }
+      if (kk + 1 < DW_KPB && kk + 1 < kc) {
+        if (kk + 2 < kc) gather(idxv[kk + 2 < DW_KPB ? kk + 2 : kk], g0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int m = 0; m < 4; ++m) {
+          float *p = xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[kk][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[kk][mt][nt], 0, 0, 0);
+          for (int s = 0; s < V; ++s) p[s] = g1[m][s];
+        }
+        mma_chunk(kk + 1 < DW_KPB ? kk + 1 : kk, b);
       }
     }
   }
 
-  // combine the four waves in fixed order through LDS
+  // combine the four waves in fixed order through LDS (the per-wave tiles are dead by now)
+  __syncthreads();
+  float *red = lds;
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
@@ -410,9 +489,9 @@ SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin,
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16) \
   X(16, 24) X(24, 32) X(64, 32) X(56, 28)
 
-SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, int cout, const int32_t *table,
-                                     int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
-                                     int64_t ws_bytes, sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy, int cout,
+                                     const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
+                                     int in_shift, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
                  in_shift >= 0 && in_shift < 31);
   hipStream_t s = (hipStream_t)stream;
@@ -421,7 +500,12 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, i
     SGNN_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), s));
     return SGNN_OK;
   }
-  SGNN_CHECK_ARG(x && dy && table);
+  SGNN_CHECK_ARG(x && dy && table && n_in >= 1);
+  SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * cout * 4 > 0xFFFFF000ll || (int64_t)K * ld * 4 > 0xFFFFF000ll) {
+    sgnn_set_error("sgnn_conv_bwd_weight: a slab exceeds the 4 GiB raw-buffer window");
+    return SGNN_EOVERFLOW;
+  }
   bool done = false;
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
@@ -434,7 +518,7 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int cin, const float *dy, i
     const int prof = sgnn_prof_begin_launch(1, n_out, cin, cout, K, 0, s);                                 \
     constexpr int kpb_ = DwCfg<CI, CO>::KPB;                                                               \
     hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)),       \
-                       dim3(256), 0, s, x, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);           \
+                       dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);     \
     sgnn_prof_end_launch(prof, s);                                                                         \
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                  \
                        (const float *)ws, nblk, elems, dw);                                                \

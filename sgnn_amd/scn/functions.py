@@ -32,8 +32,8 @@ def conv_dw_raw(x, cin, dy, cout, table, ld, K, n_out, in_shift=0):
     dw = torch.empty(K, cin, cout, dtype=torch.float32, device=x.device)
     wsb = _lib.query('sgnn_conv_bwd_weight_ws_bytes', n_out, K, cin, cout)
     ws = rt.workspace(wsb)
-    _lib.call('sgnn_conv_bwd_weight', ptr(x), cin, ptr(dy), cout, ptr(table), ld, K, n_out, ptr(dw), in_shift,
-              ptr(ws), wsb)
+    _lib.call('sgnn_conv_bwd_weight', ptr(x), x.shape[0], cin, ptr(dy), cout, ptr(table), ld, K, n_out, ptr(dw),
+              in_shift, ptr(ws), wsb)
     return dw
 
 

@@ -115,13 +115,13 @@ def main():
 
     from sgnn_amd import _lib, synth
     from sgnn_amd.model import GenModel
-    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce
+    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce, make_optimizer
     lib = _lib.load()
     _lib.require_gpu()
 
     torch.manual_seed(1234)  # same initial weights on every rank
     model = GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = make_optimizer(model.parameters(), lr=1e-3)
     sync = FlatGradAllReduce(model.parameters()) if world > 1 else None
     lw = np.ones(5, dtype=np.float32)
     # two distinct resident batches per rank, alternated, so no step sees cached results

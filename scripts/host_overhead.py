@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sgnn_amd import synth
 from sgnn_amd.model import GenModel
-from sgnn_amd.train import train_step, to_device
+from sgnn_amd.train import train_step, to_device, make_optimizer
 from sgnn_amd.scn import metadata as MD
 
 wait = [0.0]
@@ -18,7 +18,7 @@ MD._Runtime.read_count = timed
 
 torch.manual_seed(1234)
 m = GenModel(8, (64,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+opt = make_optimizer(m.parameters(), lr=1e-3)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 batch = to_device(synth.make_batch(B, (64,) * 3, cfg=2), 'cuda')
 lw = np.ones(5, dtype=np.float32)

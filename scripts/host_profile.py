@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sgnn_amd import synth
 from sgnn_amd.model import GenModel
-from sgnn_amd.train import train_step, to_device
+from sgnn_amd.train import train_step, to_device, make_optimizer
 torch.manual_seed(1234)
 m = GenModel(8, (64,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+opt = make_optimizer(m.parameters(), lr=1e-3)
 batch = to_device(synth.make_batch(2, (64,) * 3, cfg=2), 'cuda')
 lw = np.ones(5, dtype=np.float32)
 for _ in range(3): train_step(m, opt, batch, lw)

@@ -52,17 +52,22 @@ def apply_log_transform(sdf):
     return torch.sign(sdf) * torch.log(torch.abs(sdf) + 1)
 
 
+def _masked_mean(values, mask):
+    """mean(values[mask]) written as a ratio of sums: identical value (0/0 = nan for an empty mask, like the
+    mean of an empty selection) but no boolean-mask indexing, i.e. no device->host sync inside the step."""
+    m = mask.to(values.dtype)
+    return (values * m).sum() / m.sum()
+
+
 def compute_bce_sparse_dense(sparse_pred_locs, sparse_pred_vals, dense_tgts, weights, use_loss_masking):
     assert dense_tgts.dim() == 5 and dense_tgts.shape[1] == 1
     fl = _flat(sparse_pred_locs, dense_tgts.shape[2:])
     pred, tgt = sparse_pred_vals.reshape(-1), dense_tgts.view(-1)[fl]
     w = None if weights is None else weights.view(-1)[fl]
-    if use_loss_masking:
-        m = tgt != UNK_ID
-        pred, tgt = pred[m], tgt[m]
-        w = None if w is None else w[m]
-    else:
-        tgt = torch.where(tgt == UNK_ID, torch.zeros_like(tgt), tgt)
+    if use_loss_masking:   # loss.py:67-72: drop UNK_ID targets
+        per = F.binary_cross_entropy_with_logits(pred, tgt.clamp(min=0), weight=w, reduction='none')
+        return _masked_mean(per, tgt != UNK_ID)
+    tgt = torch.where(tgt == UNK_ID, torch.zeros_like(tgt), tgt)
     return F.binary_cross_entropy_with_logits(pred, tgt, weight=w)
 
 
@@ -72,14 +77,14 @@ def compute_l1_predsurf_sparse_dense(sparse_pred_locs, sparse_pred_vals, dense_t
     fl = _flat(sparse_pred_locs, dense_tgts.shape[2:])
     pred, tgt = sparse_pred_vals.reshape(-1), dense_tgts.view(-1)[fl]
     w = None if weights is None else weights.view(-1)[fl]
-    if use_loss_masking:
-        m = (known < UNK_THRESH).view(-1)[fl]
-        pred, tgt = pred[m], tgt[m]
-        w = None if w is None else w[m]
     if use_log_transform:
         pred, tgt = apply_log_transform(pred), apply_log_transform(tgt)
     d = torch.abs(pred - tgt)
-    return torch.mean(d * w) if w is not None else torch.mean(d)
+    if w is not None:
+        d = d * w
+    if use_loss_masking:   # loss.py:132-138
+        return _masked_mean(d, (known < UNK_THRESH).view(-1)[fl])
+    return torch.mean(d)
 
 
 def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights, truncation,

@@ -98,7 +98,7 @@ class TSDFEncoder(nn.Module):
             if self.use_skip_sparse:
                 skips.extend(ft)
         g = x.grid()
-        dims = tuple(int(v) for v in x.spatial_size)
+        dims = x.key
         if batch_size is None:  # upstream SparseToDense semantics: B = max batch index + 1 (one host read)
             batch_size = int(g.coords[:, 3].max().item()) + 1 if g.n else 0
         geo = dense_geometry(batch_size, dims, x.features.device)

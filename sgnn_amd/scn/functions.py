@@ -14,6 +14,20 @@ CONV_TRANSPOSE_W = 1
 CONV_FLIP_K = 2
 
 
+_ws_cache = {}
+
+
+def _ws_bytes(name, *args):
+    """Workspace-size queries are pure functions of their arguments: memoised to keep ctypes off the hot path."""
+    k = (name,) + args
+    v = _ws_cache.get(k)
+    if v is None:
+        if len(_ws_cache) > 4096:
+            _ws_cache.clear()
+        v = _ws_cache[k] = _lib.query(name, *args)
+    return v
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         raise TypeError('sgnn_amd operators are float32 (got %s)' % t.dtype)
@@ -77,7 +91,7 @@ class BatchNormLeaky(Function):
         rt = runtime(x.device)
         y = torch.empty_like(x)
         save = torch.empty(2, c, dtype=torch.float32, device=x.device)
-        wsb = _lib.query('sgnn_bn_ws_bytes', n, c)
+        wsb = _ws_bytes('sgnn_bn_ws_bytes', 0, c)
         ws = rt.workspace(wsb)
         _lib.call('sgnn_bn_fwd', ptr(x), n, c, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                   float(eps), float(momentum), int(bool(training)), float(leak), ptr(save[0]), ptr(save[1]), ptr(y),
@@ -95,7 +109,7 @@ class BatchNormLeaky(Function):
         rt = runtime(x.device)
         dx = torch.empty_like(x)
         dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
-        wsb = _lib.query('sgnn_bn_ws_bytes', n, c)
+        wsb = _ws_bytes('sgnn_bn_ws_bytes', 0, c)
         ws = rt.workspace(wsb)
         _lib.call('sgnn_bn_bwd', ptr(x), ptr(dy), n, c, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                   int(training), leak, ptr(dx), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), wsb)
@@ -180,7 +194,7 @@ class RowLinear(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
         db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        wsb = _lib.query('sgnn_linear_ws_bytes', n, cin, cout)
+        wsb = _ws_bytes('sgnn_linear_ws_bytes', 0, cin, cout)
         ws = rt.workspace(wsb)
         _lib.call('sgnn_linear_bwd', ptr(x), ptr(dy), n, cin, ptr(w), cout, ptr(dx), ptr(dw), ptr(db), ptr(ws), wsb)
         return dx, dw, db

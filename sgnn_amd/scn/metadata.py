@@ -44,12 +44,14 @@ _runtimes = {}
 
 
 def runtime(device=None):
-    _lib.require_gpu()
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = device.index if isinstance(device, torch.device) else None
     if idx is None:
-        idx = torch.cuda.current_device()
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
     rt = _runtimes.get(idx)
     if rt is None:
+        _lib.require_gpu()
         rt = _runtimes[idx] = _Runtime(torch.device('cuda', idx))
     return rt
 
@@ -140,7 +142,7 @@ class Metadata(object):
 
     @staticmethod
     def key(spatial_size):
-        return tuple(int(s) for s in spatial_size)
+        return spatial_size if isinstance(spatial_size, tuple) else tuple(int(s) for s in spatial_size)
 
     def set_input(self, spatial_size, grid):
         self.grids[self.key(spatial_size)] = grid

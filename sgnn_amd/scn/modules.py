@@ -10,23 +10,41 @@ from . import functions as F_
 
 
 class SparseConvNetTensor(object):
-    def __init__(self, features=None, metadata=None, spatial_size=None):
+    """features (N,C) + shared Metadata + spatial size.  The size is kept as a tuple of ints (`key`, also the
+    Metadata grid key); the LongTensor(3) the reference reads (`.spatial_size`, torch/model.py:380) is built
+    lazily so that the per-layer host path stays free of tensor arithmetic."""
+    __slots__ = ('features', 'metadata', 'key', '_size', '_grid')
+
+    def __init__(self, features=None, metadata=None, spatial_size=None, grid=None):
         self.features = features
         self.metadata = metadata
-        self.spatial_size = spatial_size
+        if isinstance(spatial_size, tuple):
+            self.key, self._size = spatial_size, None
+        elif spatial_size is None:
+            self.key, self._size = None, None
+        else:
+            self.key, self._size = tuple(int(s) for s in spatial_size), spatial_size
+        self._grid = grid
+
+    @property
+    def spatial_size(self):
+        if self._size is None and self.key is not None:
+            self._size = torch.LongTensor(list(self.key))
+        return self._size
 
     def get_spatial_locations(self, spatial_size=None):
-        return self.metadata.getSpatialLocations(self.spatial_size if spatial_size is None else spatial_size)
+        return self.metadata.getSpatialLocations(self.key if spatial_size is None else spatial_size)
 
     def grid(self):
-        return self.metadata.grid(self.spatial_size)
+        if self._grid is None:
+            self._grid = self.metadata.grids[self.key]
+        return self._grid
 
     def cuda(self):
         return self
 
     def __repr__(self):
-        return 'SparseConvNetTensor<features=%s spatial=%s>' % (
-            tuple(self.features.shape), [int(s) for s in self.spatial_size])
+        return 'SparseConvNetTensor<features=%s spatial=%s>' % (tuple(self.features.shape), list(self.key))
 
 
 def _size3(spatial_size, dimension):
@@ -60,7 +78,7 @@ class AddTable(nn.Module):
         f = xs[0].features
         for t in xs[1:]:
             f = F_.AddRows.apply(f, t.features)
-        return SparseConvNetTensor(f, xs[0].metadata, xs[0].spatial_size)
+        return SparseConvNetTensor(f, xs[0].metadata, xs[0].key, xs[0]._grid)
 
 
 class JoinTable(nn.Module):
@@ -68,7 +86,7 @@ class JoinTable(nn.Module):
         f = xs[0].features
         for t in xs[1:]:
             f = F_.ConcatRows.apply(f, None, t.features, None, f.shape[0])
-        return SparseConvNetTensor(f, xs[0].metadata, xs[0].spatial_size)
+        return SparseConvNetTensor(f, xs[0].metadata, xs[0].key, xs[0]._grid)
 
 
 class Identity(nn.Module):
@@ -96,8 +114,10 @@ class InputLayer(nn.Module):
             raise RuntimeError('sgnn_amd.scn.InputLayer: features must be on the GPU (no CPU fallback)')
         coords = coords_from_locs(locs, feats.device)
         md = Metadata(self.dimension)
-        md.set_input(self.spatial_size, Grid(coords))
-        return SparseConvNetTensor(feats, md, self.spatial_size.clone())
+        key = tuple(int(v) for v in self.spatial_size)
+        g = Grid(coords)
+        md.grids[key] = g
+        return SparseConvNetTensor(feats, md, key, g)
 
 
 class OutputLayer(nn.Module):
@@ -129,7 +149,7 @@ class SubmanifoldConvolution(nn.Module):
                                 F_.CONV_TRANSPOSE_W | F_.CONV_FLIP_K, 0)
         if self.bias is not None:
             y = y + self.bias
-        return SparseConvNetTensor(y, x.metadata, x.spatial_size)
+        return SparseConvNetTensor(y, x.metadata, x.key, g)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         _accept_grouped_weight(state_dict, prefix)
@@ -153,15 +173,15 @@ class Convolution(nn.Module):
         self.bias = nn.Parameter(torch.zeros(nOut)) if bias else None
 
     def forward(self, x):
-        if int((x.spatial_size % 2).sum()) != 0:
-            raise ValueError('Convolution(2,2): spatial size %s is not even' % x.spatial_size.tolist())
-        out_size = x.spatial_size // 2
-        d = x.metadata.down2(x.spatial_size, out_size)
+        if any(v % 2 for v in x.key):
+            raise ValueError('Convolution(2,2): spatial size %s is not even' % list(x.key))
+        out_size = tuple(v // 2 for v in x.key)
+        d = x.metadata.down2(x.key, out_size)
         y = F_.SparseConv.apply(x.features, self.weight, d.children, d.ldc, d.coarse.n, d.ptable, d.ldf, d.fine.n,
                                 F_.CONV_TRANSPOSE_W, 0)
         if self.bias is not None:
             y = y + self.bias
-        return SparseConvNetTensor(y, x.metadata, out_size)
+        return SparseConvNetTensor(y, x.metadata, out_size, d.coarse)
 
     _load_from_state_dict = SubmanifoldConvolution._load_from_state_dict
 
@@ -201,12 +221,12 @@ class Deconvolution(nn.Module):
         self.bias = nn.Parameter(torch.zeros(nOut)) if bias else None
 
     def forward(self, x):
-        out_size = x.spatial_size * 2
-        d = x.metadata.down2(out_size, x.spatial_size)
+        out_size = tuple(v * 2 for v in x.key)
+        d = x.metadata.down2(out_size, x.key)
         y = _DeconvFn.apply(x.features, self.weight, d)
         if self.bias is not None:
             y = y + self.bias
-        return SparseConvNetTensor(y, x.metadata, out_size)
+        return SparseConvNetTensor(y, x.metadata, out_size, d.fine)
 
 
 class UnPooling(nn.Module):
@@ -216,10 +236,10 @@ class UnPooling(nn.Module):
             raise NotImplementedError('UnPooling: size 2 / stride 2 only')
 
     def forward(self, x):
-        out_size = x.spatial_size * 2
-        d = x.metadata.down2(out_size, x.spatial_size)
+        out_size = tuple(v * 2 for v in x.key)
+        d = x.metadata.down2(out_size, x.key)
         y = F_.UnPool.apply(x.features, d.parent, d.fine.n, d.children, d.ldc)
-        return SparseConvNetTensor(y, x.metadata, out_size)
+        return SparseConvNetTensor(y, x.metadata, out_size, d.fine)
 
 
 class BatchNormalization(nn.Module):
@@ -237,7 +257,7 @@ class BatchNormalization(nn.Module):
     def forward(self, x):
         y = F_.BatchNormLeaky.apply(x.features, self.weight, self.bias, self.running_mean, self.running_var,
                                     self.eps, self.momentum, self.training, self.leakiness)
-        return SparseConvNetTensor(y, x.metadata, x.spatial_size)
+        return SparseConvNetTensor(y, x.metadata, x.key, x._grid)
 
 
 class BatchNormReLU(BatchNormalization):
@@ -258,7 +278,7 @@ class NetworkInNetwork(nn.Module):
         y = x.features @ self.weight
         if self.bias is not None:
             y = y + self.bias
-        return SparseConvNetTensor(y, x.metadata, x.spatial_size)
+        return SparseConvNetTensor(y, x.metadata, x.key, x._grid)
 
 
 class SparseToDense(nn.Module):
@@ -268,7 +288,7 @@ class SparseToDense(nn.Module):
 
     def forward(self, x, batch_size=None):
         g = x.grid()
-        s = [int(v) for v in x.spatial_size]
+        s = list(x.key)
         if batch_size is None:
             # upstream semantics: B = max batch index + 1 (one device->host read)
             batch_size = int(g.coords[:, 3].max().item()) + 1 if g.n else 0

@@ -48,6 +48,12 @@ class FlatGradAllReduce(object):
             off += n
 
 
+def make_optimizer(params, lr=1e-3, weight_decay=0.0):
+    """Adam as train.py:81; the fused multi-tensor implementation keeps the optimizer off the host's critical path
+    (307 parameter tensors)."""
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=True)
+
+
 def to_device(batch, device):
     """train.py:256-262: move one collated sample to the GPU."""
     out = dict(batch)

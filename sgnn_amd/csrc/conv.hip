@@ -37,6 +37,16 @@ struct ConvCfg {
   static constexpr int ALIGN = ((CIN % 4 == 0) && (V % 4 == 0)) ? 16 : (((CIN % 2 == 0) && (V % 2 == 0)) ? 8 : 4);
 };
 
+// optional generalisation of the rulebook walk (sgnn_conv_*_ex): offset k of group g reads table row
+// kmap[g*K + k] (NULL: k), gathers feature row idx*in_mul + kadd[k] (NULL: +0) and group g owns output rows
+// row*groups + g and the weight block g.  Plain convolutions use {NULL, NULL, 1, 1}.
+struct ConvEx {
+  const int32_t *kmap;
+  const int32_t *kadd;
+  int in_mul;
+  int groups;
+};
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -72,7 +82,7 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *__restrict__ y, int flags,
-                                                 int in_shift) {
+                                                 int in_shift, ConvEx ex) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
   constexpr int M = CONV_MREP;
@@ -80,13 +90,17 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const unsigned tile = sgnn_xcd_tile(blockIdx.x, gridDim.x);
+  // all groups of a row tile run next to each other on one XCD (they gather the same feature rows)
+  const unsigned lin = sgnn_xcd_tile(blockIdx.x, gridDim.x);
+  const unsigned tile = lin / (unsigned)ex.groups, grp = lin % (unsigned)ex.groups;
   const int64_t row0 = ((int64_t)tile * 4 + wave) * CONV_ROWS_PER_WAVE;  // < ld (ld is a multiple of 256)
+  w += (int64_t)grp * K * CIN * COUT;
+  const int32_t *kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * COUT * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * ex.groups * COUT * 4));
   const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;   // this lane's rule entry within an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];                                               // ds_bpermute byte address of tile m's entry
@@ -102,13 +116,17 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   // one coalesced 256-B load fetches the 64 rule entries of an offset; lanes pick theirs with ds_bpermute
   // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
   auto load_idx = [&](int k) -> int32_t {   // padding rows of the table hold -1
-    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0);
+    const int trow = kmap ? kmap[k] : k;
+    int32_t id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, trow * ld4, 0);
+    // fold the row transform in here (once per rule entry): -1 stays negative -> out of range -> zeros
+    id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k] : 0);
+    return id;
   };
   auto gather = [&](int32_t iv, float(&a)[M][V]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
-      buf_load_floats<V>(rs_x, (uint32_t)(id >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
+      buf_load_floats<V>(rs_x, (uint32_t)id * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
       if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
 #pragma unroll
         for (int s = 0; s < V; ++s)
@@ -180,7 +198,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + m * 16 + q * 4 + i;
-        const uint32_t off = (col < COUT && row < n_out) ? (uint32_t)(row * COUT + col) * 4u : 0xFFFFFFFFu;
+        const uint32_t off =
+            (col < COUT && row < n_out) ? (uint32_t)((row * ex.groups + grp) * COUT + col) * 4u : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nt][i]), rs_y, off, 0, 0);
       }
     }
@@ -192,17 +211,20 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
                                                          const float *__restrict__ w, int K,
                                                          const int32_t *__restrict__ table, int64_t ld,
                                                          int64_t n_out, int cout, float *__restrict__ y,
-                                                         int flags, int in_shift) {
+                                                         int flags, int in_shift, ConvEx ex) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_out * cout) return;
-  const int64_t row = t / cout;
-  const int n = (int)(t - row * cout);
+  if (t >= n_out * ex.groups * cout) return;
+  const int64_t orow = t / cout;
+  const int n = (int)(t - orow * cout);
+  const int64_t row = orow / ex.groups;
+  const int grp = (int)(orow - row * ex.groups);
+  w += (int64_t)grp * K * cin * cout;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
   float acc = 0.f;
   for (int k = 0; k < K; ++k) {
-    const int32_t idx = table[(int64_t)k * ld + row];
+    const int32_t idx = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + row];
     if (idx < 0) continue;
-    const float *xr = x + (int64_t)(idx >> in_shift) * cin;
+    const float *xr = x + ((int64_t)(idx >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[k] : 0)) * cin;
     const int ks = flip ? (K - 1 - k) : k;
     for (int c = 0; c < cin; ++c) {
       const float wv = transpose ? w[((int64_t)ks * cout + n) * cin + c] : w[((int64_t)ks * cin + c) * cout + n];
@@ -217,39 +239,48 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
   X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
   X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
-SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
-                              int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
-                              sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
+                                 int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
+                                 const int32_t *kmap, const int32_t *kadd, int in_mul, int groups,
+                                 sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
-                 in_shift < 31);
+                 in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64);
   if (n_out == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && table && y && n_in >= 1);
   SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);  // and table[k][n_out..ld) must be -1 (see sgnn_hip.h)
-  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * cout * 4 > 0xFFFFF000ll || (int64_t)K * ld * 4 > 0xFFFFF000ll) {
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll || 27ll * ld * 4 > 0xFFFFF000ll) {
     sgnn_set_error("sgnn_conv_fwd: a slab exceeds the 4 GiB raw-buffer window (n_in=%lld cin=%d n_out=%lld cout=%d)",
                    (long long)n_in, cin, (long long)n_out, cout);
     return SGNN_EOVERFLOW;
   }
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
+  const ConvEx ex{kmap, kadd, in_mul, groups};
+  const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK) * (unsigned)groups;
   bool done = false;
-  const int prof = sgnn_prof_begin_launch(0, n_out, cin, cout, K, flags, s);
+  const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
 #define X(CI, CO)                                                                                       \
   if (!done && cin == CI && cout == CO) {                                                               \
     hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, K,     \
-                       n_out, y, flags, in_shift);                                                      \
+                       n_out, y, flags, in_shift, ex);                                                  \
     done = true;                                                                                        \
   }
   CONV_FWD_CASES(X)
 #undef X
   if (!done) {
-    const int64_t total = n_out * cout;
+    const int64_t total = n_out * groups * cout;
     hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
-                       table, ld, n_out, cout, y, flags, in_shift);
+                       table, ld, n_out, cout, y, flags, in_shift, ex);
   }
   sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
+                              int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
+                              sgnn_stream_t stream) {
+  return sgnn_conv_fwd_ex(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, nullptr, nullptr, 1, 1,
+                          stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -271,7 +302,7 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
-                                                int64_t rows_per_block, int in_shift) {
+                                                int64_t rows_per_block, int in_shift, ConvEx ex) {
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
   constexpr int DW_KPB = DwCfg<CIN, COUT>::KPB;
   constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
@@ -287,7 +318,10 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   // row blocks on the same XCD (they gather the same feature rows)
   const unsigned lin = sgnn_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const unsigned bx = lin / gridDim.y, by = lin % gridDim.y;
-  const int k0 = by * DW_KPB;
+  const unsigned kgroups = gridDim.y / (unsigned)ex.groups;       // offset groups per weight group
+  const unsigned grp = by / kgroups;
+  const int k0 = (by % kgroups) * DW_KPB;
+  const int32_t *kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
   const int kc = (K - k0) < DW_KPB ? (K - k0) : DW_KPB;
   const int64_t blk_row0 = (int64_t)bx * rows_per_block;
   int64_t blk_row1 = blk_row0 + rows_per_block;
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * COUT * 4));
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * ex.groups * COUT * 4));
   const uint32_t ld4 = (uint32_t)ld * 4u;
   float *xs = lds + wave * (XS + YS);   // [64][CINP]  gathered feature rows of the current offset
   float *ys = xs + XS;                  // [64][COUTP] output-gradient rows of the chunk
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute((m * 16 + i16) * 4, iv);
-      buf_load_floats<V>(rs_x, (uint32_t)(id >> in_shift) * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), g[m]);
+      buf_load_floats<V>(rs_x, (uint32_t)id * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), g[m]);
       if constexpr (CINP != CIN) {
 #pragma unroll
         for (int s = 0; s < V; ++s)
@@ -343,17 +377,23 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
     // rule entries of this wave's 64 rows for every offset of the group (table padding rows hold -1)
     int32_t idxv[DW_KPB];
 #pragma unroll
-    for (int kk = 0; kk < DW_KPB; ++kk)
-      idxv[kk] = (kk < kc) ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u,
-                                                                          (k0 + kk) * ld4, 0)
-                           : -1;
+    for (int kk = 0; kk < DW_KPB; ++kk) {
+      int32_t id = -1;
+      if (kk < kc) {
+        const int trow = kmap ? kmap[k0 + kk] : (k0 + kk);
+        id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
+        id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k0 + kk] : 0);
+      }
+      idxv[kk] = id;
+    }
     // dy tile -> LDS -> B fragments kept in registers for all offsets (rows >= n_out read as zeros)
     {
       float g[4][W];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int64_t row = base + m * 16 + i16;
-        const uint32_t off = (row < blk_row1) ? (uint32_t)(row * COUT + q * W) * 4u : 0xFFFFFFFFu;
+        const uint32_t off =
+            (row < blk_row1) ? (uint32_t)((row * ex.groups + grp) * COUT + q * W) * 4u : 0xFFFFFFFFu;
         buf_load_floats<W>(rs_dy, off, g[m]);
         if constexpr (COUTP != COUT) {
 #pragma unroll
@@ -427,7 +467,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
     }
     __syncthreads();
   }
-  float *out = partial + ((int64_t)bx * K + k0) * CIN * COUT;
+  float *out = partial + (((int64_t)bx * ex.groups + grp) * K + k0) * CIN * COUT;
   for (int e = tid; e < kc * CIN * COUT; e += 256) {
     const int co = e % COUT, ci = (e / COUT) % CIN, kk = e / (CIN * COUT);
     out[e] = red[(kk * MT * 16 + ci) * NT * 16 + co];
@@ -459,14 +499,18 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ par
 __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict__ x, int cin,
                                                         const float *__restrict__ dy, int cout,
                                                         const int32_t *__restrict__ table, int64_t ld, int K,
-                                                        int64_t n_out, float *__restrict__ dw, int in_shift) {
+                                                        int64_t n_out, float *__restrict__ dw, int in_shift,
+                                                        ConvEx ex) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)K * cin * cout) return;
-  const int co = (int)(e % cout), ci = (int)((e / cout) % cin), k = (int)(e / ((int64_t)cin * cout));
+  if (e >= (int64_t)ex.groups * K * cin * cout) return;
+  const int co = (int)(e % cout), ci = (int)((e / cout) % cin), k = (int)((e / ((int64_t)cin * cout)) % K);
+  const int grp = (int)(e / ((int64_t)K * cin * cout));
   float s = 0.f;
   for (int64_t j = 0; j < n_out; ++j) {
-    const int32_t id = table[(int64_t)k * ld + j];
-    if (id >= 0) s = fmaf(x[(int64_t)(id >> in_shift) * cin + ci], dy[j * cout + co], s);
+    const int32_t id = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + j];
+    if (id >= 0)
+      s = fmaf(x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[k] : 0)) * cin + ci],
+               dy[(j * ex.groups + grp) * cout + co], s);
   }
   dw[e] = s;
 }
@@ -482,43 +526,46 @@ SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin,
   if (n_out <= 0) return 0;
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
-  return nblk * (int64_t)K * cin * cout * (int64_t)sizeof(float);
+  return nblk * (int64_t)K * cin * cout * (int64_t)sizeof(float);   // K counts every group's offsets (groups*K)
 }
 
 #define CONV_DW_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16) \
   X(16, 24) X(24, 32) X(64, 32) X(56, 28)
 
-SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy, int cout,
-                                     const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
-                                     int in_shift, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *dy, int cout,
+                                        const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
+                                        int in_shift, const int32_t *kmap, const int32_t *kadd, int in_mul,
+                                        int groups, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
-                 in_shift >= 0 && in_shift < 31);
+                 in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t elems = (int64_t)K * cin * cout;
+  const int64_t elems = (int64_t)groups * K * cin * cout;
   if (n_out == 0) {
     SGNN_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), s));
     return SGNN_OK;
   }
   SGNN_CHECK_ARG(x && dy && table && n_in >= 1);
   SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);
-  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * cout * 4 > 0xFFFFF000ll || (int64_t)K * ld * 4 > 0xFFFFF000ll) {
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll || 27ll * ld * 4 > 0xFFFFF000ll) {
     sgnn_set_error("sgnn_conv_bwd_weight: a slab exceeds the 4 GiB raw-buffer window");
     return SGNN_EOVERFLOW;
   }
+  const ConvEx ex{kmap, kadd, in_mul, groups};
   bool done = false;
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
 #define X(CI, CO)                                                                                          \
   if (!done && cin == CI && cout == CO) {                                                                  \
-    if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, K, cin, cout)) {                            \
+    if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, groups * K, cin, cout)) {                   \
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
       return SGNN_ENOWS;                                                                                   \
     }                                                                                                      \
-    const int prof = sgnn_prof_begin_launch(1, n_out, cin, cout, K, 0, s);                                 \
     constexpr int kpb_ = DwCfg<CI, CO>::KPB;                                                               \
-    hipLaunchKernelGGL((k_conv_dw<CI, CO>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)),       \
-                       dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift);     \
+    const int prof = sgnn_prof_begin_launch(1, n_out * groups, cin, cout, K, 0, s);                        \
+    hipLaunchKernelGGL((k_conv_dw<CI, CO>),                                                                \
+                       dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, s, \
+                       x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex);                  \
     sgnn_prof_end_launch(prof, s);                                                                         \
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                  \
                        (const float *)ws, nblk, elems, dw);                                                \
@@ -528,8 +575,15 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, cons
 #undef X
   if (!done) {
     hipLaunchKernelGGL(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
-                       cout, table, ld, K, n_out, dw, in_shift);
+                       cout, table, ld, K, n_out, dw, in_shift, ex);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy, int cout,
+                                     const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
+                                     int in_shift, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  return sgnn_conv_bwd_weight_ex(x, n_in, cin, dy, cout, table, ld, K, n_out, dw, in_shift, nullptr, nullptr, 1, 1,
+                                 ws, ws_bytes, stream);
 }

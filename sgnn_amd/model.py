@@ -223,16 +223,23 @@ class Refinement(nn.Module):
         self.n3 = scn.OutputLayer(3)
         self.linear = nn.Linear(nf, 1)
         self.linearsdf = nn.Linear(nf, 1)
+        self.fused_expand = True   # False: materialise the 8x replicated features like the reference does
 
     def forward(self, x):
         coords = x[0]
         if len(coords) == 0:
             return [[], []], [[], []]
-        f = self.p4(self.p3(self.p2(self.p1(self.p0(x)))))
+        t = self.p3(self.p2(self.p1(self.p0(x))))
+        f = self.p4(t)
         # 8-child expansion (model.py:192-207): child row 8i+j, j = 4dz+2dy+dx, features replicated
         coords_next = F_.expand8_coords(self.p0_coords(x))
-        feats_next = F_.RepeatRows.apply(f, 8)
-        y = self.n3(self.n2(self.n1(self.n0([coords_next, feats_next]))))
+        if self.fused_expand and self.n1.bias is None:
+            # n0 -> n1 on the replicated features == a grouped convolution on the parent rulebook (sgnn_hip.h)
+            y_pre = F_.expand_conv(f, self.n1.weight, t.grid())
+            y = self.n3(self.n2(scn.SparseConvNetTensor(y_pre, None, None)))
+        else:
+            feats_next = F_.RepeatRows.apply(f, 8)
+            y = self.n3(self.n2(self.n1(self.n0([coords_next, feats_next]))))
         # occupancy + sdf heads as one (nf -> 2) product; column 0 = occ logit, 1 = sdf (model.py:230-231,240)
         out = F_.RowLinear.apply(y, torch.cat([self.linear.weight, self.linearsdf.weight], 0),
                                  torch.cat([self.linear.bias, self.linearsdf.bias], 0))

@@ -83,6 +83,86 @@ class SparseConv(Function):
         return dx, dw, None, None, None, None, None, None, None, None
 
 
+_expand_cache = {}
+
+
+def expand_maps(device):
+    """Constants of the generative up-sampling convolution (see sgnn_hip.h, sgnn_conv_fwd_ex).
+    Child parity g = 4*jz+2*jy+jx, parent-level offset slot i = 4*iz+2*iy+ix with parent offset o = i - 1 + j
+    per axis.  A (64, 27): Wc[g*8+i] = sum of the 3x3x3 taps whose neighbour child lies in that parent.
+    S (64): parent-table row of (g, i);  ST = 26 - S (mirrored row, data gradient);  PAR (64): parity g."""
+    key = str(device)
+    m = _expand_cache.get(key)
+    if m is None:
+        taps = {(0, 0): (-1,), (0, 1): (0, 1), (1, 0): (-1, 0), (1, 1): (1,)}
+        A = torch.zeros(64, 27)
+        S, PAR = [], []
+        for g in range(8):
+            j = (g >> 2, (g >> 1) & 1, g & 1)
+            for i_ in range(8):
+                i = (i_ >> 2, (i_ >> 1) & 1, i_ & 1)
+                o = [i[a] - 1 + j[a] for a in range(3)]
+                S.append((o[0] + 1) * 9 + (o[1] + 1) * 3 + (o[2] + 1))
+                PAR.append(g)
+                for dz in taps[(j[0], i[0])]:
+                    for dy in taps[(j[1], i[1])]:
+                        for dx in taps[(j[2], i[2])]:
+                            A[g * 8 + i_, (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] = 1.0
+        assert float(A.sum()) == 8 * 27          # every child sees each of its 27 taps exactly once
+        St = torch.tensor(S, dtype=torch.int32)
+        m = _expand_cache[key] = (A.to(device), St.to(device), (26 - St).to(device),
+                                  torch.tensor(PAR, dtype=torch.int32, device=device))
+    return m
+
+
+class ExpandConv(Function):
+    """SubmanifoldConvolution(3x3x3) over the 8-child expansion of a level whose children all carry their parent's
+    features (torch/model.py:192-207 followed by n0/n1, :220-222), evaluated on the PARENT rulebook:
+        y[8p+g] = sum_i Wc[g][i]^T f[nbr[S[g][i]][p]],   Wc[g][i] = sum of the taps that fall into that parent.
+    Same function as the reference's expand -> InputLayer -> SubmanifoldConvolution, with 64 instead of 216
+    gathers per parent and no children grid / rulebook."""
+
+    @staticmethod
+    def forward(ctx, f, wc, table, ld, n):
+        f, wc = _f32c(f), _f32c(wc)
+        cin, cout = wc.shape[1], wc.shape[2]
+        _, S, ST, PAR = expand_maps(f.device)
+        y = torch.empty(8 * n, cout, dtype=torch.float32, device=f.device)
+        _lib.call('sgnn_conv_fwd_ex', ptr(f), n, cin, ptr(wc), 8, ptr(table), ld, n, cout, ptr(y), 0, 0, ptr(S), None,
+                  1, 8)
+        ctx.save_for_backward(f, wc)
+        ctx.cfg = (table, ld, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, wc = ctx.saved_tensors
+        table, ld, n = ctx.cfg
+        cin, cout = wc.shape[1], wc.shape[2]
+        dy = _f32c(dy)
+        _, S, ST, PAR = expand_maps(f.device)
+        df = dwc = None
+        if ctx.needs_input_grad[0]:
+            df = torch.empty(n, cin, dtype=torch.float32, device=f.device)
+            _lib.call('sgnn_conv_fwd_ex', ptr(dy), 8 * n, cout, ptr(wc), 64, ptr(table), ld, n, cin, ptr(df),
+                      CONV_TRANSPOSE_W, 0, ptr(ST), ptr(PAR), 8, 1)
+        if ctx.needs_input_grad[1]:
+            rt = runtime(f.device)
+            dwc = torch.empty_like(wc)
+            wsb = _lib.query('sgnn_conv_bwd_weight_ws_bytes', n, 64, cin, cout)
+            ws = rt.workspace(wsb)
+            _lib.call('sgnn_conv_bwd_weight_ex', ptr(f), n, cin, ptr(dy), cout, ptr(table), ld, 8, n, ptr(dwc), 0,
+                      ptr(S), None, 1, 8, ptr(ws), wsb)
+        return df, dwc, None, None, None
+
+
+def expand_conv(f, weight, grid):
+    """weight: the (27, nIn, nOut) parameter of the reference's n1 layer; grid: the parent level's Grid."""
+    A = expand_maps(f.device)[0]
+    wc = (A @ weight.reshape(27, -1)).view(64, weight.shape[1], weight.shape[2])   # differentiable, 64x27 GEMM
+    return ExpandConv.apply(f, wc, grid.subm_table(), grid.ld, grid.n)
+
+
 class BatchNormLeaky(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, leak):

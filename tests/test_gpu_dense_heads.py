@@ -86,3 +86,35 @@ def test_batchnorm3d_on_rows_matches_torch():
     y_ref.backward(g)
     y.backward(g.permute(0, 2, 3, 4, 1).reshape(-1, 24).float().cuda())
     assert (rows.grad.cpu().double() - xd.grad.permute(0, 2, 3, 4, 1).reshape(-1, 24)).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize('cin,cout', [(48, 16), (12, 8)])
+def test_generative_upsampling_conv_equals_expand_then_subm(cin, cout):
+    """torch/model.py:192-207 + n0/n1 (:220-222): expand every site into 8 children carrying its features,
+    then SubmanifoldConvolution on the children — versus the parent-rulebook formulation (ExpandConv)."""
+    import numpy as np
+    import scn_oracle as oscn
+    import model_oracle as mo
+    import sgnn_amd.scn as scn
+    from sgnn_amd.scn import functions as F_
+    from util import random_sites
+    torch.manual_seed(cin)
+    locs = random_sites(2, 12, 0.2, 4, surface=True)
+    f = torch.randn(locs.shape[0], cin)
+    conv_o = oscn.SubmanifoldConvolution(3, cin, cout, 3, False)
+    fo = f.clone().double().requires_grad_(True)
+    co = conv_o.double()
+    locs_c, feats_c = mo.expand_children(locs, fo)
+    yo = co(oscn.InputLayer(3, [24] * 3, mode=0)([locs_c, feats_c])).features
+    g = torch.randn_like(yo)
+    yo.backward(g)
+    fh = f.clone().cuda().requires_grad_(True)
+    wh = conv_o.weight.detach().float().cuda().requires_grad_(True)
+    grid = scn.InputLayer(3, [12] * 3, mode=0)([locs.cuda(), fh]).grid()
+    yh = F_.expand_conv(fh, wh, grid)
+    assert yh.shape == yo.shape
+    assert (yh.detach().cpu().double() - yo.detach()).abs().max().item() < TOL
+    yh.backward(g.float().cuda())
+    assert (fh.grad.cpu().double() - fo.grad).abs().max().item() < TOL * max(1.0, fo.grad.abs().max().item())
+    gw = co.weight.grad
+    assert (wh.grad.cpu().double() - gw).abs().max().item() < TOL * max(1.0, gw.abs().max().item())

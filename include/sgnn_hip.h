@@ -131,7 +131,8 @@ int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, 
  *   offset k of group g reads table row kmap[g*K + k]       (kmap NULL: row k)
  *   and gathers feature row  (entry >> in_shift)*in_mul + kadd[k]   (kadd NULL: + 0)
  *   group g uses the weight block w + g*K*cin*cout and owns output rows  row*groups + g
- * so y has n_out*groups rows.  kmap (groups*K ints) and kadd (K ints) are device arrays.
+ * so y has n_out*groups rows.  kmap (groups*K ints) and kadd (K ints) are device arrays; table_rows =
+ * number of offset rows the table really has (27 for a 3x3x3 rulebook).
  * Generative up-sampling (Refinement.n0/n1, torch/model.py:185-186,220-223): all 8 children of a site
  * carry its features (model.py:203), so SubmanifoldConvolution on the 8N children collapses, per child
  * parity g, into 8 parent-level offsets with pre-summed weights: forward = one launch with groups = 8,
@@ -139,12 +140,12 @@ int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, 
  * grid and its rulebook are never built); data gradient = one launch with K = 64, in_mul = 8, kadd = parity. */
 int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
                      int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
-                     const int32_t *kmap, const int32_t *kadd, int in_mul, int groups,
+                     const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows,
                      sgnn_stream_t stream);
 int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *dy, int cout,
                             const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
-                            const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, void *ws,
-                            int64_t ws_bytes, sgnn_stream_t stream);
+                            const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows,
+                            void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
 /* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic
  * two-stage reduction through the workspace. */

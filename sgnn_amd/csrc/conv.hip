@@ -21,9 +21,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CONV_MREP 4
+#define CONV_MREP 4                        // 16-row MFMA tiles per wave in the large-grid variant
 #define CONV_ROWS_PER_WAVE (16 * CONV_MREP)
-#define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)
+#define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)   // also the required multiple of the table's ld
+#define CONV_SMALL_GRID 768                // below this many 256-row workgroups use the 64-row variant
 
 template <int CIN, int COUT>
 struct ConvCfg {
@@ -45,6 +46,7 @@ struct ConvEx {
   const int32_t *kadd;
   int in_mul;
   int groups;
+  int table_rows;   // rows of `table` (K unless kmap selects rows of a larger table)
 };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -78,14 +80,14 @@ __device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint3
   }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int M>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *__restrict__ y, int flags,
                                                  int in_shift, ConvEx ex) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
-  constexpr int M = CONV_MREP;
+  constexpr int RPW = 16 * M;   // rows per wave: M = 4 normally, 1 when the level is too small to fill the chip
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,15 +95,15 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   // all groups of a row tile run next to each other on one XCD (they gather the same feature rows)
   const unsigned lin = sgnn_xcd_tile(blockIdx.x, gridDim.x);
   const unsigned tile = lin / (unsigned)ex.groups, grp = lin % (unsigned)ex.groups;
-  const int64_t row0 = ((int64_t)tile * 4 + wave) * CONV_ROWS_PER_WAVE;  // < ld (ld is a multiple of 256)
+  const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
   w += (int64_t)grp * K * CIN * COUT;
   const int32_t *kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)ex.table_rows * ld * 4));
   const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * ex.groups * COUT * 4));
-  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;   // this lane's rule entry within an offset row
+  const uint32_t lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;   // this lane's rule entry in an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];                                               // ds_bpermute byte address of tile m's entry
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // one coalesced 256-B load fetches the 64 rule entries of an offset; lanes pick theirs with ds_bpermute
+  // one coalesced load fetches the wave's rule entries of an offset; lanes pick theirs with ds_bpermute
   // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
   auto load_idx = [&](int k) -> int32_t {   // padding rows of the table hold -1
     const int trow = kmap ? kmap[k] : k;
@@ -242,26 +244,34 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
                                  int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                                  const int32_t *kmap, const int32_t *kadd, int in_mul, int groups,
-                                 sgnn_stream_t stream) {
+                                 int table_rows, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
-                 in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64);
+                 in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
+                 table_rows <= 64 && (kmap || table_rows >= K));
   if (n_out == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && table && y && n_in >= 1);
   SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);  // and table[k][n_out..ld) must be -1 (see sgnn_hip.h)
-  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll || 27ll * ld * 4 > 0xFFFFF000ll) {
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll ||
+      (int64_t)table_rows * ld * 4 > 0xFFFFF000ll) {
     sgnn_set_error("sgnn_conv_fwd: a slab exceeds the 4 GiB raw-buffer window (n_in=%lld cin=%d n_out=%lld cout=%d)",
                    (long long)n_in, cin, (long long)n_out, cout);
     return SGNN_EOVERFLOW;
   }
   hipStream_t s = (hipStream_t)stream;
-  const ConvEx ex{kmap, kadd, in_mul, groups};
-  const unsigned grid = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK) * (unsigned)groups;
+  const ConvEx ex{kmap, kadd, in_mul, groups, table_rows};
+  const unsigned grid4 = (unsigned)((n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK) * (unsigned)groups;
+  const unsigned grid1 = (unsigned)((n_out + 63) / 64) * (unsigned)groups;
+  const bool small = grid4 < CONV_SMALL_GRID;   // too few 256-row workgroups for 256 CUs: 64-row workgroups
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
 #define X(CI, CO)                                                                                       \
   if (!done && cin == CI && cout == CO) {                                                               \
-    hipLaunchKernelGGL((k_conv_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, K,     \
-                       n_out, y, flags, in_shift, ex);                                                  \
+    if (small)                                                                                          \
+      hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, ld,  \
+                         K, n_out, y, flags, in_shift, ex);                                             \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_conv_fwd<CI, CO, CONV_MREP>), dim3(grid4), dim3(256), 0, s, x, n_in, w,     \
+                         table, ld, K, n_out, y, flags, in_shift, ex);                                  \
     done = true;                                                                                        \
   }
   CONV_FWD_CASES(X)
@@ -280,7 +290,7 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float
                               int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                               sgnn_stream_t stream) {
   return sgnn_conv_fwd_ex(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, nullptr, nullptr, 1, 1,
-                          stream);
+                          K, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   if (blk_row1 > n_out) blk_row1 = n_out;
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)ex.table_rows * ld * 4));
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * ex.groups * COUT * 4));
   const uint32_t ld4 = (uint32_t)ld * 4u;
   float *xs = lds + wave * (XS + YS);   // [64][CINP]  gathered feature rows of the current offset
@@ -536,9 +546,11 @@ SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin,
 SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *dy, int cout,
                                         const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
                                         int in_shift, const int32_t *kmap, const int32_t *kadd, int in_mul,
-                                        int groups, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+                                        int groups, int table_rows, void *ws, int64_t ws_bytes,
+                                        sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
-                 in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64);
+                 in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
+                 table_rows <= 64 && (kmap || table_rows >= K));
   hipStream_t s = (hipStream_t)stream;
   const int64_t elems = (int64_t)groups * K * cin * cout;
   if (n_out == 0) {
@@ -547,11 +559,12 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
   }
   SGNN_CHECK_ARG(x && dy && table && n_in >= 1);
   SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);
-  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll || 27ll * ld * 4 > 0xFFFFF000ll) {
+  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll ||
+      (int64_t)table_rows * ld * 4 > 0xFFFFF000ll) {
     sgnn_set_error("sgnn_conv_bwd_weight: a slab exceeds the 4 GiB raw-buffer window");
     return SGNN_EOVERFLOW;
   }
-  const ConvEx ex{kmap, kadd, in_mul, groups};
+  const ConvEx ex{kmap, kadd, in_mul, groups, table_rows};
   bool done = false;
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
@@ -585,5 +598,5 @@ SGNN_EXPORT int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, cons
                                      const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,
                                      int in_shift, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   return sgnn_conv_bwd_weight_ex(x, n_in, cin, dy, cout, table, ld, K, n_out, dw, in_shift, nullptr, nullptr, 1, 1,
-                                 ws, ws_bytes, stream);
+                                 K, ws, ws_bytes, stream);
 }

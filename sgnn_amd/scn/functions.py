@@ -129,7 +129,7 @@ class ExpandConv(Function):
         _, S, ST, PAR = expand_maps(f.device)
         y = torch.empty(8 * n, cout, dtype=torch.float32, device=f.device)
         _lib.call('sgnn_conv_fwd_ex', ptr(f), n, cin, ptr(wc), 8, ptr(table), ld, n, cout, ptr(y), 0, 0, ptr(S), None,
-                  1, 8)
+                  1, 8, 27)
         ctx.save_for_backward(f, wc)
         ctx.cfg = (table, ld, n)
         return y
@@ -145,14 +145,14 @@ class ExpandConv(Function):
         if ctx.needs_input_grad[0]:
             df = torch.empty(n, cin, dtype=torch.float32, device=f.device)
             _lib.call('sgnn_conv_fwd_ex', ptr(dy), 8 * n, cout, ptr(wc), 64, ptr(table), ld, n, cin, ptr(df),
-                      CONV_TRANSPOSE_W, 0, ptr(ST), ptr(PAR), 8, 1)
+                      CONV_TRANSPOSE_W, 0, ptr(ST), ptr(PAR), 8, 1, 27)
         if ctx.needs_input_grad[1]:
             rt = runtime(f.device)
             dwc = torch.empty_like(wc)
             wsb = _lib.query('sgnn_conv_bwd_weight_ws_bytes', n, 64, cin, cout)
             ws = rt.workspace(wsb)
             _lib.call('sgnn_conv_bwd_weight_ex', ptr(f), n, cin, ptr(dy), cout, ptr(table), ld, 8, n, ptr(dwc), 0,
-                      ptr(S), None, 1, 8, ptr(ws), wsb)
+                      ptr(S), None, 1, 8, 27, ptr(ws), wsb)
         return df, dwc, None, None, None
 
 

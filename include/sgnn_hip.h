@@ -238,6 +238,42 @@ int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int cin, const f
                     sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Sparse-network programs: a static sub-network (what the reference composes from scn.Sequential /
+ * ConcatTable / AddTable / JoinTable containers, torch/model.py:31-47, 178-188, 253-257) compiled into a
+ * flat op list and run forward / backward from ONE call — same kernels, same order, bit-identical to the
+ * per-layer entry points, no host round trip per layer.  All descriptor arrays are HOST memory:
+ *   ops   int32[nops][8] = {type, in0, in1, out, param, level, cin, cout}
+ *         type 0 subm conv, 1 stride-2 conv (level -> level+1), 2 unpool (out on `level`, in0 on level+1),
+ *         3 batch-norm (param .. param+3 = gamma, beta, running_mean, running_var), 4 add, 5 join
+ *         (cin / cout = channels of in0 / in1)
+ *   opf   float[nops][4] = {eps, momentum, leak, 0}
+ *   bufs  int32[nbuf][2] = {level, channels}; buffer 0 is the input
+ *   lev_* per level: rows, table ld, nbr table, and for the transition level -> level+1 the children /
+ *         ptable tables and the parent array (device pointers, NULL where unused)
+ *   params / pgrads: host arrays of device pointers.
+ * Feature buffers live in a caller-owned arena (sgnn_prog_arena_floats floats; layout via
+ * sgnn_prog_buffer_offset); `input` optionally points buffer 0 outside the arena.  Backward: garena has the
+ * same layout, the caller fills the output gradients and flags them in ginit[nbuf].
+ * ------------------------------------------------------------------------- */
+int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+                               const int64_t *lev_n, int nlev);
+int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
+int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+                                const int64_t *lev_n, int nlev, int b);
+int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+                      const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
+                      void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
+                      int nlev, void *const *params, int nparams, const float *input, float *arena,
+                      int64_t arena_floats, int training, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
+                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
+                       int nlev, void *const *params, void *const *pgrads, int nparams,
+                       const float *input, const float *arena, float *garena, int64_t arena_floats,
+                       const int32_t *ginit, int need_input_grad, int training, void *ws, int64_t ws_bytes,
+                       sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
  * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
  * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.

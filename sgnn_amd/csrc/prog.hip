@@ -1,0 +1,285 @@
+// Sparse-network program executor: runs a whole static sub-network (an encoder level stack, a
+// FullyConvolutionalNet U, ...) forward or backward from ONE call, launching the same kernels in the
+// same order as the per-layer path (bit-identical results) without a host round trip per layer.
+//
+// Counterpart of what upstream does with Python nn.Module containers (scn.Sequential / ConcatTable /
+// AddTable / JoinTable composing <Op>_updateOutput calls): the reference's model.py builds
+// those containers at torch/model.py:31-47, 178-188, 253-257; here the container tree is compiled once into
+// a flat op list (sgnn_amd/scn/program.py) and interpreted natively.  Host-side code only: no kernels here.
+#include <vector>
+#include "common.h"
+
+enum { OP_CONV_SUBM = 0, OP_CONV_DOWN = 1, OP_UNPOOL = 2, OP_BN = 3, OP_ADD = 4, OP_JOIN = 5 };
+
+namespace {
+
+struct View {
+  const int32_t *ops;   // nops x 8: type, in0, in1, out, param, level, cin, cout
+  const float *opf;     // nops x 4: eps, momentum, leak, unused
+  int nops;
+  const int32_t *bufs;  // nbuf x 2: level, channels
+  int nbuf;
+  const int64_t *lev_n, *lev_ld;
+  void *const *lev_nbr, *const *lev_children, *const *lev_ptable, *const *lev_parent;
+  int nlev;
+};
+
+inline int64_t round64(int64_t v) { return (v + 63) & ~int64_t(63); }
+
+// arena layout: [buffers..., BN save areas (2*C floats per BN op)..., 2 scratch buffers (backward only)]
+struct Layout {
+  std::vector<int64_t> buf_off, buf_floats, aux_off;
+  int64_t max_buf = 0, total = 0, scratch0 = 0, scratch1 = 0;
+};
+
+int make_layout(const View &v, Layout &L) {
+  L.buf_off.resize(v.nbuf);
+  L.buf_floats.resize(v.nbuf);
+  L.aux_off.assign(v.nops, -1);
+  int64_t off = 0;
+  for (int b = 0; b < v.nbuf; ++b) {
+    const int lev = v.bufs[2 * b], ch = v.bufs[2 * b + 1];
+    if (lev < 0 || lev >= v.nlev || ch < 1) return -1;
+    L.buf_floats[b] = v.lev_n[lev] * ch;
+    L.buf_off[b] = off;
+    off += round64(L.buf_floats[b]);
+    if (L.buf_floats[b] > L.max_buf) L.max_buf = L.buf_floats[b];
+  }
+  for (int i = 0; i < v.nops; ++i)
+    if (v.ops[8 * i] == OP_BN) {
+      L.aux_off[i] = off;
+      off += round64(2 * (int64_t)v.ops[8 * i + 6]);
+    }
+  L.scratch0 = off;
+  off += round64(L.max_buf);
+  L.scratch1 = off;
+  off += round64(L.max_buf);
+  L.total = off;
+  return 0;
+}
+
+int64_t ws_need(const View &v) {
+  int64_t need = 0;
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + 8 * i;
+    int64_t w = 0;
+    if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
+    if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
+    if (o[0] == OP_BN) w = sgnn_bn_ws_bytes(v.lev_n[o[5]], o[6]);
+    if (w > need) need = w;
+  }
+  return need;
+}
+
+}  // namespace
+
+#define PROG_TRY(call)           \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != SGNN_OK) return rc_; \
+  } while (0)
+
+SGNN_EXPORT int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+                                           const int64_t *lev_n, int nlev) {
+  View v{ops, nullptr, nops, bufs, nbuf, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  Layout L;
+  if (make_layout(v, L) != 0) return -1;
+  return L.total;
+}
+
+SGNN_EXPORT int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev) {
+  View v{ops, nullptr, nops, nullptr, 0, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  return ws_need(v);
+}
+
+// byte offset of buffer `b` inside an arena (so the host layer can hand out views)
+SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+                                            const int64_t *lev_n, int nlev, int b) {
+  View v{ops, nullptr, nops, bufs, nbuf, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  Layout L;
+  if (make_layout(v, L) != 0 || b < 0 || b >= nbuf) return -1;
+  return L.buf_off[b];
+}
+
+SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+                                  const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
+                                  void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
+                                  int nlev, void *const *params, int nparams, const float *input, float *arena,
+                                  int64_t arena_floats, int training, void *ws, int64_t ws_bytes,
+                                  sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1);
+  View v{ops, opf, nops, bufs, nbuf, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+  Layout L;
+  SGNN_CHECK_ARG(make_layout(v, L) == 0);
+  if (arena_floats < L.total) {
+    sgnn_set_error("sgnn_prog_forward: arena too small (%lld < %lld floats)", (long long)arena_floats,
+                   (long long)L.total);
+    return SGNN_ENOWS;
+  }
+  if (ws_bytes < ws_need(v)) {
+    sgnn_set_error("sgnn_prog_forward: workspace too small");
+    return SGNN_ENOWS;
+  }
+  // buffer 0 (the program input) may live outside the arena
+  auto B = [&](int b) { return (b == 0 && input) ? const_cast<float *>(input) : arena + L.buf_off[b]; };
+  auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
+  for (int i = 0; i < nops; ++i) {
+    const int32_t *o = ops + 8 * i;
+    const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
+    SGNN_CHECK_ARG(in0 >= 0 && in0 < nbuf && out >= 0 && out < nbuf && lev >= 0 && lev < nlev);
+    const int64_t n = lev_n[lev];
+    switch (type) {
+      case OP_CONV_SUBM:
+        PROG_TRY(sgnn_conv_fwd(B(in0), n, cin, P(par), 27, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out),
+                               0, 0, stream));
+        break;
+      case OP_CONV_DOWN:
+        SGNN_CHECK_ARG(lev + 1 < nlev);
+        PROG_TRY(sgnn_conv_fwd(B(in0), n, cin, P(par), 8, (const int32_t *)lev_children[lev], lev_ld[lev + 1],
+                               lev_n[lev + 1], cout, B(out), 0, 0, stream));
+        break;
+      case OP_UNPOOL:  // in0 lives on level lev+1, out on level lev
+        SGNN_CHECK_ARG(lev + 1 < nlev);
+        PROG_TRY(sgnn_gather_rows(B(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), stream));
+        break;
+      case OP_BN: {
+        float *save = arena + L.aux_off[i];
+        PROG_TRY(sgnn_bn_fwd(B(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i], opf[4 * i + 1],
+                             training, opf[4 * i + 2], save, save + cin, B(out), ws, ws_bytes, stream));
+        break;
+      }
+      case OP_ADD:
+        SGNN_CHECK_ARG(in1 >= 0 && in1 < nbuf);
+        PROG_TRY(sgnn_add(B(in0), B(in1), n * cin, B(out), stream));
+        break;
+      case OP_JOIN:  // cin = channels of in0, cout = channels of in1
+        SGNN_CHECK_ARG(in1 >= 0 && in1 < nbuf);
+        PROG_TRY(sgnn_concat_rows(B(in0), cin, nullptr, B(in1), cout, nullptr, n, B(out), stream));
+        break;
+      default:
+        sgnn_set_error("sgnn_prog_forward: unknown op %d", type);
+        return SGNN_EINVAL;
+    }
+  }
+  return SGNN_OK;
+}
+
+// garena has the same layout as arena; ginit[b] != 0 marks gradient buffers the caller already filled
+// (the program outputs).  need_input_grad: whether buffer 0's gradient is wanted.
+SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
+                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
+                                   int nlev, void *const *params, void *const *pgrads, int nparams,
+                                   const float *input, const float *arena, float *garena, int64_t arena_floats,
+                                   const int32_t *ginit,
+                                   int need_input_grad, int training, void *ws, int64_t ws_bytes,
+                                   sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && pgrads && arena && garena && ginit);
+  View v{ops, opf, nops, bufs, nbuf, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+  Layout L;
+  SGNN_CHECK_ARG(make_layout(v, L) == 0);
+  if (arena_floats < L.total || ws_bytes < ws_need(v)) {
+    sgnn_set_error("sgnn_prog_backward: arena or workspace too small");
+    return SGNN_ENOWS;
+  }
+  hipStream_t hs = (hipStream_t)stream;
+  std::vector<char> init(nbuf);
+  for (int b = 0; b < nbuf; ++b) init[b] = ginit[b] != 0;
+  auto X = [&](int b) { return (b == 0 && input) ? input : arena + L.buf_off[b]; };
+  auto G = [&](int b) { return garena + L.buf_off[b]; };
+  auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
+  auto PG = [&](int p) { return (p >= 0 && p < nparams) ? (float *)pgrads[p] : nullptr; };
+  float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
+  // where a kernel should write the gradient of buffer b: the buffer itself if nothing was accumulated yet
+  auto target = [&](int b, int which) { return init[b] ? scratch[which] : G(b); };
+  auto commit = [&](int b, float *wrote) -> int {  // fold a freshly written gradient into buffer b
+    if (wrote == G(b)) {
+      init[b] = 1;
+      return SGNN_OK;
+    }
+    return sgnn_add(G(b), wrote, L.buf_floats[b], G(b), stream);
+  };
+  auto wants = [&](int b) { return b != 0 || need_input_grad; };
+
+  for (int i = nops - 1; i >= 0; --i) {
+    const int32_t *o = ops + 8 * i;
+    const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
+    const int64_t n = lev_n[lev];
+    if (!init[out]) {  // no gradient reached this output: its producers contribute nothing
+      if (type == OP_CONV_SUBM || type == OP_CONV_DOWN)
+        SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, (size_t)(type == OP_CONV_SUBM ? 27 : 8) * cin * cout * sizeof(float), hs));
+      if (type == OP_BN) {
+        if (PG(par)) SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, cin * sizeof(float), hs));
+        if (PG(par + 1)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 1), 0, cin * sizeof(float), hs));
+      }
+      continue;
+    }
+    const float *dy = G(out);
+    switch (type) {
+      case OP_CONV_SUBM: {
+        const int32_t *nbr = (const int32_t *)lev_nbr[lev];
+        if (wants(in0)) {
+          float *t = target(in0, 0);
+          PROG_TRY(sgnn_conv_fwd(dy, n, cout, P(par), 27, nbr, lev_ld[lev], n, cin, t,
+                                 SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K, 0, stream));
+          PROG_TRY(commit(in0, t));
+        }
+        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 27, n, PG(par), 0, ws, ws_bytes,
+                                      stream));
+        break;
+      }
+      case OP_CONV_DOWN: {
+        const int64_t nc = lev_n[lev + 1];
+        if (wants(in0)) {
+          float *t = target(in0, 0);
+          PROG_TRY(sgnn_conv_fwd(dy, nc, cout, P(par), 8, (const int32_t *)lev_ptable[lev], lev_ld[lev], n, cin, t,
+                                 SGNN_CONV_TRANSPOSE_W, 0, stream));
+          PROG_TRY(commit(in0, t));
+        }
+        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, (const int32_t *)lev_children[lev], lev_ld[lev + 1],
+                                      8, nc, PG(par), 0, ws, ws_bytes, stream));
+        break;
+      }
+      case OP_UNPOOL:
+        if (wants(in0)) {
+          float *t = target(in0, 0);
+          PROG_TRY(sgnn_gather_sum(dy, cin, (const int32_t *)lev_children[lev], lev_ld[lev + 1], 8, lev_n[lev + 1], t,
+                                   stream));
+          PROG_TRY(commit(in0, t));
+        }
+        break;
+      case OP_BN: {
+        const float *save = arena + L.aux_off[i];
+        float *t = wants(in0) ? target(in0, 0) : scratch[0];
+        PROG_TRY(sgnn_bn_bwd(X(in0), dy, n, cin, P(par), P(par + 1), save, save + cin, training, opf[4 * i + 2], t,
+                             PG(par), PG(par + 1), ws, ws_bytes, stream));
+        if (wants(in0)) PROG_TRY(commit(in0, t));
+        break;
+      }
+      case OP_ADD:
+        for (int side = 0; side < 2; ++side) {
+          const int b = side ? in1 : in0;
+          if (!wants(b)) continue;
+          if (init[b]) {
+            PROG_TRY(sgnn_add(G(b), dy, L.buf_floats[b], G(b), stream));
+          } else {
+            SGNN_HIP_TRY(hipMemcpyAsync(G(b), dy, (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+            init[b] = 1;
+          }
+        }
+        break;
+      case OP_JOIN: {
+        float *ta = wants(in0) ? target(in0, 0) : nullptr;
+        float *tb = wants(in1) ? target(in1, 1) : nullptr;
+        PROG_TRY(sgnn_concat_rows_bwd(dy, cin, nullptr, cout, nullptr, n, ta, n, tb, n, stream));
+        if (ta) PROG_TRY(commit(in0, ta));
+        if (tb) PROG_TRY(commit(in1, tb));
+        break;
+      }
+      default:
+        sgnn_set_error("sgnn_prog_backward: unknown op %d", type);
+        return SGNN_EINVAL;
+    }
+  }
+  return SGNN_OK;
+}

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import scn
 from .scn import functions as F_
+from .scn import program as P_
 from .scn.metadata import coords_from_locs
 
 
@@ -93,10 +94,24 @@ class TSDFEncoder(nn.Module):
         rows are the dense coarse volume in batch-major raster order (== permute(0,2,3,4,1).view(-1, C))."""
         skips = []
         n_layers = len(self.process_sparse)
-        for i, layer in enumerate(self.process_sparse):
-            x, ft = layer(x, batch_size, densify=(i < n_layers - 1))
+        prog = self._sparse_program() if P_.ENABLED else None
+        if prog is not None:
+            # the three sparse encoder levels (p1, p2, p3 each) as one native program; taps = the p2 outputs
+            x0 = self.process_sparse[0].p0(x)
+            taps = [prog.taps[id(l.p2)][0] for l in self.process_sparse]
+            outs, grids, _ = P_.run_program(prog, x0, self.training, taps + [prog.out])
+            keys = [x0.key]
+            for _ in range(n_layers):
+                keys.append(tuple(v // 2 for v in keys[-1]))
+            ts = [scn.SparseConvNetTensor(outs[i], x0.metadata, keys[i], grids[i]) for i in range(n_layers + 1)]
+            x = ts[-1]
             if self.use_skip_sparse:
-                skips.extend(ft)
+                skips = ts
+        else:
+            for i, layer in enumerate(self.process_sparse):
+                x, ft = layer(x, batch_size, densify=(i < n_layers - 1))
+                if self.use_skip_sparse:
+                    skips.extend(ft)
         g = x.grid()
         dims = x.key
         if batch_size is None:  # upstream SparseToDense semantics: B = max batch index + 1 (one host read)
@@ -115,6 +130,16 @@ class TSDFEncoder(nn.Module):
         # both 1x1 heads in one pass; column 0 = occupancy logit, 1 = sdf (model.py:163-165)
         w = torch.cat([self.occpred[0].weight.view(1, -1), self.sdfpred[0].weight.view(1, -1)], 0)
         return xr, F_.RowLinear.apply(xr, w, None), skips, geo
+
+
+    def _sparse_program(self):
+        if not hasattr(self, '_prog'):
+            chain, taps = [], []
+            for l in self.process_sparse:
+                chain += [l.p1, l.p2, l.p3]
+                taps.append(l.p2)
+            object.__setattr__(self, '_prog', P_.compile_or_none(chain, self.process_sparse[0].nf_in, taps))
+        return self._prog
 
 
 # ---- dense bottleneck on the sparse-conv kernels ------------------------------------------------------------
@@ -207,6 +232,12 @@ def _join(a, b):
     return F_.ConcatRows.apply(a, None, b, None, a.shape[0])
 
 
+def _cached_program(owner, chain, in_channels):
+    if not hasattr(owner, '_prog'):
+        object.__setattr__(owner, '_prog', P_.compile_or_none(chain, in_channels))
+    return owner._prog
+
+
 class Refinement(nn.Module):
     def __init__(self, nf_in, nf, pass_occ, pass_feats, max_data_size, truncation=3):
         nn.Module.__init__(self)
@@ -229,7 +260,13 @@ class Refinement(nn.Module):
         coords = x[0]
         if len(coords) == 0:
             return [[], []], [[], []]
-        t = self.p3(self.p2(self.p1(self.p0(x))))
+        prog = _cached_program(self, [self.p1, self.p2, self.p3], self.nf_in) if P_.ENABLED else None
+        if prog is not None:
+            x0 = self.p0(x)
+            outs, grids, _ = P_.run_program(prog, x0, self.training)
+            t = scn.SparseConvNetTensor(outs[0], x0.metadata, x0.key, grids[0])
+        else:
+            t = self.p3(self.p2(self.p1(self.p0(x))))
         f = self.p4(t)
         # 8-child expansion (model.py:192-207): child row 8i+j, j = 4dz+2dy+dx, features replicated
         coords_next = F_.expand8_coords(self.p0_coords(x))
@@ -272,7 +309,12 @@ class SurfacePrediction(nn.Module):
     def forward(self, x):
         if len(x[0]) == 0:
             return [], []
-        f = self.p4(self.p3(self.p2(self.p1(self.p0(x)))))
+        prog = _cached_program(self, [self.p1, self.p2, self.p3], self.p1.nIn) if P_.ENABLED else None
+        if prog is not None:
+            outs, _, _ = P_.run_program(prog, self.p0(x), self.training)
+            f = outs[0]
+        else:
+            f = self.p4(self.p3(self.p2(self.p1(self.p0(x)))))
         return F_.RowLinear.apply(f, self.linear.weight, self.linear.bias)
 
 

@@ -1,0 +1,66 @@
+"""The native program executor (sgnn_prog_forward/backward) must reproduce the per-layer path: same kernels in the
+same order, so logits, site lists and every parameter gradient agree to fp32 round-off (bit-identical except
+for the order of two-term gradient sums)."""
+import numpy as np
+import pytest
+import torch
+
+from util import param_fill
+from sgnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(enabled, train=True):
+    from sgnn_amd.model import GenModel
+    from sgnn_amd import loss as L
+    from sgnn_amd.scn import program as P
+    P.ENABLED = enabled
+    try:
+        dims, cfg = (32, 32, 32), 17
+        data = synth.make_batch(2, dims, cfg=cfg, occupancy=0.08)
+        m = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train).cuda()
+        lw = np.ones(5, dtype=np.float32)
+        t = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
+                              data['known'].cuda())
+        if not train:
+            with torch.no_grad():
+                osdf, oocc = m([data['input'][0].cuda(), data['input'][1].cuda()], lw)
+            return m, osdf, oocc, None
+        osdf, oocc = m([data['input'][0].cuda(), data['input'][1].cuda()], lw)
+        loss, _ = L.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, data['input'][0].cuda(), True,
+                                 data['known'].cuda())
+        loss.backward()
+        return m, osdf, oocc, loss.item()
+    finally:
+        P.ENABLED = True
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_program_path_equals_layer_path(train):
+    ma, sa, oa, la = _run(True, train)
+    mb, sb, ob, lb = _run(False, train)
+    assert ma.encoder._sparse_program() is not None and ma.refinement[0]._prog is not None
+    for h in range(4):
+        assert torch.equal(oa[h][0], ob[h][0])
+        assert (oa[h][1] - ob[h][1]).abs().max().item() <= 1e-6
+    assert torch.equal(sa[0], sb[0]) and (sa[1] - sb[1]).abs().max().item() <= 1e-6
+    if train:
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+        pb = dict(mb.named_parameters())
+        for n, p in ma.named_parameters():
+            assert p.grad is not None and pb[n].grad is not None, n
+            scale = max(1.0, pb[n].grad.abs().max().item())
+            assert (p.grad - pb[n].grad).abs().max().item() <= 1e-5 * scale, n
+        bb = dict(mb.named_buffers())
+        for n, b in ma.named_buffers():
+            assert torch.allclose(b.float(), bb[n].float(), atol=1e-6), n
+
+
+def test_program_compiler_rejects_what_it_cannot_run():
+    import sgnn_amd.scn as scn
+    from sgnn_amd.scn import program as P
+    assert P.compile_or_none([scn.SubmanifoldConvolution(3, 4, 8, 3, True)], 4) is None      # bias
+    assert P.compile_or_none([scn.UnPooling(3, 2, 2)], 4) is None                            # above level 0
+    p = P.compile_or_none([scn.FullyConvolutionalNet(3, 1, [8, 8], True)], 8)
+    assert p is not None and p.nlev == 2 and p.bufs[p.out][1] == 16

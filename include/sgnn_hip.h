@@ -280,6 +280,7 @@ int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int
  * ------------------------------------------------------------------------- */
 int sgnn_prof_enable(int max_records);
 int sgnn_prof_disable(void);
+int sgnn_prof_resume(void); /* keep the records gathered so far */
 int sgnn_prof_count(void);
 int sgnn_prof_dropped(void);
 int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *cout, int *K, int *flags, float *ms);

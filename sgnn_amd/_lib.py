@@ -63,6 +63,7 @@ PROTOTYPES = {
                                    c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_prof_enable': (c_i32, [c_i32]),
     'sgnn_prof_disable': (c_i32, []),
+    'sgnn_prof_resume': (c_i32, []),
     'sgnn_prof_count': (c_i32, []),
     'sgnn_prof_dropped': (c_i32, []),
     'sgnn_prof_get': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -51,6 +51,13 @@ SGNN_EXPORT int sgnn_prof_disable(void) {
   return SGNN_OK;
 }
 
+// continue recording into the existing buffers (after sgnn_prof_enable ... sgnn_prof_disable)
+SGNN_EXPORT int sgnn_prof_resume(void) {
+  SGNN_CHECK_ARG(!g_recs.empty());
+  g_on = true;
+  return SGNN_OK;
+}
+
 SGNN_EXPORT int sgnn_prof_count(void) { return g_used; }
 SGNN_EXPORT int sgnn_prof_dropped(void) { return g_dropped; }
 

@@ -40,7 +40,9 @@ def _run(enabled, train=True):
 def test_program_path_equals_layer_path(train):
     ma, sa, oa, la = _run(True, train)
     mb, sb, ob, lb = _run(False, train)
-    assert ma.encoder._sparse_program() is not None and ma.refinement[0]._prog is not None
+    assert ma.encoder._sparse_program() is not None
+    if train:
+        assert ma.refinement[0]._prog is not None and ma.surfacepred._prog is not None
     for h in range(4):
         assert torch.equal(oa[h][0], ob[h][0])
         assert (oa[h][1] - ob[h][1]).abs().max().item() <= 1e-6

@@ -238,6 +238,28 @@ int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int cin, const f
                     sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Fused loss of one hierarchy level: sparse predictions vals (m, vstride) at
+ * locs (m,4) int64 [z,y,x,b] against dense (B,1,d0,d1,d2) targets —
+ *   out2[0] = mean over kept sites of w * BCE_with_logits(vals[:,occ_col], tgt_occ)   (torch/loss.py:58-82)
+ *   out2[1] = mean over kept sites of w * |logt(vals[:,sdf_col]) - logt(tgt_sdf)|      (torch/loss.py:122-157)
+ * occ_col / sdf_col = -1 skips that term; weights / known may be NULL.
+ * mask_mode 0: keep every site (UNK_ID occupancy targets count as 0); 1: keep tgt_occ != -1;
+ * 2: keep known < 2.  sums (3 doubles, device) carries {sum bce, sum l1, kept} to the backward call,
+ * which writes dvals (m, vstride) given gout2 = d loss / d out2 (device, 2 floats).
+ * ------------------------------------------------------------------------- */
+int64_t sgnn_loss_ws_bytes(void);
+int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
+                        const float *tgt_occ, const float *tgt_sdf, const float *weights,
+                        const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
+                        int mask_mode, double *sums, float *out2, void *ws, int64_t ws_bytes,
+                        sgnn_stream_t stream);
+int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
+                        const float *tgt_occ, const float *tgt_sdf, const float *weights,
+                        const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
+                        int mask_mode, const double *sums, const float *gout2, float *dvals,
+                        sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Sparse-network programs: a static sub-network (what the reference composes from scn.Sequential /
  * ConcatTable / AddTable / JoinTable containers, torch/model.py:31-47, 178-188, 253-257) compiled into a
  * flat op list and run forward / backward from ONE call — same kernels, same order, bit-identical to the

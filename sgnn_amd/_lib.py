@@ -54,6 +54,11 @@ PROTOTYPES = {
     'sgnn_linear_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
     'sgnn_linear_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     'sgnn_linear_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_loss_ws_bytes': (c_i64, []),
+    'sgnn_loss_level_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
+                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_loss_level_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
+                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32]),

@@ -87,6 +87,48 @@ def compute_l1_predsurf_sparse_dense(sparse_pred_locs, sparse_pred_vals, dense_t
     return torch.mean(d)
 
 
+FUSED = True   # use the HIP level-loss kernels (sgnn_loss_level_*) for device tensors; False: torch ops below
+
+
+class _LevelLoss(torch.autograd.Function):
+    """(bce_mean, l1_mean) of one level through sgnn_loss_level_fwd/bwd (include/sgnn_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, vals, locs, tgt_occ, tgt_sdf, weights, known, occ_col, sdf_col, use_log, mask_mode):
+        from . import _lib
+        from .scn.metadata import runtime
+        vals = vals.contiguous()
+        locs = locs.contiguous()
+        m, vstride = vals.shape
+        dims = tgt_sdf.shape[2:]
+        rt = runtime(vals.device)
+        sums = torch.empty(3, dtype=torch.float64, device=vals.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=vals.device)
+        wsb = _lib.query('sgnn_loss_ws_bytes')
+        ws = rt.workspace(wsb)
+        args = (_lib.ptr(locs), _lib.ptr(vals), vstride, occ_col, sdf_col, _lib.ptr(tgt_occ), _lib.ptr(tgt_sdf),
+                _lib.ptr(weights), _lib.ptr(known), int(dims[0]), int(dims[1]), int(dims[2]), m, int(use_log),
+                mask_mode)
+        _lib.call('sgnn_loss_level_fwd', *args, _lib.ptr(sums), _lib.ptr(out2), _lib.ptr(ws), wsb)
+        ctx.args = args
+        ctx.keep = (locs, vals, tgt_occ, tgt_sdf, weights, known, sums)
+        return out2
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        locs, vals, tgt_occ, tgt_sdf, weights, known, sums = ctx.keep
+        g = g.contiguous()
+        dvals = torch.empty_like(vals)
+        _lib.call('sgnn_loss_level_bwd', *ctx.args, _lib.ptr(sums), _lib.ptr(g), _lib.ptr(dvals))
+        return (dvals,) + (None,) * 9
+
+
+def _fusable(vals, *dense):
+    return (FUSED and torch.is_tensor(vals) and vals.is_cuda and vals.dtype == torch.float32 and
+            all(d is None or (d.is_cuda and d.is_contiguous()) for d in dense))
+
+
 def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights, truncation,
                  use_log_transform=True, weight_missing_geo=1, input_locs=None, use_loss_masking=True, known=None):
     """Returns (loss tensor, per-level loss tensors or -1).  Unlike loss.py:185 the per-level values are
@@ -101,16 +143,28 @@ def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, targe
             losses.append(-1)
             continue
         locs, vals = output_occs[h]
-        l_occ = compute_bce_sparse_dense(locs, vals[:, 0], target_for_occs[h], weights[h], use_loss_masking)
-        cur_known = None if not use_loss_masking else (target_for_occs[h] == UNK_ID) * UNK_THRESH
-        l_sdf = compute_l1_predsurf_sparse_dense(locs, vals[:, 1], target_for_hier[h], weights[h], use_log_transform,
-                                                 use_loss_masking, cur_known)
-        cur = l_occ + l_sdf
+        if _fusable(vals, target_for_occs[h], target_for_hier[h], weights[h]) and target_for_occs[h].dtype == torch.float32:
+            both = _LevelLoss.apply(vals, locs, target_for_occs[h], target_for_hier[h], weights[h], None, 0, 1,
+                                    use_log_transform, 1 if use_loss_masking else 0)
+            cur = both[0] + both[1]
+        else:
+            l_occ = compute_bce_sparse_dense(locs, vals[:, 0], target_for_occs[h], weights[h], use_loss_masking)
+            cur_known = None if not use_loss_masking else (target_for_occs[h] == UNK_ID) * UNK_THRESH
+            l_sdf = compute_l1_predsurf_sparse_dense(locs, vals[:, 1], target_for_hier[h], weights[h],
+                                                     use_log_transform, use_loss_masking, cur_known)
+            cur = l_occ + l_sdf
         loss = loss + float(loss_weights[h]) * cur
         losses.append(cur.detach())
     if len(output_sdf[0]) > 0 and loss_weights[-1] > 0:
-        cur = compute_l1_predsurf_sparse_dense(output_sdf[0], output_sdf[1], target_for_sdf, weights[-1],
-                                               use_log_transform, use_loss_masking, known)
+        vals = output_sdf[1]
+        if _fusable(vals, target_for_sdf, weights[-1], known if use_loss_masking else None) and \
+                (not use_loss_masking or known.dtype == torch.uint8):
+            cur = _LevelLoss.apply(vals, output_sdf[0], None, target_for_sdf, weights[-1],
+                                   known if use_loss_masking else None, -1, 0, use_log_transform,
+                                   2 if use_loss_masking else 0)[1]
+        else:
+            cur = compute_l1_predsurf_sparse_dense(output_sdf[0], vals, target_for_sdf, weights[-1],
+                                                   use_log_transform, use_loss_masking, known)
         loss = loss + float(loss_weights[-1]) * cur
         losses.append(cur.detach())
     else:

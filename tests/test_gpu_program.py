@@ -66,3 +66,40 @@ def test_program_compiler_rejects_what_it_cannot_run():
     assert P.compile_or_none([scn.UnPooling(3, 2, 2)], 4) is None                            # above level 0
     p = P.compile_or_none([scn.FullyConvolutionalNet(3, 1, [8, 8], True)], 8)
     assert p is not None and p.nlev == 2 and p.bufs[p.out][1] == 16
+
+
+@pytest.mark.parametrize('masking,wgeo', [(True, 5.0), (False, 1.0), (True, 1.0)])
+def test_fused_level_loss_equals_torch_loss(masking, wgeo):
+    """sgnn_loss_level_fwd/bwd vs the torch-op restatement of torch/loss.py:58-157 (value and gradients)."""
+    from sgnn_amd import loss as L
+    torch.manual_seed(2)
+    data = synth.make_batch(2, (16, 16, 16), cfg=9, occupancy=0.1)
+    dims = data['sdf'].shape[2:]
+    outs = []
+    for h, f in enumerate((8, 4, 2, 1)):
+        d = [v // f for v in dims]
+        n = 300
+        locs = torch.stack([torch.randint(0, d[0], (n,)), torch.randint(0, d[1], (n,)), torch.randint(0, d[2], (n,)),
+                            torch.randint(0, 2, (n,))], 1).cuda()
+        outs.append([locs, torch.randn(n, 2).cuda()])
+    sdf_locs, sdf_vals = outs[3][0], torch.randn(outs[3][0].shape[0], 1).cuda()
+    lw = np.array([1, 0.5, 1, 1, 2], dtype=np.float32)
+    res = []
+    for fused in (True, False):
+        L.FUSED = fused
+        try:
+            t = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3,
+                                  masking, data['known'].cuda())
+            vs = [o[1].clone().requires_grad_(True) for o in outs]
+            sv = sdf_vals.clone().requires_grad_(True)
+            loss, losses = L.compute_loss([sdf_locs, sv], [[o[0], v] for o, v in zip(outs, vs)], t[0], t[1], t[2], lw, 3,
+                                          True, wgeo, data['input'][0].cuda(), masking, data['known'].cuda())
+            g = torch.autograd.grad(loss, vs + [sv])
+            res.append((loss.item(), [float(x) for x in losses], g))
+        finally:
+            L.FUSED = True
+    (la, lsa, ga), (lb, lsb, gb) = res
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    assert np.allclose(lsa, lsb, rtol=1e-5, atol=1e-6)
+    for x, y in zip(ga, gb):
+        assert (x - y).abs().max().item() < 1e-6

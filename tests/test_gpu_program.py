@@ -43,10 +43,16 @@ def test_program_path_equals_layer_path(train):
     assert ma.encoder._sparse_program() is not None
     if train:
         assert ma.refinement[0]._prog is not None and ma.surfacepred._prog is not None
+    def same(a, b):   # a level that received no sites is reported as empty lists (torch/model.py:211)
+        if len(a[0]) == 0 or len(b[0]) == 0:
+            assert len(a[0]) == 0 and len(b[0]) == 0
+            return
+        assert torch.equal(a[0], b[0])
+        assert (a[1] - b[1]).abs().max().item() <= 1e-6
+
     for h in range(4):
-        assert torch.equal(oa[h][0], ob[h][0])
-        assert (oa[h][1] - ob[h][1]).abs().max().item() <= 1e-6
-    assert torch.equal(sa[0], sb[0]) and (sa[1] - sb[1]).abs().max().item() <= 1e-6
+        same(oa[h], ob[h])
+    same(sa, sb)
     if train:
         assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
         pb = dict(mb.named_parameters())

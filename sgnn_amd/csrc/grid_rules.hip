@@ -152,8 +152,10 @@ SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int6
 }
 
 // ---------------------------------------------------------------------------
-// 3x3x3 submanifold rulebook: nbr[k][j].  One thread per site, 26 probes; every
-// per-offset store is a coalesced 256-B run across the wave.
+// 3x3x3 submanifold rulebook: nbr[k][j].  One thread per site.  The rulebook is symmetric —
+// nbr[k][j] = i  <=>  nbr[26-k][i] = j — so only the 13 "lower" offsets are probed in the hash; each hit
+// also writes its mirror entry (unique writer per entry, no atomics).  Rows 14..26 are pre-filled with -1.
+// Probes are the cost (random L2 lines); the direct per-offset stores are coalesced 256-B runs.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restrict__ keys,
                                                        const int32_t *__restrict__ vals, uint64_t mask,
@@ -161,25 +163,22 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
                                                        int32_t *__restrict__ nbr, int64_t ld) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= ld) return;
-  if (j >= n) {  // padding entries: the conv kernels rely on them being -1
+  if (j >= n) {  // padding entries: the conv kernels rely on them being -1 (rows 14..26 come from the memset)
 #pragma unroll
-    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
+    for (int k = 0; k <= 13; ++k) nbr[(int64_t)k * ld + j] = -1;
     return;
   }
   const int4 c = coords[j];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {
+  for (int k = 0; k < 13; ++k) {
     const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-    int32_t r;
-    if (k == 13) {
-      r = (int32_t)j;
-    } else {
-      const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
-      const bool ok = ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
-      r = ok ? sgnn_hash_find(keys, vals, mask, sgnn_pack_key(z, y, x, c.w)) : -1;
-    }
+    const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
+    const bool ok = ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
+    const int32_t r = ok ? sgnn_hash_find(keys, vals, mask, sgnn_pack_key(z, y, x, c.w)) : -1;
     nbr[(int64_t)k * ld + j] = r;
+    if (r >= 0) nbr[(int64_t)(26 - k) * ld + r] = (int32_t)j;
   }
+  nbr[(int64_t)13 * ld + j] = (int32_t)j;
 }
 
 SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
@@ -188,6 +187,7 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && nbr);
+  SGNN_HIP_TRY(hipMemsetAsync(nbr + 14 * ld, 0xFF, (size_t)(13 * ld) * sizeof(int32_t), (hipStream_t)stream));
   hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld);
   SGNN_CHECK_LAUNCH();

@@ -25,27 +25,19 @@ class FlatGradAllReduce(object):
     def __call__(self):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
-        p0 = self.params[0]
-        if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        off = 0
-        for p in self.params:  # a parameter unreached this step (empty level) contributes zeros
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        # a parameter unreached this step (empty generative level) contributes zeros and still receives the mean
+        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
+                 for p in self.params]
+        self.flat = torch.cat(grads)                      # one gather kernel instead of one copy per tensor
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(dist.get_world_size(self.group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
+        pieces = self.flat.split([p.numel() for p in self.params])
+        have = [(p.grad, v.view_as(p)) for p, v in zip(self.params, pieces) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([a for a, _ in have], [b for _, b in have])
+        for p, v in zip(self.params, pieces):
             if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+                p.grad = v.view_as(p).clone()
 
 
 def make_optimizer(params, lr=1e-3, weight_decay=0.0):

@@ -80,7 +80,8 @@ __device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint3
   }
 }
 
-template <int CIN, int COUT, int M>
+// EX = false: plain rulebook walk (ex is ignored; keeps the register budget of the hot instantiations)
+template <int CIN, int COUT, int M, bool EX>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *__restrict__ y, int flags,
@@ -94,15 +95,20 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const int r = lane & 15, q = lane >> 4;
   // all groups of a row tile run next to each other on one XCD (they gather the same feature rows)
   const unsigned lin = sgnn_xcd_tile(blockIdx.x, gridDim.x);
-  const unsigned tile = lin / (unsigned)ex.groups, grp = lin % (unsigned)ex.groups;
+  const unsigned groups = EX ? (unsigned)ex.groups : 1u;
+  const unsigned tile = lin / groups, grp = lin % groups;
   const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
-  w += (int64_t)grp * K * CIN * COUT;
-  const int32_t *kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
+  const int32_t *kmap = nullptr;
+  if constexpr (EX) {
+    w += (int64_t)grp * K * CIN * COUT;
+    kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
+  }
+  const int table_rows = EX ? ex.table_rows : K;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)ex.table_rows * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * ex.groups * COUT * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)table_rows * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * groups * COUT * 4));
   const uint32_t lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;   // this lane's rule entry in an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];                                               // ds_bpermute byte address of tile m's entry
@@ -118,11 +124,14 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   // one coalesced load fetches the wave's rule entries of an offset; lanes pick theirs with ds_bpermute
   // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
   auto load_idx = [&](int k) -> int32_t {   // padding rows of the table hold -1
-    const int trow = kmap ? kmap[k] : k;
-    int32_t id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, trow * ld4, 0);
-    // fold the row transform in here (once per rule entry): -1 stays negative -> out of range -> zeros
-    id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k] : 0);
-    return id;
+    if constexpr (EX) {
+      const int trow = kmap ? kmap[k] : k;
+      int32_t id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, trow * ld4, 0);
+      // fold the row transform in here (once per rule entry): -1 stays negative -> out of range -> zeros
+      return (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k] : 0);
+    } else {
+      return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
+    }
   };
   auto gather = [&](int32_t iv, float(&a)[M][V]) {
 #pragma unroll
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
       for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + m * 16 + q * 4 + i;
         const uint32_t off =
-            (col < COUT && row < n_out) ? (uint32_t)((row * ex.groups + grp) * COUT + col) * 4u : 0xFFFFFFFFu;
+            (col < COUT && row < n_out) ? (uint32_t)((row * groups + grp) * COUT + col) * 4u : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nt][i]), rs_y, off, 0, 0);
       }
     }
@@ -236,6 +245,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
   y[t] = acc;
 }
 
+// shapes of the generative up-sampling convolution (grouped / remapped walk): forward and data gradient
+#define CONV_EX_CASES(X) X(48, 16) X(16, 48) X(24, 8) X(8, 24)
+
 #define CONV_FWD_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
   X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
@@ -264,17 +276,24 @@ SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const fl
   const bool small = grid4 < CONV_SMALL_GRID;   // too few 256-row workgroups for 256 CUs: 64-row workgroups
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
-#define X(CI, CO)                                                                                       \
-  if (!done && cin == CI && cout == CO) {                                                               \
+  const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
+#define LAUNCH_FWD(CI, CO, EXV)                                                                         \
+  do {                                                                                                  \
     if (small)                                                                                          \
-      hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, ld,  \
-                         K, n_out, y, flags, in_shift, ex);                                             \
+      hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
+                         ld, K, n_out, y, flags, in_shift, ex);                                         \
     else                                                                                                \
-      hipLaunchKernelGGL((k_conv_fwd<CI, CO, CONV_MREP>), dim3(grid4), dim3(256), 0, s, x, n_in, w,     \
-                         table, ld, K, n_out, y, flags, in_shift, ex);                                  \
+      hipLaunchKernelGGL((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in,   \
+                         w, table, ld, K, n_out, y, flags, in_shift, ex);                               \
     done = true;                                                                                        \
-  }
+  } while (0)
+#define X(CI, CO) \
+  if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)
+#undef X
+#define X(CI, CO) \
+  if (!done && !plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, true);
+  CONV_EX_CASES(X)
 #undef X
   if (!done) {
     const int64_t total = n_out * groups * cout;
@@ -308,7 +327,7 @@ struct DwCfg {
   static constexpr int KPB = (MT * NT == 1) ? 9 : ((MT * NT <= 3) ? 5 : 3);
 };
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool EX>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
@@ -328,18 +347,20 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   // row blocks on the same XCD (they gather the same feature rows)
   const unsigned lin = sgnn_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const unsigned bx = lin / gridDim.y, by = lin % gridDim.y;
-  const unsigned kgroups = gridDim.y / (unsigned)ex.groups;       // offset groups per weight group
+  const unsigned groups = EX ? (unsigned)ex.groups : 1u;
+  const unsigned kgroups = gridDim.y / groups;       // offset groups per weight group
   const unsigned grp = by / kgroups;
   const int k0 = (by % kgroups) * DW_KPB;
-  const int32_t *kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
+  const int32_t *kmap = (EX && ex.kmap) ? ex.kmap + grp * K : nullptr;
+  const int table_rows = EX ? ex.table_rows : K;
   const int kc = (K - k0) < DW_KPB ? (K - k0) : DW_KPB;
   const int64_t blk_row0 = (int64_t)bx * rows_per_block;
   int64_t blk_row1 = blk_row0 + rows_per_block;
   if (blk_row1 > n_out) blk_row1 = n_out;
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)ex.table_rows * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * ex.groups * COUT * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)table_rows * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(n_out * groups * COUT * 4));
   const uint32_t ld4 = (uint32_t)ld * 4u;
   float *xs = lds + wave * (XS + YS);   // [64][CINP]  gathered feature rows of the current offset
   float *ys = xs + XS;                  // [64][COUTP] output-gradient rows of the chunk
@@ -390,9 +411,14 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
     for (int kk = 0; kk < DW_KPB; ++kk) {
       int32_t id = -1;
       if (kk < kc) {
-        const int trow = kmap ? kmap[k0 + kk] : (k0 + kk);
-        id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
-        id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k0 + kk] : 0);
+        if constexpr (EX) {
+          const int trow = kmap ? kmap[k0 + kk] : (k0 + kk);
+          id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
+          id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k0 + kk] : 0);
+        } else {
+          id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, (k0 + kk) * ld4, 0) >>
+               in_shift;
+        }
       }
       idxv[kk] = id;
     }
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       for (int m = 0; m < 4; ++m) {
         const int64_t row = base + m * 16 + i16;
         const uint32_t off =
-            (row < blk_row1) ? (uint32_t)((row * ex.groups + grp) * COUT + q * W) * 4u : 0xFFFFFFFFu;
+            (row < blk_row1) ? (uint32_t)((row * groups + grp) * COUT + q * W) * 4u : 0xFFFFFFFFu;
         buf_load_floats<W>(rs_dy, off, g[m]);
         if constexpr (COUTP != COUT) {
 #pragma unroll
@@ -427,29 +453,48 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
         b[t][nt] = (co < COUTP) ? ys[(4 * t + q) * COUTP + co] : 0.f;
       }
 
-    float g0[4][V], g1[4][V];
-    gather(idxv[0], g0);
+    if constexpr (MT * NT == 1) {
+      // narrow layers: little MFMA work per gather -> prefetch the next offset's rows (ping-pong registers)
+      float g0[4][V], g1[4][V];
+      gather(idxv[0], g0);
 #pragma unroll
-    for (int kk = 0; kk < DW_KPB; kk += 2) {
-      if (kk < kc) {
-        if (kk + 1 < kc) gather(idxv[kk + 1 < DW_KPB ? kk + 1 : kk], g1);
+      for (int kk = 0; kk < DW_KPB; kk += 2) {
+        if (kk < kc) {
+          if (kk + 1 < kc) gather(idxv[kk + 1 < DW_KPB ? kk + 1 : kk], g1);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float *p = xs + (m * 16 + i16) * CINP + q * V;
+          for (int m = 0; m < 4; ++m) {
+            float *p = xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
-          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
+            for (int s = 0; s < V; ++s) p[s] = g0[m][s];
+          }
+          mma_chunk(kk, b);
         }
-        mma_chunk(kk, b);
+        if (kk + 1 < DW_KPB && kk + 1 < kc) {
+          if (kk + 2 < kc) gather(idxv[kk + 2 < DW_KPB ? kk + 2 : kk], g0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float *p = xs + (m * 16 + i16) * CINP + q * V;
+#pragma unroll
+            for (int s = 0; s < V; ++s) p[s] = g1[m][s];
+          }
+          mma_chunk(kk + 1 < DW_KPB ? kk + 1 : kk, b);
+        }
       }
-      if (kk + 1 < DW_KPB && kk + 1 < kc) {
-        if (kk + 2 < kc) gather(idxv[kk + 2 < DW_KPB ? kk + 2 : kk], g0);
+    } else {
+      // wide layers: 3+ MFMA tiles per gathered row hide the latency; one register set keeps occupancy up
+      float g0[4][V];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float *p = xs + (m * 16 + i16) * CINP + q * V;
+      for (int kk = 0; kk < DW_KPB; ++kk) {
+        if (kk < kc) {
+          gather(idxv[kk], g0);
 #pragma unroll
-          for (int s = 0; s < V; ++s) p[s] = g1[m][s];
+          for (int m = 0; m < 4; ++m) {
+            float *p = xs + (m * 16 + i16) * CINP + q * V;
+#pragma unroll
+            for (int s = 0; s < V; ++s) p[s] = g0[m][s];
+          }
+          mma_chunk(kk, b);
         }
-        mma_chunk(kk + 1 < DW_KPB ? kk + 1 : kk, b);
       }
     }
   }
@@ -477,7 +522,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
     }
     __syncthreads();
   }
-  float *out = partial + (((int64_t)bx * ex.groups + grp) * K + k0) * CIN * COUT;
+  float *out = partial + (((int64_t)bx * groups + grp) * K + k0) * CIN * COUT;
   for (int e = tid; e < kc * CIN * COUT; e += 256) {
     const int co = e % COUT, ci = (e / COUT) % CIN, kk = e / (CIN * COUT);
     out[e] = red[(kk * MT * 16 + ci) * NT * 16 + co];
@@ -568,24 +613,29 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
   bool done = false;
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
-#define X(CI, CO)                                                                                          \
-  if (!done && cin == CI && cout == CO) {                                                                  \
+  const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
+#define LAUNCH_DW(CI, CO, EXV)                                                                             \
+  do {                                                                                                     \
     if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, groups * K, cin, cout)) {                   \
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
       return SGNN_ENOWS;                                                                                   \
     }                                                                                                      \
     constexpr int kpb_ = DwCfg<CI, CO>::KPB;                                                               \
     const int prof = sgnn_prof_begin_launch(1, n_out * groups, cin, cout, K, 0, s);                        \
-    hipLaunchKernelGGL((k_conv_dw<CI, CO>),                                                                \
+    hipLaunchKernelGGL((k_conv_dw<CI, CO, EXV>),                                                           \
                        dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, s, \
                        x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex);                  \
     sgnn_prof_end_launch(prof, s);                                                                         \
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                  \
                        (const float *)ws, nblk, elems, dw);                                                \
     done = true;                                                                                           \
-  }
+  } while (0)
+#define X(CI, CO) \
+  if (!done && plain && cin == CI && cout == CO) LAUNCH_DW(CI, CO, false);
   CONV_DW_CASES(X)
 #undef X
+  if (!done && !plain && cin == 48 && cout == 16) LAUNCH_DW(48, 16, true);
+  if (!done && !plain && cin == 24 && cout == 8) LAUNCH_DW(24, 8, true);
   if (!done) {
     hipLaunchKernelGGL(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
                        cout, table, ld, K, n_out, dw, in_shift, ex);

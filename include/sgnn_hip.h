@@ -147,6 +147,10 @@ int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *
                             const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows,
                             void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
+/* Large 3x3x3 levels of narrow layers run a variant that reuses gathered rows along x (lane rotates instead
+ * of repeated gathers, conv.hip); 0 switches it off (A/B measurements, parity test).  Returns the old value. */
+int sgnn_conv_set_dxr(int on);
+
 /* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic
  * two-stage reduction through the workspace. */
 int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin, int cout);

@@ -31,6 +31,7 @@ PROTOTYPES = {
     'sgnn_conv_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'sgnn_conv_fwd_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_conv_set_dxr': (c_i32, [c_i32]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),

@@ -17,6 +17,7 @@
 //    fragment of lane (n, q) is the same V contiguous floats;
 //  * weights are staged KC offsets at a time to keep LDS <= 32 KiB (>= 4 workgroups per CU).
 // Exact fp32 (MFMA f32 == fmaf chain), required for the 1e-4 logit tolerance.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -216,6 +217,163 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// 3x3x3 forward / data-gradient with reuse along x.  Offsets 3g, 3g+1, 3g+2 are the dx = -1, 0, +1 taps of
+// the same (dz, dy).  When rows j and j+1 of a tile are x-adjacent sites, the dx = +1 neighbour of row j IS the
+// dx = 0 neighbour of row j+1 (and dx = -1 of j is dx = 0 of j-1), so its feature row is already in the
+// registers of the neighbouring lane: one 16-lane rotate (DPP) instead of another gather.  The rule entries
+// say exactly when this holds: lane j takes the shortcut iff its own entry equals the centre entry of the lane
+// it rotates from (the index takes the same rotate as the data, so the test is exact for any table and any
+// site order); all other lanes fall back to an exec-masked gather.  The texture addresser is the saturated
+// unit of the plain kernel (profiles/r01c_conv_pmc.txt); on raster-ordered surface blocks this removes about
+// half of its gather work.  Narrow layers only (CIN <= 16, one output tile): all 27 weight slices stay in LDS.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+#define DPP_ROW_ROR(n) (0x120 + (n))
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv_fwd_dxr(const float *__restrict__ x, int64_t n_in,
+                                                     const float *__restrict__ w, const int32_t *__restrict__ table,
+                                                     int64_t ld, int64_t n_out, float *__restrict__ y, int flags) {
+  using C = ConvCfg<CIN, COUT>;
+  constexpr int V = C::V, CINP = C::CINP, M = CONV_MREP, K = 27;
+  static_assert(C::NT == 1 && C::KC == 27, "dx-reuse kernel: one output tile, all offsets resident");
+  __shared__ __attribute__((aligned(16))) float wl[K * C::PER_K];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const unsigned tile = sgnn_xcd_tile(blockIdx.x, gridDim.x);
+  const int64_t row0 = ((int64_t)tile * 4 + wave) * (16 * M);
+  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * COUT * 4));
+  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;
+  const uint32_t ld4 = (uint32_t)ld * 4u;
+
+  for (int e = tid; e < K * C::PER_K; e += 256) {   // wl[k][n][c], zero padded
+    const int c = e % CINP, n = (e / CINP) % 16, k = e / C::PER_K;
+    float v = 0.f;
+    if (c < CIN && n < COUT) {
+      const int ks = flip ? (K - 1 - k) : k;
+      v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
+    }
+    wl[e] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_iv = [&](int k) -> int32_t { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0); };
+  auto row_id = [&](int32_t iv, int m) -> int32_t { return __builtin_amdgcn_ds_bpermute((m * 16 + r) * 4, iv); };
+  auto gather_row = [&](int32_t id, float(&a)[V]) {
+    buf_load_floats<V>(rs_x, (uint32_t)id * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a);
+    if constexpr (CINP != CIN) {
+#pragma unroll
+      for (int s = 0; s < V; ++s)
+        if (3 * V + s >= CIN) a[s] = (q == 3) ? 0.f : a[s];
+    }
+  };
+  auto mma = [&](int k, const float(&a)[M][V]) {
+    const float *bp = wl + (k * 16 + r) * CINP + q * V;
+    float b[V];
+#pragma unroll
+    for (int s = 0; s < V; ++s) b[s] = bp[s];
+#pragma unroll
+    for (int s = 0; s < V; ++s)
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m], 0, 0, 0);
+  };
+
+  // rule entries of groups g and g+1 are resident; centre rows of group g are gathered one group ahead
+  int32_t ivL[2], ivC[2], ivR[2];
+  float aC[2][M][V];
+  int32_t idC[2][M];
+  ivL[0] = load_iv(0); ivC[0] = load_iv(1); ivR[0] = load_iv(2);
+  ivL[1] = load_iv(3); ivC[1] = load_iv(4); ivR[1] = load_iv(5);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    idC[0][m] = row_id(ivC[0], m);
+    gather_row(idC[0][m], aC[0][m]);
+  }
+
+#pragma unroll
+  for (int g = 0; g < 9; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    // side entries of this group; the entries the rotate would deliver come from the centre entries
+    int32_t idL[M], idR[M];
+    bool needL[M], needR[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      idL[m] = row_id(ivL[cur], m);
+      idR[m] = row_id(ivR[cur], m);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int32_t fromPrev = dpp_i<DPP_ROW_ROR(1)>(idC[cur][m]);                       // lane r <- lane r-1 (mod 16)
+      const int32_t fromPrevTile = (m > 0) ? dpp_i<DPP_ROW_ROR(1)>(idC[cur][m > 0 ? m - 1 : 0]) : -2;
+      const int32_t fromNext = dpp_i<DPP_ROW_ROR(15)>(idC[cur][m]);                      // lane r <- lane r+1 (mod 16)
+      const int32_t fromNextTile = (m + 1 < M) ? dpp_i<DPP_ROW_ROR(15)>(idC[cur][m + 1 < M ? m + 1 : m]) : -2;
+      const int32_t eL = (r == 0) ? fromPrevTile : fromPrev;
+      const int32_t eR = (r == 15) ? fromNextTile : fromNext;
+      needL[m] = (idL[m] >= 0) && (idL[m] != eL);
+      needR[m] = (idR[m] >= 0) && (idR[m] != eR);
+    }
+    float aL[M][V], aR[M][V];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int s = 0; s < V; ++s) {
+        const float p = dpp_f<DPP_ROW_ROR(1)>(aC[cur][m][s]);
+        const float pt = (m > 0) ? dpp_f<DPP_ROW_ROR(1)>(aC[cur][m > 0 ? m - 1 : 0][s]) : 0.f;
+        const float nx = dpp_f<DPP_ROW_ROR(15)>(aC[cur][m][s]);
+        const float nt = (m + 1 < M) ? dpp_f<DPP_ROW_ROR(15)>(aC[cur][m + 1 < M ? m + 1 : m][s]) : 0.f;
+        aL[m][s] = (idL[m] >= 0) ? ((r == 0) ? pt : p) : 0.f;
+        aR[m][s] = (idR[m] >= 0) ? ((r == 15) ? nt : nx) : 0.f;
+      }
+    // lanes whose neighbour is not in the adjacent lane: exec-masked gathers
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (needL[m]) gather_row(idL[m], aL[m]);
+      if (needR[m]) gather_row(idR[m], aR[m]);
+    }
+    // next group's centre rows and the rule entries after that
+    if (g + 1 < 9) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        idC[nxt][m] = row_id(ivC[nxt], m);
+        gather_row(idC[nxt][m], aC[nxt][m]);
+      }
+    }
+    mma(3 * g + 1, aC[cur]);
+    if (g + 2 < 9) {
+      ivL[cur] = load_iv(3 * (g + 2));
+      ivC[cur] = load_iv(3 * (g + 2) + 1);
+      ivR[cur] = load_iv(3 * (g + 2) + 2);
+    }
+    mma(3 * g, aL);
+    mma(3 * g + 2, aR);
+  }
+
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = row0 + m * 16 + q * 4 + i;
+      const uint32_t off = (r < COUT && row < n_out) ? (uint32_t)(row * COUT + r) * 4u : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][i]), rs_y, off, 0, 0);
+    }
+}
+
 // any (cin, cout): one thread per output element, plain FMA.  Correctness fallback for layer
 // widths outside the SG-NN set; not a performance path.
 __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restrict__ x, int cin,
@@ -247,6 +405,17 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 
 // shapes of the generative up-sampling convolution (grouped / remapped walk): forward and data gradient
 #define CONV_EX_CASES(X) X(48, 16) X(16, 48) X(24, 8) X(8, 24)
+
+// narrow 3x3x3 layers that run the x-reuse kernel on large levels
+#define CONV_DXR_CASES(X) X(16, 16) X(8, 8) X(12, 12) X(8, 12) X(12, 16) X(12, 8) X(16, 12)
+
+static int g_use_dxr = 1;
+// 0 disables the x-reuse kernel (A/B measurements and its parity test); returns the previous setting
+SGNN_EXPORT int sgnn_conv_set_dxr(int on) {
+  const int prev = g_use_dxr;
+  g_use_dxr = on ? 1 : 0;
+  return prev;
+}
 
 #define CONV_FWD_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
@@ -287,6 +456,15 @@ SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const fl
                          w, table, ld, K, n_out, y, flags, in_shift, ex);                               \
     done = true;                                                                                        \
   } while (0)
+  const int use_dxr = g_use_dxr;
+#define X(CI, CO)                                                                                             \
+  if (!done && plain && use_dxr && !small && K == 27 && in_shift == 0 && cin == CI && cout == CO) {           \
+    hipLaunchKernelGGL((k_conv_fwd_dxr<CI, CO>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, \
+                       flags);                                                                                \
+    done = true;                                                                                              \
+  }
+  CONV_DXR_CASES(X)
+#undef X
 #define X(CI, CO) \
   if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)

@@ -406,8 +406,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 // shapes of the generative up-sampling convolution (grouped / remapped walk): forward and data gradient
 #define CONV_EX_CASES(X) X(48, 16) X(16, 48) X(24, 8) X(8, 24)
 
-// narrow 3x3x3 layers that run the x-reuse kernel on large levels
-#define CONV_DXR_CASES(X) X(16, 16) X(8, 8) X(12, 12) X(8, 12) X(12, 16) X(12, 8) X(16, 12)
+// layers that run the x-reuse kernel on large levels.  Measured at N = 366 k (scripts/bench_conv.py --dxr 0/1):
+// <16,16> 90.7 -> 78.1 us; <8,8> and <12,12> lose 12 % (too little MFMA work per row to pay for the rotates),
+// so only the 16-wide layers use it.
+#define CONV_DXR_CASES(X) X(16, 16)
 
 static int g_use_dxr = 1;
 // 0 disables the x-reuse kernel (A/B measurements and its parity test); returns the previous setting

@@ -23,7 +23,7 @@ def compute_targets(target, hierarchy, num_hierarchy_levels, truncation, use_los
     target_for_hier[-1] = target.clone()
     occ = (torch.abs(target_for_sdf) < truncation).float()
     if use_loss_masking:
-        occ[known >= UNK_THRESH] = UNK_ID
+        occ = torch.where(known >= UNK_THRESH, torch.full_like(occ, UNK_ID), occ)   # select, not a nonzero + scatter (no sync)
     target_for_occs[-1] = occ
     for h in range(L - 2, -1, -1):
         target_for_occs[h] = F.max_pool3d(target_for_occs[h + 1], kernel_size=2)
@@ -41,7 +41,7 @@ def compute_weights_missing_geo(weight_missing_geo, input_locs, target_for_occs,
     dims = target_for_occs[-1].shape[2:]
     w = torch.ones(target_for_occs[-1].shape, dtype=torch.int32, device=target_for_occs[-1].device)
     w.view(-1)[_flat(input_locs.to(w.device), dims)] += 1
-    w[torch.abs(target_for_occs[-1]) <= truncation] += 3
+    w = w + 3 * (torch.abs(target_for_occs[-1]) <= truncation).to(torch.int32)
     weights[-1] = (w == 4).float() * (weight_missing_geo - 1) + 1
     for h in range(L - 2, -1, -1):
         weights[h] = weights[h + 1][:, :, ::2, ::2, ::2].contiguous()

@@ -300,6 +300,39 @@ int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int
                        sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * On-disk formats feeding the path: .sdfs training chunks, .sdf scenes, .knw masks.
+ * Replaces torch/data_util.py:63-117 (load_train_file), :121-139 (load_scene), :142-155
+ * (load_scene_known) and the mask + collate of torch/scene_dataloader.py:101-105, :13-36.
+ *
+ * sgnn_io_layout is host-only (no GPU needed): it validates one file image and returns the byte offset
+ * and entry count of every section; nothing is copied.  kind: 0 .sdfs, 1 .sdf, 2 .knw.
+ * out[24] (int64, -1 = section absent):
+ *   [0..2] dimx, dimy, dimz   [3] voxelsize (f32 bit pattern)   [4] offset of world2grid (16 x f32)
+ *   [5] n_input  [6] offset of its (x,y,z) u32 triples  [7] offset of its f32 values      (.sdf: the scene)
+ *   [8] n_target [9] [10] likewise                                                         (.sdfs only)
+ *   [11] offset of the u8 known volume (dimz*dimy*dimx bytes, z-major)                     (.sdfs, .knw)
+ *   [12+3h .. 14+3h] count / triple offset / value offset of hierarchy level h, factor 2^(h+1) (.sdfs only)
+ *   [21] bytes consumed
+ * The device entry points work on a PACKED batch: the sections of all samples concatenated, with
+ * seg[s] .. seg[s+1] delimiting sample s (device int64[nb+1]) and voxelsize[s] its voxel size.
+ * ------------------------------------------------------------------------- */
+int sgnn_io_layout(const void *bytes, int64_t nbytes, int kind, int64_t *out);
+/* mask[i] = |value_i / voxelsize| < truncation && z_i < max_z   (scene_dataloader.py:83-86, :101) */
+int sgnn_io_flag_entries(const uint32_t *locs_xyz, const float *vals, const float *voxelsize,
+                         const int64_t *seg, int nb, int64_t n, float truncation, int64_t max_z,
+                         uint8_t *mask, sgnn_stream_t stream);
+/* rows j < *count: out_locs[j] = {z,y,x,sample} (int64), out_feats[j] = value/voxelsize of entry sel[j]
+ * (sel from sgnn_compact_mask: ascending, so file order is kept as collate keeps it) */
+int sgnn_io_emit_entries(const uint32_t *locs_xyz, const float *vals, const float *voxelsize,
+                         const int64_t *seg, int nb, const int32_t *sel, const int64_t *count,
+                         int64_t n_max, int64_t *out_locs, float *out_feats, sgnn_stream_t stream);
+/* dense[s][z][y][x] = value/voxelsize (data_util.py:44-56 sparse_to_dense_np); `dense` is (nb,d0,d1,d2)
+ * pre-filled by the caller (-inf); entries outside the volume or with z >= max_z are skipped */
+int sgnn_io_scatter_dense(const uint32_t *locs_xyz, const float *vals, const float *voxelsize,
+                          const int64_t *seg, int nb, int64_t n, int d0, int d1, int d2, int64_t max_z,
+                          float *dense, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
  * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
  * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.

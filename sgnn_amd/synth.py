@@ -79,3 +79,52 @@ def make_batch(batch_size, dims=(64, 64, 64), cfg=2, first_block=0, occupancy=0.
         'known': torch.from_numpy(np.stack(knowns, 0)),
         'hierarchy': [torch.from_numpy(np.stack(h, 0)) for h in hier],
     }
+
+
+def _sparse_of(dense_vox, band, voxelsize):
+    z, y, x = np.nonzero(band)
+    return np.stack([z, y, x], 1).astype(np.int64), (dense_vox[z, y, x] * np.float32(voxelsize)).astype(np.float32)
+
+
+def block_arrays(dims, seed, occupancy=0.05, stored_band=5.0, voxelsize=0.02):
+    """Everything one .sdfs chunk stores (data_util.py:63-117), values in metres, bands wider than the training
+    truncation so the loader's |sdf| < truncation mask has something to remove."""
+    rng = np.random.default_rng(seed)
+    dims = tuple(int(d) for d in dims)
+    sdf = _block_sdf(dims, rng, occupancy)
+    band = np.abs(sdf) < stored_band
+    known = np.where(sdf > 0, 0, np.where(np.abs(sdf) < 3.0, 1, np.minimum(255, np.ceil(-sdf) + 1))).astype(np.uint8)
+    nrm = rng.normal(size=3)
+    nrm /= np.linalg.norm(nrm)
+    zz, yy, xx = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing='ij')
+    side = ((zz - dims[0] / 2) * nrm[0] + (yy - dims[1] / 2) * nrm[1] + (xx - dims[2] / 2) * nrm[2]) < 0.25 * min(dims)
+    hier = []
+    for f in (2, 4, 8):                              # file order: 1/2, 1/4, 1/8
+        sub = (sdf[f // 2::f, f // 2::f, f // 2::f] / f)[:dims[0] // f, :dims[1] // f, :dims[2] // f]
+        hier.append(_sparse_of(sub, np.abs(sub) < stored_band, voxelsize))
+    world2grid = np.eye(4, dtype=np.float32)
+    world2grid[:3, 3] = rng.uniform(-4, 4, 3).astype(np.float32)
+    world2grid[:3, :3] /= np.float32(voxelsize)
+    return {'dims': dims, 'voxelsize': np.float32(voxelsize), 'world2grid': world2grid,
+            'input': _sparse_of(sdf, band & side, voxelsize), 'target': _sparse_of(sdf, band, voxelsize),
+            'known': known, 'hierarchy': hier}
+
+
+def write_chunk(path, dims, seed, **kw):
+    """Write one synthetic .sdfs training chunk (see sgnn_amd/data.py for the layout)."""
+    from . import data
+    a = block_arrays(dims, seed, **kw)
+    data.write_train_file(path, a['dims'], a['voxelsize'], a['world2grid'], a['input'], a['target'], a['known'],
+                          a['hierarchy'])
+    return a
+
+
+def write_scene_triple(in_path, tgt_path, dims, seed, **kw):
+    """Synthetic whole-scene input .sdf, target .sdf and its .knw (test_scene.py:60-70 data layout)."""
+    import os
+    from . import data
+    a = block_arrays(dims, seed, **kw)
+    data.write_scene(in_path, a['dims'], a['voxelsize'], a['world2grid'], a['input'])
+    data.write_scene(tgt_path, a['dims'], a['voxelsize'], a['world2grid'], a['target'])
+    data.write_known(os.path.splitext(tgt_path)[0] + '.knw', a['dims'], a['voxelsize'], a['world2grid'], a['known'])
+    return a

@@ -333,6 +333,26 @@ int sgnn_io_scatter_dense(const uint32_t *locs_xyz, const float *vals, const flo
                           float *dense, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Evaluation metrics on the device.
+ * ------------------------------------------------------------------------- */
+/* IoU ingredients of one hierarchy level (torch/loss.py:84-120 compute_iou_sparse_dense, fed as in
+ * torch/train.py:271-290).  Rows r of locs (m,4 int64 z,y,x,b) count when keep[r] != 0, or — keep == NULL —
+ * when sigmoid(logits[r*lstride]) > 0.5, or always when both are NULL.  tgt: dense (nb,1,d0,d1,d2) occupancy,
+ * float {0,1,-1 = unknown} or uint8 {0,1,255} (the reference's `.byte()` of -1).  counters (device int64
+ * [nb][3]) receive per sample {P = counted rows (minus rows on unknown voxels if use_mask), C = those whose
+ * target is 1, T = voxels with target 1}: intersection = C, union = P + T - C. */
+int sgnn_iou_counts(const int64_t *locs, const uint8_t *keep, const float *logits, int64_t lstride, int64_t m,
+                    const void *tgt, int tgt_is_u8, int nb, int d0, int d1, int d2, int use_mask,
+                    int64_t *counters, sgnn_stream_t stream);
+/* mean |pred - target| over target-surface voxels (torch/loss.py:201-231 compute_l1_tgtsurf_sparse_dense):
+ * surface = |t| < truncation (thresh < 0) or |t| <= thresh; voxels without a prediction count as -truncation;
+ * known != NULL drops voxels with known >= 2.  out3 (device double[3]) = {sum, count, mean}. */
+int64_t sgnn_l1_tgtsurf_ws_bytes(void);
+int sgnn_l1_tgtsurf(const int64_t *locs, const float *vals, int64_t m, const float *tgt_sdf, const uint8_t *known,
+                    int nb, int d0, int d1, int d2, float truncation, float thresh, double *out3, void *ws,
+                    int64_t ws_bytes, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
  * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
  * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.

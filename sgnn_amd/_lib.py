@@ -71,6 +71,9 @@ PROTOTYPES = {
     'sgnn_io_flag_entries': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_i64, c_vp, c_vp]),
     'sgnn_io_emit_entries': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_io_scatter_dense': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp]),
+    'sgnn_iou_counts': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'sgnn_l1_tgtsurf_ws_bytes': (c_i64, []),
+    'sgnn_l1_tgtsurf': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_prof_enable': (c_i32, [c_i32]),
     'sgnn_prof_disable': (c_i32, []),
     'sgnn_prof_resume': (c_i32, []),

@@ -353,6 +353,45 @@ int sgnn_l1_tgtsurf(const int64_t *locs, const float *vals, int64_t m, const flo
                     int64_t ws_bytes, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Marching cubes + mesh clean-up on the device.  Replaces
+ * torch/marching_cubes/marching_cubes.cpp: run_marching_cubes_internal (:458-476), merge_close_vertices with
+ * approx = true (:359-456), remove_degenerate_faces (:298-321), remove_duplicate_faces (:266-297) — same vertex
+ * order, same indices, same bits.  The caller chains the stages and reads the counts back in between:
+ *   sgnn_mc_count  -> *ntri (device)          triangles the volume produces; keeps per-voxel counts in ws
+ *   sgnn_mc_emit   -> verts (3*ntri,3) f32 x,y,z and vcols (3*ntri,3) u8, in the reference's z,y,x voxel order
+ *   sgnn_weld_build / sgnn_weld_sweep (repeat until *undecided == 0) / sgnn_weld_lookup
+ *                  -> creator_of[i] = the soup vertex that vertex i is merged into, is_creator[i]
+ *   sgnn_compact_mask(is_creator) -> sel;  sgnn_weld_number(sel) -> newid;  sgnn_take_rows3 -> welded verts / colours
+ *   sgnn_mesh_faces -> faces (ntri,3) remapped + keep[t] (not degenerate, first of its vertex triple);
+ *   sgnn_compact_mask(keep) + sgnn_take_rows3 -> final faces.
+ * tsdf: dense (d0,d1,d2) = (z,y,x) f32, -inf or |d| >= truncation = no data; colors: (d0,d1,d2,3) u8 or NULL (220).
+ * ------------------------------------------------------------------------- */
+int64_t sgnn_mc_ws_bytes(int d0, int d1, int d2);
+int sgnn_mc_count(const float *tsdf, int d0, int d1, int d2, float isovalue, float truncation, float thresh,
+                  void *ws, int64_t ws_bytes, int64_t *ntri, sgnn_stream_t stream);
+int sgnn_mc_emit(const float *tsdf, const uint8_t *colors, int d0, int d1, int d2, float isovalue,
+                 float truncation, float thresh, void *ws, int64_t ws_bytes, float *verts, uint8_t *vcols,
+                 sgnn_stream_t stream);
+/* hash slots needed for n keys (vertices for the weld, triangles for the duplicate-face set) */
+int64_t sgnn_weld_slots(int64_t n);
+/* cells (nv,3) i32 = grid cell of every vertex at pitch `thresh` (the reference passes 1e-5);
+ * rep/first (cap) i32, state (cap) u8: the cell table, initialised here */
+int sgnn_weld_build(const float *verts, int64_t nv, float thresh, int32_t *cells, int32_t *rep, int32_t *first,
+                    uint8_t *state, int64_t cap, sgnn_stream_t stream);
+/* one sweep of the creation fixed point; *undecided (device) = cells still open after it */
+int sgnn_weld_sweep(const int32_t *cells, const int32_t *rep, const int32_t *first, uint8_t *state, int64_t cap,
+                    int64_t *undecided, sgnn_stream_t stream);
+int sgnn_weld_lookup(const int32_t *cells, int64_t nv, const int32_t *rep, const int32_t *first,
+                     const uint8_t *state, int64_t cap, int32_t *creator_of, uint8_t *is_creator,
+                     sgnn_stream_t stream);
+/* newid[sel[p]] = p */
+int sgnn_weld_number(const int32_t *sel, int64_t n, int32_t *newid, sgnn_stream_t stream);
+int sgnn_mesh_faces(const int32_t *creator_of, const int32_t *newid, int64_t ntri, int32_t *faces, int32_t *frep,
+                    int32_t *ffirst, int64_t cap, uint8_t *keep, sgnn_stream_t stream);
+/* dst row p = src row sel[p] for (.,3) arrays of 1- or 4-byte elements */
+int sgnn_take_rows3(const void *src, int elem_bytes, const int32_t *sel, int64_t n, void *dst, sgnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optional live timing of the convolution launches (bench.py's roofline leg): HIP events are
  * recorded on the caller's stream around every sgnn_conv_fwd (kind 0) / sgnn_conv_bwd_weight
  * main kernel (kind 1).  Off by default.  sgnn_prof_get must follow a stream synchronise.

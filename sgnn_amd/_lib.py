@@ -74,6 +74,16 @@ PROTOTYPES = {
     'sgnn_iou_counts': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'sgnn_l1_tgtsurf_ws_bytes': (c_i64, []),
     'sgnn_l1_tgtsurf': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_mc_ws_bytes': (c_i64, [c_i32, c_i32, c_i32]),
+    'sgnn_mc_count': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_mc_emit': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_weld_slots': (c_i64, [c_i64]),
+    'sgnn_weld_build': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_weld_sweep': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_weld_lookup': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_weld_number': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_mesh_faces': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_take_rows3': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_prof_enable': (c_i32, [c_i32]),
     'sgnn_prof_disable': (c_i32, []),
     'sgnn_prof_resume': (c_i32, []),

@@ -299,6 +299,13 @@ int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int
                        const int32_t *ginit, int need_input_grad, int training, void *ws, int64_t ws_bytes,
                        sgnn_stream_t stream);
 
+/* Optional second lane for sgnn_prog_backward: every weight-gradient launch (dW + its reduce) runs on `stream2`
+ * with workspace `ws2`, concurrently with the dX / BatchNorm chain on the caller's stream (both only read dy); the
+ * call joins the lane before it returns control of the parameter gradients.  stream2 == NULL turns it off.
+ * Process-wide setting; ws2 must be private to the lane and >= the largest sgnn_conv_bwd_weight_ws_bytes of the
+ * program (smaller: the lane is silently not used). */
+int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_bytes);
+
 /* ---------------------------------------------------------------------------
  * On-disk formats feeding the path: .sdfs training chunks, .sdf scenes, .knw masks.
  * Replaces torch/data_util.py:63-117 (load_train_file), :121-139 (load_scene), :142-155

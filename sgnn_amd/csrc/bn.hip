@@ -186,21 +186,31 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
   if (!is_last) return;
   __threadfence();
   const int nblk = gridDim.x;
-  // `per` threads cooperate on one of the 2c scalars (strided partial sums, then an in-order sum of the `per` pieces)
-  int per = 256 / outs;
-  per = per < 1 ? 1 : (per > 16 ? 16 : per);
-  const int spp = 256 / per;                          // scalars per pass
+  // scalar o = tid % spp (consecutive lanes read consecutive doubles: coalesced rows of the partial table),
+  // `per` = 256/spp lanes share a scalar, each summing every per-th block in ascending order; their pieces are then
+  // added in lane order — a fixed order, whichever workgroup happens to be last
+  const int spp = outs < 256 ? outs : 256;            // scalars per pass
+  const int per = 256 / spp;
   double *tot = sh + 256;                             // [2c]
   for (int base = 0; base < outs; base += spp) {
-    const int o = base + tid / per, piece = tid % per;
-    double a = 0.0;
-    if (o < outs && tid < spp * per)
-      for (int blk = piece; blk < nblk; blk += per) a += __builtin_nontemporal_load(&partial[(size_t)blk * outs + o]);
-    sh[tid] = a;
+    const int o = base + tid % spp, piece = tid / spp;
+    const bool live = o < outs && piece < per;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // four independent chains keep several loads in flight
+    if (live) {
+      int blk = piece;
+      for (; blk + 3 * per < nblk; blk += 4 * per) {
+        a0 += partial[(size_t)blk * outs + o];
+        a1 += partial[(size_t)(blk + per) * outs + o];
+        a2 += partial[(size_t)(blk + 2 * per) * outs + o];
+        a3 += partial[(size_t)(blk + 3 * per) * outs + o];
+      }
+      for (; blk < nblk; blk += per) a0 += partial[(size_t)blk * outs + o];
+    }
+    sh[tid] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (o < outs && piece == 0 && tid < spp * per) {
+    if (live && piece == 0) {
       double t = 0.0;
-      for (int j = 0; j < per; ++j) t += sh[tid + j];
+      for (int j = 0; j < per; ++j) t += sh[j * spp + (tid % spp)];
       tot[o] = t;
     }
     __syncthreads();

@@ -71,7 +71,40 @@ int64_t ws_need(const View &v) {
   return need;
 }
 
+// weight-gradient lane: sgnn_prog_backward can run every dW (+ its reduce) on a second stream with its own
+// workspace, concurrently with the dX / BatchNorm chain that forms the critical path (both only READ dy)
+struct SideLane {
+  hipStream_t stream = nullptr;
+  void *ws = nullptr;
+  int64_t ws_bytes = 0;
+  hipEvent_t fork = nullptr, join = nullptr;
+} g_side;
+
+int64_t dw_ws_need(const View &v) {
+  int64_t need = 0;
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + 8 * i;
+    int64_t w = 0;
+    if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
+    if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
+    if (w > need) need = w;
+  }
+  return need;
+}
+
 }  // namespace
+
+// stream2 == NULL switches the lane off.  ws2 must not be used by anything else while a backward call is in flight.
+SGNN_EXPORT int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_bytes) {
+  if (stream2 && !g_side.fork) {
+    SGNN_HIP_TRY(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+    SGNN_HIP_TRY(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+  }
+  g_side.stream = (hipStream_t)stream2;
+  g_side.ws = stream2 ? ws2 : nullptr;
+  g_side.ws_bytes = stream2 ? ws2_bytes : 0;
+  return SGNN_OK;
+}
 
 #define PROG_TRY(call)           \
   do {                           \
@@ -200,6 +233,18 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     return sgnn_add(G(b), wrote, L.buf_floats[b], G(b), stream);
   };
   auto wants = [&](int b) { return b != 0 || need_input_grad; };
+  // dW launches go to the side lane when one is configured and its workspace is big enough
+  const bool side = g_side.stream && g_side.stream != hs && g_side.ws && g_side.ws_bytes >= dw_ws_need(v);
+  bool forked = false;
+  auto dw_lane = [&]() -> hipStream_t {
+    if (!side) return hs;
+    (void)hipEventRecord(g_side.fork, hs);                 // dy of this op is final here (all its consumers ran)
+    (void)hipStreamWaitEvent(g_side.stream, g_side.fork, 0);
+    forked = true;
+    return g_side.stream;
+  };
+  void *dw_ws = side ? g_side.ws : ws;
+  const int64_t dw_ws_bytes = side ? g_side.ws_bytes : ws_bytes;
 
   for (int i = nops - 1; i >= 0; --i) {
     const int32_t *o = ops + 8 * i;
@@ -218,18 +263,20 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     switch (type) {
       case OP_CONV_SUBM: {
         const int32_t *nbr = (const int32_t *)lev_nbr[lev];
+        const hipStream_t lane = dw_lane();
         if (wants(in0)) {
           float *t = target(in0, 0);
           PROG_TRY(sgnn_conv_fwd(dy, n, cout, P(par), 27, nbr, lev_ld[lev], n, cin, t,
                                  SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K, 0, stream));
           PROG_TRY(commit(in0, t));
         }
-        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 27, n, PG(par), 0, ws, ws_bytes,
-                                      stream));
+        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 27, n, PG(par), 0, dw_ws, dw_ws_bytes,
+                                      (sgnn_stream_t)lane));
         break;
       }
       case OP_CONV_DOWN: {
         const int64_t nc = lev_n[lev + 1];
+        const hipStream_t lane = dw_lane();
         if (wants(in0)) {
           float *t = target(in0, 0);
           PROG_TRY(sgnn_conv_fwd(dy, nc, cout, P(par), 8, (const int32_t *)lev_ptable[lev], lev_ld[lev], n, cin, t,
@@ -237,7 +284,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           PROG_TRY(commit(in0, t));
         }
         PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, (const int32_t *)lev_children[lev], lev_ld[lev + 1],
-                                      8, nc, PG(par), 0, ws, ws_bytes, stream));
+                                      8, nc, PG(par), 0, dw_ws, dw_ws_bytes, (sgnn_stream_t)lane));
         break;
       }
       case OP_UNPOOL:
@@ -280,6 +327,10 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         sgnn_set_error("sgnn_prog_backward: unknown op %d", type);
         return SGNN_EINVAL;
     }
+  }
+  if (forked) {                                       // parameter gradients are complete once the lane has drained
+    SGNN_HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
+    SGNN_HIP_TRY(hipStreamWaitEvent(hs, g_side.join, 0));
   }
   return SGNN_OK;
 }

@@ -11,6 +11,9 @@ from .. import _lib
 from .._lib import ptr
 
 
+SIDE_LANE = True     # run dW on a second stream during program backward (sgnn_prog_set_side_stream)
+
+
 class _Runtime(object):
     """Per-device scratch: grow-only workspace + an 8-word state block (count, status)."""
 
@@ -24,6 +27,25 @@ class _Runtime(object):
         if self.ws.numel() < nbytes:
             self.ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
         return self.ws
+
+    def side_lane(self, nbytes):
+        """Second stream + private workspace for the weight-gradient lane of sgnn_prog_backward (registered with the
+        library whenever it changes; only called between backward calls, when the lane is idle)."""
+        if not SIDE_LANE:
+            if getattr(self, '_side_on', False):
+                _lib.query('sgnn_prog_set_side_stream', None, None, 0)
+                self._side_on = False
+            return
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_ws = None
+        if self._side_ws is None or self._side_ws.numel() < nbytes or not getattr(self, '_side_on', False):
+            if self._side_ws is None or self._side_ws.numel() < nbytes:
+                self._side_ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
+            rc = _lib.query('sgnn_prog_set_side_stream', self._side_stream.cuda_stream, self._side_ws.data_ptr(),
+                            self._side_ws.numel())
+            assert rc == 0
+            self._side_on = True
 
     def read_count(self):
         """One D2H copy: returns the count word and raises on pending input errors."""

@@ -232,6 +232,7 @@ class _ProgramFn(Function):
         gp = _ptr_array(gptr)
         need_dx = bool(ctx.needs_input_grad[0])
         ws = rt.workspace(run.wsb)
+        rt.side_lane(run.wsb)
         _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf,
                   run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                   run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, prog.nlev, run.pptr.ctypes.data, gp.ctypes.data,

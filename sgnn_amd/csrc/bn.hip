@@ -9,37 +9,10 @@
 //   bwd    : reduce pass (dy, x read) + apply pass (dy, x read, dx written).
 // Thread mapping keeps a thread on a fixed channel group: blockDim = RPB rows x CQ column
 // groups, CQ = C/VEC, so per-channel constants live in registers.
-// The per-channel finalisation (mean / invstd / running statistics, or the backward coefficients) runs in the
-// LAST workgroup of the reduce pass to finish (ticket counter + __threadfence), summing the block partials in
-// fixed order — same result whichever workgroup ends up last, and one launch less per pass.
 #include "common.h"
-#include <mutex>
-#include <unordered_map>
 
-#define BN_MAX_BLOCKS 512
+#define BN_MAX_BLOCKS 1024
 #define BN_FLUSH 16
-
-// one zero-initialised ticket word per stream (launches on one stream are ordered, so the last workgroup's reset
-// to zero is visible to the next launch); 256 bytes of library-owned device memory per stream, never freed
-static unsigned int *bn_ticket(hipStream_t s) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, unsigned int *> tickets;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = tickets.find(s);
-  if (it != tickets.end()) return it->second;
-  unsigned int *p = nullptr;
-  if (hipMalloc((void **)&p, 256) != hipSuccess) return nullptr;
-  if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-  tickets[s] = p;
-  return p;
-}
-
-struct BnFinal {
-  unsigned int *ticket;
-  float eps, momentum;
-  float *running_mean, *running_var, *save_mean, *save_invstd;   // MODE 0
-  float *dgamma, *dbeta, *coef;                                   // MODE 1
-};
 
 struct BnGeom {
   int vec;   // 4 or 1 floats per thread-column
@@ -61,11 +34,6 @@ static int bn_blocks(int64_t n, const BnGeom &g) {
   if (b < 1) b = 1;
   if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
   return (int)b;
-}
-
-static size_t bn_shbytes(const BnGeom &g, int c) {
-  const size_t reduce = (size_t)g.rpb * g.cq * 2 * g.vec, fin = 256 + 2 * (size_t)c;
-  return (reduce > fin ? reduce : fin) * sizeof(double);
 }
 
 SGNN_EXPORT int64_t sgnn_bn_ws_bytes(int64_t n, int c) {
@@ -101,7 +69,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                                                    const float *__restrict__ invstd,
                                                    const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float leak,
-                                                   double *__restrict__ partial, BnFinal fin) {
+                                                   double *__restrict__ partial) {
   extern __shared__ double sh[];  // [rpb][2][c] would be large; reduce per column group instead
   const int tid = threadIdx.x;
   const int col = tid % cq, rloc = tid / cq;
@@ -176,66 +144,52 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
     for (int rr = 0; rr < rpb; ++rr) s += sh[((size_t)rr * cq + cg) * 2 * VEC + which * VEC + v];
     partial[((size_t)blockIdx.x * 2 + which) * c + ch] = s;
   }
+}
 
-  // ---- last workgroup to arrive finalises all channels ----
-  __shared__ int is_last;
-  __threadfence();
+// fixed-order tree sum of the block partials of one channel: one workgroup per channel, 256 lanes
+__device__ __forceinline__ void bn_reduce_channel(const double *__restrict__ partial, int nblk, int c, int ch,
+                                                  double *sh, double &s, double &s2) {
+  double a = 0.0, b = 0.0;
+  for (int blk = threadIdx.x; blk < nblk; blk += 256) {
+    a += partial[((size_t)blk * 2 + 0) * c + ch];
+    b += partial[((size_t)blk * 2 + 1) * c + ch];
+  }
+  sh[threadIdx.x] = a;
+  sh[256 + threadIdx.x] = b;
   __syncthreads();
-  if (tid == 0) is_last = (atomicAdd(fin.ticket, 1u) == gridDim.x - 1);
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  const int nblk = gridDim.x;
-  // scalar o = tid % spp (consecutive lanes read consecutive doubles: coalesced rows of the partial table),
-  // `per` = 256/spp lanes share a scalar, each summing every per-th block in ascending order; their pieces are then
-  // added in lane order — a fixed order, whichever workgroup happens to be last
-  const int spp = outs < 256 ? outs : 256;            // scalars per pass
-  const int per = 256 / spp;
-  double *tot = sh + 256;                             // [2c]
-  for (int base = 0; base < outs; base += spp) {
-    const int o = base + tid % spp, piece = tid / spp;
-    const bool live = o < outs && piece < per;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // four independent chains keep several loads in flight
-    if (live) {
-      int blk = piece;
-      for (; blk + 3 * per < nblk; blk += 4 * per) {
-        a0 += partial[(size_t)blk * outs + o];
-        a1 += partial[(size_t)(blk + per) * outs + o];
-        a2 += partial[(size_t)(blk + 2 * per) * outs + o];
-        a3 += partial[(size_t)(blk + 3 * per) * outs + o];
-      }
-      for (; blk < nblk; blk += per) a0 += partial[(size_t)blk * outs + o];
-    }
-    sh[tid] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (live && piece == 0) {
-      double t = 0.0;
-      for (int j = 0; j < per; ++j) t += sh[j * spp + (tid % spp)];
-      tot[o] = t;
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) {
+      sh[threadIdx.x] += sh[threadIdx.x + d];
+      sh[256 + threadIdx.x] += sh[256 + threadIdx.x + d];
     }
     __syncthreads();
   }
-  for (int ch = tid; ch < c; ch += 256) {
-    const double s1 = tot[ch], s2 = tot[c + ch];
-    if (MODE == 0) {
-      const double mu = s1 / (double)n;
-      double var = s2 / (double)n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      fin.save_mean[ch] = (float)mu;
-      fin.save_invstd[ch] = (float)(1.0 / sqrt(var + (double)fin.eps));
-      if (fin.running_mean) fin.running_mean[ch] = fin.momentum * fin.running_mean[ch] + (1.f - fin.momentum) * (float)mu;
-      if (fin.running_var) {
-        const double unb = var * ((double)n / (double)(n > 1 ? n - 1 : 1));
-        fin.running_var[ch] = fin.momentum * fin.running_var[ch] + (1.f - fin.momentum) * (float)unb;
-      }
-    } else {
-      if (fin.dbeta) fin.dbeta[ch] = (float)s1;
-      if (fin.dgamma) fin.dgamma[ch] = (float)s2;
-      fin.coef[ch] = (float)(s1 / (double)n);
-      fin.coef[c + ch] = (float)(s2 / (double)n);
+  s = sh[0];
+  s2 = sh[256];
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize_fwd(const double *__restrict__ partial, int nblk,
+                                                        int64_t n, int c, float eps, float momentum,
+                                                        float *__restrict__ running_mean,
+                                                        float *__restrict__ running_var,
+                                                        float *__restrict__ save_mean,
+                                                        float *__restrict__ save_invstd) {
+  __shared__ double sh[512];
+  const int ch = blockIdx.x;
+  double s, s2;
+  bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
+  if (threadIdx.x == 0) {
+    const double mean = s / (double)n;
+    double var = s2 / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[ch] = momentum * running_mean[ch] + (1.f - momentum) * (float)mean;
+    if (running_var) {
+      const double unb = var * ((double)n / (double)(n > 1 ? n - 1 : 1));
+      running_var[ch] = momentum * running_var[ch] + (1.f - momentum) * (float)unb;
     }
   }
-  if (tid == 0) *fin.ticket = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__ running_mean,
@@ -270,6 +224,22 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
       yv[v] = t > 0.f ? t : t * leak;
     }
     store_vec<VEC>(y + g * VEC, yv);
+  }
+}
+
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); also dgamma/dbeta.  One workgroup per channel.
+__global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restrict__ partial, int nblk,
+                                                        int64_t n, int c, float *__restrict__ dgamma,
+                                                        float *__restrict__ dbeta, float *__restrict__ coef) {
+  __shared__ double sh[512];
+  const int ch = blockIdx.x;
+  double s, s2;
+  bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[ch] = (float)s;
+    if (dgamma) dgamma[ch] = (float)s2;
+    coef[ch] = (float)(s / (double)n);
+    coef[c + ch] = (float)(s2 / (double)n);
   }
 }
 
@@ -317,15 +287,15 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
       return SGNN_ENOWS;
     }
     const int nblk = bn_blocks(n, g);
-    const size_t shbytes = bn_shbytes(g, c);
-    BnFinal fin{bn_ticket(s), eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, nullptr};
-    SGNN_CHECK_ARG(fin.ticket != nullptr);
+    const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
     if (g.vec == 4)
       hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
-                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, fin);
+                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
     else
       hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
-                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, fin);
+                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
     SGNN_HIP_TRY(hipMemsetAsync(save_invstd, 0, c * sizeof(float), s));
@@ -365,17 +335,17 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
   }
   const BnGeom g = bn_geom(c);
   const int nblk = bn_blocks(n, g);
-  const size_t shbytes = bn_shbytes(g, c);
+  const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
   double *partial = (double *)ws;
   float *coef = (float *)((char *)ws + (size_t)BN_MAX_BLOCKS * 2 * c * sizeof(double));
-  BnFinal fin{bn_ticket(s), 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta, coef};
-  SGNN_CHECK_ARG(fin.ticket != nullptr);
   if (g.vec == 4)
     hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, partial, fin);
+                       save_invstd, gamma, beta, leak, partial);
   else
     hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, partial, fin);
+                       save_invstd, gamma, beta, leak, partial);
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
+                     coef);
   const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
   if (g.vec == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,

@@ -12,7 +12,7 @@
 #include "common.h"
 
 #define BN_MAX_BLOCKS 1024
-#define BN_FLUSH 16
+#define BN_FLUSH 4
 
 struct BnGeom {
   int vec;   // 4 or 1 floats per thread-column

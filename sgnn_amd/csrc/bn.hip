@@ -11,8 +11,8 @@
 // groups, CQ = C/VEC, so per-channel constants live in registers.
 #include "common.h"
 
-#define BN_MAX_BLOCKS 1024
-#define BN_FLUSH 4
+#define BN_MAX_BLOCKS 2048
+#define BN_FLUSH 2
 
 struct BnGeom {
   int vec;   // 4 or 1 floats per thread-column

@@ -404,7 +404,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 }
 
 // shapes of the generative up-sampling convolution (grouped / remapped walk): forward and data gradient
-#define CONV_EX_CASES(X) X(48, 16) X(16, 48) X(24, 8) X(8, 24)
+// + the dense-bottleneck shapes: their k4s2 convolutions run offset-split (groups = slices of the 64 taps, partial
+// outputs summed by sgnn_sum_groups) because a 2 048-row level would otherwise be 32 workgroups walking 64 offsets
+#define CONV_EX_CASES(X) \
+  X(48, 16) X(16, 48) X(24, 8) X(8, 24) X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
 // layers that run the x-reuse kernel on large levels.  Measured at N = 366 k (scripts/bench_conv.py --dxr 0/1):
 // <16,16> 90.7 -> 78.1 us; <8,8> and <12,12> lose 12 % (too little MFMA work per row to pay for the rotates),

@@ -41,6 +41,30 @@ def conv_fwd_raw(x, cin, w, K, table, ld, n_out, cout, flags=0, in_shift=0):
     return y
 
 
+_SPLIT_SHAPES = {(16, 24), (24, 16), (24, 32), (32, 24), (64, 32), (32, 64), (56, 28), (28, 56)}
+_arange_cache = {}
+
+
+def conv_fwd_split(x, cin, w, K, table, ld, n_out, cout, flags=0):
+    """Same result as conv_fwd_raw up to summation order, for few rows and many offsets (the dense bottleneck's
+    k4s2 convolutions: 256..16 384 rows, 64 taps): the taps are cut into G slices that run as the `groups` of
+    sgnn_conv_fwd_ex — G times the workgroups, 1/G of the serial offset walk — and sgnn_sum_groups adds the slices."""
+    tiles = (n_out + 63) // 64
+    G = 1
+    while G * 2 <= K and K % (G * 2) == 0 and tiles * G < 1024:
+        G *= 2
+    if G == 1 or (cin, cout) not in _SPLIT_SHAPES:
+        return conv_fwd_raw(x, cin, w, K, table, ld, n_out, cout, flags, 0)
+    key = (str(x.device), K)
+    kmap = _arange_cache.get(key)
+    if kmap is None:
+        kmap = _arange_cache[key] = torch.arange(K, dtype=torch.int32, device=x.device)
+    part = torch.empty(n_out, G * cout, dtype=torch.float32, device=x.device)
+    _lib.call('sgnn_conv_fwd_ex', ptr(x), x.shape[0], cin, ptr(w), K // G, ptr(table), ld, n_out, cout, ptr(part), flags,
+              0, ptr(kmap), None, 1, G, K)
+    return sum_groups_raw(part, cout, n_out, G)
+
+
 def conv_dw_raw(x, cin, dy, cout, table, ld, K, n_out, in_shift=0):
     rt = runtime(x.device)
     dw = torch.empty(K, cin, cout, dtype=torch.float32, device=x.device)
@@ -59,7 +83,10 @@ class SparseConv(Function):
         x, weight = _f32c(x), _f32c(weight)
         K, cin, cout = weight.shape
         assert x.shape[1] == cin, 'feature width %d != nIn %d' % (x.shape[1], cin)
-        y = conv_fwd_raw(x, cin, weight, K, table_f, ld_f, n_out, cout, 0, in_shift)
+        if K == 64 and not in_shift:
+            y = conv_fwd_split(x, cin, weight, K, table_f, ld_f, n_out, cout, 0)
+        else:
+            y = conv_fwd_raw(x, cin, weight, K, table_f, ld_f, n_out, cout, 0, in_shift)
         ctx.save_for_backward(x, weight)
         ctx.tables = (table_f, ld_f, n_out, table_b, ld_b, n_in, flags_b, in_shift)
         return y
@@ -76,6 +103,8 @@ class SparseConv(Function):
                 # gradient w.r.t. the virtual (replicated) rows, then summed over each group
                 dfull = conv_fwd_raw(dy, cout, weight, K, table_b, ld_b, n_in, cin, flags_b, 0)
                 dx = sum_groups_raw(dfull, cin, n_in >> in_shift, 1 << in_shift)
+            elif K == 64:
+                dx = conv_fwd_split(dy, cout, weight, K, table_b, ld_b, n_in, cin, flags_b)
             else:
                 dx = conv_fwd_raw(dy, cout, weight, K, table_b, ld_b, n_in, cin, flags_b, 0)
         if ctx.needs_input_grad[1]:

@@ -62,11 +62,19 @@ def collect_prof(lib):
         if rc != 0:
             continue
         key = (kind.value, cin.value, cout.value, K.value)
-        a = agg.setdefault(key, {'launches': 0, 'ms': 0.0, 'bytes': 0.0, 'flops': 0.0})
+        a = agg.setdefault(key, {'launches': 0, 'ms': 0.0, 'bytes': 0.0, 'flops': 0.0, 'by_size': {}})
+        fl = 2.0 * n_out.value * K.value * cin.value * cout.value
         a['launches'] += 1
         a['ms'] += ms.value
         a['bytes'] += conv_alg_bytes(kind.value, n_out.value, cin.value, cout.value, K.value)
-        a['flops'] += 2.0 * n_out.value * K.value * cin.value * cout.value
+        a['flops'] += fl
+        # the same kernel serves levels of very different size: keep the launches apart by output rows (powers of 4)
+        bucket = 0 if n_out.value <= 0 else int(np.floor(np.log(max(n_out.value, 1)) / np.log(4.0)))
+        b = a['by_size'].setdefault(bucket, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'rows': 0})
+        b['launches'] += 1
+        b['ms'] += ms.value
+        b['flops'] += fl
+        b['rows'] += n_out.value
     return agg
 
 
@@ -194,6 +202,15 @@ def main():
                          'TFLOPs': round(tfs, 2), 'frac_of_fp32_mfma_peak': round(tfs / FP32_MFMA_PEAK_TF, 4),
                          'conv_ms_per_step': round(sum(a['ms'] for a in agg.values()) / max(n_prof_steps, 1), 3),
                          'profiled_steps': n_prof_steps,
+                         # `frac` above is over ALL launches of the kernel; split by level size it is throughput-bound
+                         # only on the big levels and launch/latency-bound on the small ones
+                         'by_level_size': [
+                             {'mean_rows': int(b['rows'] / b['launches']), 'launches': b['launches'],
+                              'avg_us': round(1e3 * b['ms'] / b['launches'], 1),
+                              'share_of_kernel_time': round(b['ms'] / dom['ms'], 3),
+                              'TFLOPs': round(b['flops'] / (b['ms'] * 1e-3) / 1e12, 2),
+                              'frac_of_fp32_mfma_peak': round(b['flops'] / (b['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+                             for _, b in sorted(dom['by_size'].items(), reverse=True) if b['ms'] > 0],
                          'top_kernels': kernels[:6]})
         levels = None
         if outs is not None:

@@ -202,13 +202,70 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__
   }
 }
 
+// Small levels (few block partials, C <= BN_FUSE_MAXC): the apply kernels finalise the statistics themselves — every
+// workgroup sums the short partial table in the same fixed order into LDS, workgroup 0 also stores the results the
+// later passes / the caller need — and the separate finalize launch disappears.
+#define BN_FUSE_BLOCKS 128
+#define BN_FUSE_MAXC 64
+
+struct BnFuse {
+  const double *partial;   // NULL: statistics come from the mean/invstd (or coef) arrays
+  int nblk;
+  float eps, momentum;
+  float *running_mean, *running_var, *save_mean, *save_invstd;   // forward
+  float *dgamma, *dbeta;                                          // backward
+};
+
+// sums of channel ch over the block partials, ascending block order
+__device__ __forceinline__ void bn_fuse_sums(const BnFuse &f, int c, int ch, double &s1, double &s2) {
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  int blk = 0;
+  for (; blk + 1 < f.nblk; blk += 2) {
+    a0 += f.partial[((size_t)blk * 2 + 0) * c + ch];
+    b0 += f.partial[((size_t)blk * 2 + 1) * c + ch];
+    a1 += f.partial[((size_t)blk * 2 + 2) * c + ch];
+    b1 += f.partial[((size_t)blk * 2 + 3) * c + ch];
+  }
+  if (blk < f.nblk) {
+    a0 += f.partial[((size_t)blk * 2 + 0) * c + ch];
+    b0 += f.partial[((size_t)blk * 2 + 1) * c + ch];
+  }
+  s1 = a0 + a1;
+  s2 = b0 + b1;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t n, int c, int cq,
                                                  const float *__restrict__ mean,
                                                  const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma,
                                                  const float *__restrict__ beta, float leak,
-                                                 float *__restrict__ y) {
+                                                 float *__restrict__ y, BnFuse fuse) {
+  __shared__ float s_mean[BN_FUSE_MAXC], s_inv[BN_FUSE_MAXC];
+  if (fuse.partial) {
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      double s1, s2;
+      bn_fuse_sums(fuse, c, ch, s1, s2);
+      const double mu = s1 / (double)n;
+      double var = s2 / (double)n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float fm = (float)mu, fi = (float)(1.0 / sqrt(var + (double)fuse.eps));
+      s_mean[ch] = fm;
+      s_inv[ch] = fi;
+      if (blockIdx.x == 0) {
+        fuse.save_mean[ch] = fm;
+        fuse.save_invstd[ch] = fi;
+        if (fuse.running_mean) fuse.running_mean[ch] = fuse.momentum * fuse.running_mean[ch] + (1.f - fuse.momentum) * fm;
+        if (fuse.running_var) {
+          const double unb = var * ((double)n / (double)(n > 1 ? n - 1 : 1));
+          fuse.running_var[ch] = fuse.momentum * fuse.running_var[ch] + (1.f - fuse.momentum) * (float)unb;
+        }
+      }
+    }
+    __syncthreads();
+    mean = s_mean;
+    invstd = s_inv;
+  }
   // flat element-group index; channel group = g % cq
   const int64_t groups = n * cq;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -249,7 +306,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                      const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float leak, int training,
-                                                     const float *__restrict__ coef, float *__restrict__ dx) {
+                                                     const float *__restrict__ coef, float *__restrict__ dx, BnFuse fuse) {
+  __shared__ float s_coef[2 * BN_FUSE_MAXC];
+  if (fuse.partial) {
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      double s1, s2;
+      bn_fuse_sums(fuse, c, ch, s1, s2);
+      s_coef[ch] = (float)(s1 / (double)n);
+      s_coef[c + ch] = (float)(s2 / (double)n);
+      if (blockIdx.x == 0) {
+        if (fuse.dbeta) fuse.dbeta[ch] = (float)s1;
+        if (fuse.dgamma) fuse.dgamma[ch] = (float)s2;
+      }
+    }
+    __syncthreads();
+    coef = s_coef;
+  }
   const int64_t groups = n * cq;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
@@ -280,6 +352,7 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
   const BnGeom g = bn_geom(c);
+  BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (training && n > 0) {
     SGNN_CHECK_ARG(x);
     if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
@@ -294,8 +367,11 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
     else
       hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
                          nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd);
+    if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)   // small level: k_bn_apply finalises
+      fuse = BnFuse{(const double *)ws, nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
+    else
+      hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
+                         running_mean, running_var, save_mean, save_invstd);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
     SGNN_HIP_TRY(hipMemsetAsync(save_invstd, 0, c * sizeof(float), s));
@@ -308,10 +384,10 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
     const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
     if (g.vec == 4)
       hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
-                         (const float *)save_invstd, gamma, beta, leak, y);
+                         (const float *)save_invstd, gamma, beta, leak, y, fuse);
     else
       hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
-                         (const float *)save_invstd, gamma, beta, leak, y);
+                         (const float *)save_invstd, gamma, beta, leak, y, fuse);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -344,15 +420,19 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
   else
     hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
                        save_invstd, gamma, beta, leak, partial);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
-                     coef);
+  BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)
+    fuse = BnFuse{(const double *)partial, nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
+  else
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
+                       coef);
   const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
   if (g.vec == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx);
+                       gamma, beta, leak, training, (const float *)coef, dx, fuse);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx);
+                       gamma, beta, leak, training, (const float *)coef, dx, fuse);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

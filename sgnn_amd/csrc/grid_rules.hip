@@ -403,14 +403,28 @@ SGNN_EXPORT int64_t sgnn_down2_ws_bytes(int64_t nf) {
   return 2 * nf * (int64_t)sizeof(int32_t) + (nblk + 1) * (int64_t)sizeof(int32_t) + 256;
 }
 
+// one launch initialises the coarse hash (keys = empty, values = INT_MAX) and the rank scratch (-1)
+__global__ __launch_bounds__(256) void k_down2_init(unsigned long long *__restrict__ ckeys, int32_t *__restrict__ cvals,
+                                                   int64_t ccap, int32_t *__restrict__ rank_at, int64_t nf) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t top = ccap > nf ? ccap : nf;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < top; i += stride) {
+    if (i < ccap) {
+      ckeys[i] = ~0ull;
+      cvals[i] = 0x7FFFFFFF;
+    }
+    if (i < nf) rank_at[i] = -1;
+  }
+}
+
 SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint64_t *ckeys, int32_t *cvals,
                                     int64_t ccap, int32_t *parent, int32_t *coarse_coords,
                                     int64_t *n_coarse, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(nf >= 0 && n_coarse && ckeys && cvals);
   SGNN_CHECK_ARG(ccap >= 2 * nf && ccap >= 2 && (ccap & (ccap - 1)) == 0 && ccap < (1ll << 31));
-  SGNN_HIP_TRY(hipMemsetAsync(ckeys, 0xFF, (size_t)ccap * sizeof(uint64_t), s));
   if (nf == 0) {
+    SGNN_HIP_TRY(hipMemsetAsync(ckeys, 0xFF, (size_t)ccap * sizeof(uint64_t), s));
     SGNN_HIP_TRY(hipMemsetAsync(n_coarse, 0, sizeof(int64_t), s));
     return SGNN_OK;
   }
@@ -423,9 +437,8 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
   int32_t *slot_of = (int32_t *)ws;
   int32_t *rank_at = slot_of + nf;
   int32_t *block_sums = rank_at + nf;
-  // cvals := INT_MAX (0x7F7F7F7F is large enough: > any 31-bit row < 2^31-1? use explicit fill)
-  SGNN_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cvals, 0x7FFFFFFF, (size_t)ccap, s));
-  SGNN_HIP_TRY(hipMemsetAsync(rank_at, 0xFF, (size_t)nf * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_down2_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s, (unsigned long long *)ckeys,
+                     cvals, ccap, rank_at, nf);
   const int g = sgnn_grid_for(nf, 256, 8192);
   hipLaunchKernelGGL(k_down2_insert, dim3(g), dim3(256), 0, s, (const int4 *)fine_coords, nf,
                      (unsigned long long *)ckeys, cvals, (uint64_t)(ccap - 1), slot_of);

@@ -173,6 +173,11 @@ int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, const float *
                 const float *beta, const float *save_mean, const float *save_invstd, int training,
                 float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
                 sgnn_stream_t stream);
+/* same, with dx = (BatchNorm gradient) + addend[...]; addend may be dx itself (in-place accumulation) or NULL */
+int sgnn_bn_bwd_add(const float *x, const float *dy, int64_t n, int c, const float *gamma, const float *beta,
+                    const float *save_mean, const float *save_invstd, int training, float leak,
+                    const float *addend, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
+                    sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Row movement (all pure copies / sums, fp32 rows of c floats)

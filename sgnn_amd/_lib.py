@@ -37,6 +37,7 @@ PROTOTYPES = {
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),
     'sgnn_bn_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_bn_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_bn_bwd_add': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_gather_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_scatter_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_gather_sum': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),

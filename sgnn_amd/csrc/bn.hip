@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                      const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float leak, int training,
-                                                     const float *__restrict__ coef, float *__restrict__ dx, BnFuse fuse) {
+                                                     const float *__restrict__ coef, float *dx, BnFuse fuse,
+                                                     const float *addend) {
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
   if (fuse.partial) {
     for (int ch = threadIdx.x; ch < c; ch += 256) {
@@ -339,6 +340,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
       float d = dz;
       if (training) d = dz - coef[ch] - xh * coef[c + ch];
       ov[v] = d * gm * invstd[ch];
+    }
+    if (addend) {   // gradient already accumulated for this buffer (may be dx itself: element-wise, in place)
+      float av[VEC];
+      load_vec<VEC>(addend + g * VEC, av);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ov[v] += av[v];
     }
     store_vec<VEC>(dx + g * VEC, ov);
   }
@@ -397,6 +404,14 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
                             const float *beta, const float *save_mean, const float *save_invstd, int training,
                             float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
                             sgnn_stream_t stream) {
+  return sgnn_bn_bwd_add(x, dy, n, c, gamma, beta, save_mean, save_invstd, training, leak, nullptr, dx, dgamma, dbeta,
+                         ws, ws_bytes, stream);
+}
+
+SGNN_EXPORT int sgnn_bn_bwd_add(const float *x, const float *dy, int64_t n, int c, const float *gamma,
+                                const float *beta, const float *save_mean, const float *save_invstd, int training,
+                                float leak, const float *addend, float *dx, float *dgamma, float *dbeta, void *ws,
+                                int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   if (n == 0) {
@@ -429,10 +444,10 @@ SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, c
   const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
   if (g.vec == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx, fuse);
+                       gamma, beta, leak, training, (const float *)coef, dx, fuse, addend);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx, fuse);
+                       gamma, beta, leak, training, (const float *)coef, dx, fuse, addend);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

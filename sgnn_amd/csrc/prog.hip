@@ -216,17 +216,28 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     return SGNN_ENOWS;
   }
   hipStream_t hs = (hipStream_t)stream;
+  // gradient state of a buffer: 0 nothing yet, 1 G(b) holds it, 2 it EQUALS the gradient of buffer alias[b]
+  // (an AddTable input whose only contribution so far is the sum's gradient: nothing is copied until something
+  // has to be added to it, and a reader just follows the alias)
   std::vector<char> init(nbuf);
+  std::vector<int> alias(nbuf, -1);
   for (int b = 0; b < nbuf; ++b) init[b] = ginit[b] != 0;
   auto X = [&](int b) { return (b == 0 && input) ? input : arena + L.buf_off[b]; };
   auto G = [&](int b) { return garena + L.buf_off[b]; };
+  auto GR = [&](int b) -> const float * { return init[b] == 2 ? G(alias[b]) : G(b); };   // where b's gradient is read
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto PG = [&](int p) { return (p >= 0 && p < nparams) ? (float *)pgrads[p] : nullptr; };
   float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
-  // where a kernel should write the gradient of buffer b: the buffer itself if nothing was accumulated yet
-  auto target = [&](int b, int which) { return init[b] ? scratch[which] : G(b); };
+  // where a kernel should write the gradient of buffer b: the buffer itself unless it already holds data
+  auto target = [&](int b, int which) { return init[b] == 1 ? scratch[which] : G(b); };
   auto commit = [&](int b, float *wrote) -> int {  // fold a freshly written gradient into buffer b
     if (wrote == G(b)) {
+      if (init[b] == 2) {                            // G(b) = fresh + the aliased gradient
+        const int a = alias[b];
+        alias[b] = -1;
+        init[b] = 1;
+        return sgnn_add(G(b), G(a), L.buf_floats[b], G(b), stream);
+      }
       init[b] = 1;
       return SGNN_OK;
     }
@@ -259,7 +270,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       }
       continue;
     }
-    const float *dy = G(out);
+    const float *dy = GR(out);
     switch (type) {
       case OP_CONV_SUBM: {
         const int32_t *nbr = (const int32_t *)lev_nbr[lev];
@@ -297,24 +308,35 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         break;
       case OP_BN: {
         const float *save = arena + L.aux_off[i];
-        float *t = wants(in0) ? target(in0, 0) : scratch[0];
-        PROG_TRY(sgnn_bn_bwd(X(in0), dy, n, cin, P(par), P(par + 1), save, save + cin, training, opf[4 * i + 2], t,
-                             PG(par), PG(par + 1), ws, ws_bytes, stream));
-        if (wants(in0)) PROG_TRY(commit(in0, t));
+        // the kernel adds what the buffer already holds (in place) or the aliased gradient: no scratch pass, no k_add
+        const float *addend = !wants(in0) ? nullptr : (init[in0] == 1 ? G(in0) : (init[in0] == 2 ? G(alias[in0]) : nullptr));
+        float *t = wants(in0) ? G(in0) : scratch[0];
+        PROG_TRY(sgnn_bn_bwd_add(X(in0), dy, n, cin, P(par), P(par + 1), save, save + cin, training, opf[4 * i + 2],
+                                 addend, t, PG(par), PG(par + 1), ws, ws_bytes, stream));
+        if (wants(in0)) {
+          init[in0] = 1;
+          alias[in0] = -1;
+        }
         break;
       }
-      case OP_ADD:
+      case OP_ADD: {
+        const int src = init[out] == 2 ? alias[out] : out;      // the buffer that physically holds dy
         for (int side = 0; side < 2; ++side) {
           const int b = side ? in1 : in0;
           if (!wants(b)) continue;
-          if (init[b]) {
+          if (init[b] == 1) {
             PROG_TRY(sgnn_add(G(b), dy, L.buf_floats[b], G(b), stream));
-          } else {
-            SGNN_HIP_TRY(hipMemcpyAsync(G(b), dy, (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+          } else if (init[b] == 2) {                            // two aliased contributions: materialise the sum
+            PROG_TRY(sgnn_add(G(alias[b]), dy, L.buf_floats[b], G(b), stream));
             init[b] = 1;
+            alias[b] = -1;
+          } else {
+            init[b] = 2;
+            alias[b] = src;
           }
         }
         break;
+      }
       case OP_JOIN: {
         float *ta = wants(in0) ? target(in0, 0) : nullptr;
         float *tb = wants(in1) ? target(in1, 1) : nullptr;
@@ -328,6 +350,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         return SGNN_EINVAL;
     }
   }
+  if (need_input_grad && init[0] == 2)                // the caller reads G(0): an alias has to become a copy
+    SGNN_HIP_TRY(hipMemcpyAsync(G(0), G(alias[0]), (size_t)L.buf_floats[0] * sizeof(float), hipMemcpyDeviceToDevice, hs));
   if (forked) {                                       // parameter gradients are complete once the lane has drained
     SGNN_HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
     SGNN_HIP_TRY(hipStreamWaitEvent(hs, g_side.join, 0));

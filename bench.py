@@ -32,8 +32,8 @@ FP32_MFMA_PEAK_TF = 157.3    # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--batch', type=int, default=32, help='blocks per GPU')
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--occupancy', type=float, default=0.05)

@@ -87,3 +87,27 @@ def test_synthetic_batch_layout_and_determinism():
     assert torch.unique(key).numel() == key.numel()
     occ = locs.shape[0] / (3 * 32 ** 3)
     assert 0.01 < occ < 0.12
+
+
+def test_fast_adam_matches_torch_adam():
+    """FastAdam = torch.optim.Adam(fused=True) without the per-step Python loop: identical parameters and state,
+    also when some parameters receive no gradient on some steps (an empty generative level)."""
+    import copy
+    from sgnn_amd.train import FastAdam
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3), torch.nn.Linear(3, 3))
+    b = copy.deepcopy(a)
+    oa = FastAdam(a.parameters(), lr=1e-2, weight_decay=0.01)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-2, weight_decay=0.01, fused=True)
+    for it in range(8):
+        x = torch.randn(4, 5)
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad(set_to_none=True)
+            h = net[1](net[0](x))
+            (h if it in (2, 3, 6) else net[2](h)).pow(2).sum().backward()
+            opt.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+        assert float(oa.state[pa]['step']) == float(ob.state[pb]['step'])
+        assert torch.equal(oa.state[pa]['exp_avg_sq'], ob.state[pb]['exp_avg_sq'])
+    assert oa.state_dict()['param_groups'][0]['lr'] == 1e-2

@@ -169,14 +169,38 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
     return;
   }
   const int4 c = coords[j];
+  // the 13 probes are independent random L2 lines: issue all first-slot key loads, then all value loads of the hits,
+  // and only walk on for the (rare, load factor <= 0.5) collisions — 2 dependent round trips instead of up to 26
+  uint64_t key[13], slot[13], got[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) {
     const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
     const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
     const bool ok = ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
-    const int32_t r = ok ? sgnn_hash_find(keys, vals, mask, sgnn_pack_key(z, y, x, c.w)) : -1;
-    nbr[(int64_t)k * ld + j] = r;
-    if (r >= 0) nbr[(int64_t)(26 - k) * ld + r] = (int32_t)j;
+    key[k] = ok ? sgnn_pack_key(z, y, x, c.w) : SGNN_EMPTY_KEY;     // the empty key never matches a stored one
+    slot[k] = sgnn_hash64(key[k]) & mask;
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) got[k] = key[k] == SGNN_EMPTY_KEY ? SGNN_EMPTY_KEY : keys[slot[k]];
+  int32_t r[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) r[k] = (got[k] == key[k] && key[k] != SGNN_EMPTY_KEY) ? vals[slot[k]] : -1;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    if (got[k] != key[k] && got[k] != SGNN_EMPTY_KEY) {              // first slot held another key: keep probing
+      uint64_t sl = (slot[k] + 1) & mask;
+      while (true) {
+        const uint64_t kk = keys[sl];
+        if (kk == key[k]) {
+          r[k] = vals[sl];
+          break;
+        }
+        if (kk == SGNN_EMPTY_KEY) break;
+        sl = (sl + 1) & mask;
+      }
+    }
+    nbr[(int64_t)k * ld + j] = r[k];
+    if (r[k] >= 0) nbr[(int64_t)(26 - k) * ld + r[k]] = (int32_t)j;
   }
   nbr[(int64_t)13 * ld + j] = (int32_t)j;
 }

@@ -155,3 +155,49 @@ def marching_cubes(tsdf, colors, isovalue, truncation, thresh, output_filename):
         export_marching_cubes(tsdf, colors, isovalue, truncation, thresh, output_filename)
     else:
         save_mesh(*run_marching_cubes(tsdf, colors, isovalue, truncation, thresh), output_filename)
+
+
+def dense_from_sparse(locs, vals, dims, device=None):
+    """data_util.sparse_to_dense_np(locs, vals, dims[2], dims[1], dims[0], -inf) for one volume, on the device:
+    locs (N,3) z,y,x; vals (N,) or (N,1).  Later duplicates win, like numpy's fancy assignment."""
+    _lib.require_gpu()
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    locs = torch.as_tensor(locs).to(dev).long()
+    vals = torch.as_tensor(vals).to(dev).float().reshape(-1)
+    d0, d1, d2 = (int(v) for v in dims)
+    dense = torch.full((d0, d1, d2), -float('inf'), dtype=torch.float32, device=dev)
+    if len(locs):
+        dense.view(-1)[(locs[:, 0] * d1 + locs[:, 1]) * d2 + locs[:, 2]] = vals
+    return dense
+
+
+def save_predictions(output_path, names, inputs, target_for_sdf, target_for_occs, output_sdf, output_occs, world2grids,
+                     truncation, thresh=1):
+    """Mesh part of data_util.save_predictions (data_util.py:249-284): '<name>input-mesh.ply', '<name>pred-mesh.ply'
+    and, with targets, '<name>target-mesh.ply' — the files test_scene.py:98 writes.  The per-level point-cloud dumps
+    (output_occs / target_for_occs given) go through `plyfile` in the reference and are not reproduced."""
+    if output_occs is not None or target_for_occs is not None:
+        raise NotImplementedError('point-cloud dumps of the hierarchy levels are outside this build (plyfile)')
+    os.makedirs(output_path, exist_ok=True)
+    in_locs = np.asarray(inputs[0].cpu() if torch.is_tensor(inputs[0]) else inputs[0])
+    in_feats = np.asarray(inputs[1].cpu() if torch.is_tensor(inputs[1]) else inputs[1])
+    if target_for_sdf is None:
+        o0 = output_sdf[0][0]
+        o0 = np.asarray(o0.cpu() if torch.is_tensor(o0) else o0)
+        dims = np.maximum(np.max(o0, 0), np.max(in_locs, 0)) + 1          # data_util.py:257, the quirk included
+    else:
+        dims = target_for_sdf.shape[2:]
+    trunc = truncation - 0.1
+    for k, name in enumerate(names):
+        m = in_locs[:, -1] == k
+        dense = dense_from_sparse(in_locs[m][:, :-1], in_feats[m], dims[:3])
+        marching_cubes(dense, None, 0, trunc, 10, os.path.join(output_path, name + 'input-mesh.ply'))
+        if output_sdf[k] is not None:
+            pl, pv = output_sdf[k]
+            pl = np.asarray(pl.cpu() if torch.is_tensor(pl) else pl)
+            dense = dense_from_sparse(pl[:, :3], pv, dims[:3])
+            marching_cubes(dense, None, 0, trunc, 10, os.path.join(output_path, name + 'pred-mesh.ply'))
+        if target_for_sdf is not None:
+            t = target_for_sdf[k, 0]
+            t = t if torch.is_tensor(t) else torch.from_numpy(np.asarray(t))
+            marching_cubes(t.float(), None, 0, trunc, 10, os.path.join(output_path, name + 'target-mesh.ply'))

@@ -21,6 +21,26 @@ import marching_cubes_cpp as ref  # noqa: E402
 from mc_cases import CASES, make_volume  # noqa: E402
 
 
+def save_predictions_case():
+    """The reference's data_util.save_predictions (data_util.py:249-284) exactly as test_scene.py:98 calls it
+    (targets and occupancy levels None): its own marching_cubes.py wrapper + the compiled extension; `plyfile` is a
+    stub (only the point-cloud branches, not taken here, use it)."""
+    import tempfile
+    import types
+    sys.modules.setdefault('plyfile', types.ModuleType('plyfile'))
+    sys.path.insert(0, '/root/reference/torch')
+    import data_util as ref_data
+    from mc_cases import scene_prediction
+    names, inputs, pred = scene_prediction()
+    tmp = tempfile.mkdtemp()
+    ref_data.save_predictions(tmp, names, inputs, None, None, pred, None, None, 3.0)
+    res = {}
+    for f in sorted(os.listdir(tmp)):
+        res['pred_' + f.replace('-', '_').replace('.', '_')] = np.fromfile(os.path.join(tmp, f), dtype=np.uint8)
+    print('save_predictions wrote', sorted(os.listdir(tmp)))
+    return res
+
+
 def main():
     out = {}
     for name, spec in CASES.items():
@@ -34,6 +54,7 @@ def main():
     ref.export_marching_cubes(tsdf, torch.ones(tuple(tsdf.shape) + (3,), dtype=torch.uint8) * 220, 0.0, 3.0, 10.0, p)
     out['sphere32_ply'] = np.fromfile(p, dtype=np.uint8)
     os.remove(p)
+    out.update(save_predictions_case())
     np.savez_compressed(os.path.join(HERE, 'mc_expected.npz'), **out)
 
 

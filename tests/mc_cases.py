@@ -38,3 +38,17 @@ def make_volume(spec):
     if spec.get('colors'):
         colors = torch.from_numpy(rng.integers(0, 256, dims + (3,), dtype=np.uint8))
     return torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32)), colors
+
+
+def scene_prediction():
+    """Inputs of a test_scene.py:96-98 style save_predictions call: one scene's input sites [z,y,x,b] + tsdf values and
+    a sparse sdf prediction (coordinates + values), numpy on the host as the reference passes them."""
+    a = synth.block_arrays((40, 48, 56), 33, occupancy=0.12, stored_band=2.85, voxelsize=1.0)
+    il, iv = a['input']
+    tl, tv = a['target']
+    rng = np.random.default_rng(77)
+    keep = rng.random(len(tl)) < 0.93
+    inputs = [np.concatenate([il, np.zeros((len(il), 1), np.int64)], 1), iv[:, None].astype(np.float32)]
+    pred = [[np.concatenate([tl[keep], np.zeros((int(keep.sum()), 1), np.int64)], 1),
+             (tv[keep] + rng.normal(0, 0.05, int(keep.sum()))).astype(np.float32)]]
+    return ['scene0_'], inputs, pred

@@ -87,3 +87,15 @@ def test_scene_size_against_live_reference():
     tsdf, _ = make_volume(noisy)
     want = [t.numpy() for t in ref.run_marching_cubes(tsdf, col, 0.0, 3.0, 10.0)]
     same_mesh(mc.run_marching_cubes(tsdf.cuda(), None, 0.0, 3.0, 10.0), want)
+
+
+def test_save_predictions_files_match_reference(g, tmp_path):
+    """test_scene.py:98 -> data_util.save_predictions: the two mesh files, byte for byte."""
+    from mc_cases import scene_prediction
+    names, inputs, pred = scene_prediction()
+    mc.save_predictions(str(tmp_path), names, inputs, None, None, pred, None, None, 3.0)
+    for f, key in (('scene0_input-mesh.ply', 'pred_scene0_input_mesh_ply'), ('scene0_pred-mesh.ply', 'pred_scene0_pred_mesh_ply')):
+        got = np.fromfile(str(tmp_path / f), dtype=np.uint8)
+        assert got.size > 1000 and np.array_equal(got, g[key]), f
+    with pytest.raises(NotImplementedError):
+        mc.save_predictions(str(tmp_path), names, inputs, None, None, pred, [None], None, 3.0)

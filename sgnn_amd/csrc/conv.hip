@@ -179,26 +179,69 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
   };
 
-  // software pipeline, unrolled by two with ping-pong registers: rule entries run three offsets ahead,
-  // gathered rows one offset ahead of the MFMAs that consume them (counted vmcnt waits, no copies)
-  int32_t iv0 = load_idx(0), iv1 = (K > 1) ? load_idx(1) : -1, iv2 = (K > 2) ? load_idx(2) : -1;
-  float a0[M][V], a1[M][V];
-  gather(iv0, a0);
-  int k = 0;
-  for (; k + 1 < K; k += 2) {
-    if (k % KC == 0) stage(k);
-    gather(iv1, a1);                          // rows of offset k+1
-    iv0 = (k + 3 < K) ? load_idx(k + 3) : -1;
-    mma(k % KC, a0);
-    if ((k + 1) % KC == 0) stage(k + 1);
-    if (k + 2 < K) gather(iv2, a0);           // rows of offset k+2
-    iv1 = iv0;                                // entries of k+3
-    iv2 = (k + 4 < K) ? load_idx(k + 4) : -1;
-    mma((k + 1) % KC, a1);
-  }
-  if (k < K) {
-    if (k % KC == 0) stage(k);
-    mma(k % KC, a0);
+  // software pipeline, unrolled by two with ping-pong registers: rule entries run three offsets ahead, gathered rows
+  // one offset ahead of the MFMAs that consume them.  The loop body is branch-free on purpose: every load is issued
+  // unconditionally (offsets past the end are clamped to the last one and their rows ignored), so the compiler can
+  // give every use a COUNTED s_waitcnt vmcnt(n).  With loads under uniform branches (tail checks, weight restaging
+  // inside the loop) it has to fall back to vmcnt(0) at the merge points, which drained the freshly issued gathers
+  // of the next offset in every second step.
+  const int klast = K - 1;
+  auto idx_at = [&](int k) { return load_idx(k < klast ? k : klast); };
+  if constexpr (V <= 4 && NT >= 2) {
+    // narrow rows, several output tiles (long MFMA phase per offset): three register sets, rows gathered TWO offsets
+    // ahead of their MFMAs.  Measured at N = 366 k: <16,48> 228 -> 187 us; <16,16> (NT = 1) is 3 % faster with two sets
+    float a0[M][V], a1[M][V], a2[M][V];
+    for (int k0 = 0; k0 < K; k0 += KC) {      // one pass per staged weight chunk (a single one for the 3x3x3 16->16 layers)
+      const int kc = (K - k0) < KC ? (K - k0) : KC;
+      stage(k0);
+      gather(idx_at(k0), a0);
+      gather(idx_at(k0 + 1), a1);
+      int32_t iv2 = idx_at(k0 + 2), iv3 = idx_at(k0 + 3), iv4 = idx_at(k0 + 4);
+      int kk = 0;
+      for (; kk + 2 < kc; kk += 3) {
+        // sched_barrier: the machine scheduler otherwise sinks the gathers to half an offset before their use
+        gather(iv2, a2);                        // rows of offset k0+kk+2
+        iv2 = idx_at(k0 + kk + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kk, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(iv3, a0);                        // rows of offset k0+kk+3 (dropped if that is past this chunk)
+        iv3 = idx_at(k0 + kk + 6);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kk + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(iv4, a1);                        // rows of offset k0+kk+4
+        iv4 = idx_at(k0 + kk + 7);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kk + 2, a2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kk < kc) mma(kk, a0);
+      if (kk + 1 < kc) mma(kk + 1, a1);
+    }
+  } else {
+    float a0[M][V], a1[M][V];
+    for (int k0 = 0; k0 < K; k0 += KC) {
+      const int kc = (K - k0) < KC ? (K - k0) : KC;
+      stage(k0);
+      int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
+      gather(idx_at(k0), a0);
+      int kk = 0;
+      for (; kk + 1 < kc; kk += 2) {
+        gather(iv1, a1);                        // rows of offset k0+kk+1
+        const int32_t iv3 = idx_at(k0 + kk + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kk, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(iv2, a0);                        // rows of offset k0+kk+2 (dropped if that is past this chunk)
+        iv1 = iv3;
+        iv2 = idx_at(k0 + kk + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kk + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kk < kc) mma(kk, a0);
+    }
   }
 
   // C/D layout: col = lane&15, row = (lane>>4)*4 + reg; out-of-range rows/cols are dropped by the buffer bounds
@@ -414,7 +457,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 // so only the 16-wide layers use it.
 #define CONV_DXR_CASES(X) X(16, 16)
 
-static int g_use_dxr = 1;
+static int g_use_dxr = 0;   // off: with counted waits the plain kernel is faster (71.7 vs 78.8 us at N = 366 k)
 // 0 disables the x-reuse kernel (A/B measurements and its parity test); returns the previous setting
 SGNN_EXPORT int sgnn_conv_set_dxr(int on) {
   const int prev = g_use_dxr;

@@ -632,21 +632,21 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
   for (int64_t base = blk_row0 + wave * 64; base < blk_row1; base += 256) {
     // rule entries of this wave's 64 rows for every offset of the group (table padding rows hold -1)
+    // (branch-free: offsets past the group's end load a clamped row and are then forced to -1 = "no rule", so every
+    // load below is unconditional and the compiler can use counted s_waitcnt instead of draining at merge points)
     int32_t idxv[DW_KPB];
 #pragma unroll
     for (int kk = 0; kk < DW_KPB; ++kk) {
-      int32_t id = -1;
-      if (kk < kc) {
-        if constexpr (EX) {
-          const int trow = kmap ? kmap[k0 + kk] : (k0 + kk);
-          id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
-          id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k0 + kk] : 0);
-        } else {
-          id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, (k0 + kk) * ld4, 0) >>
-               in_shift;
-        }
+      const int ko = k0 + (kk < kc ? kk : kc - 1);
+      int32_t id;
+      if constexpr (EX) {
+        const int trow = kmap ? kmap[ko] : ko;
+        id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
+        id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[ko] : 0);
+      } else {
+        id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, ko * ld4, 0) >> in_shift;
       }
-      idxv[kk] = id;
+      idxv[kk] = (kk < kc) ? id : -1;
     }
     // dy tile -> LDS -> B fragments kept in registers for all offsets (rows >= n_out read as zeros)
     {
@@ -685,25 +685,27 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       gather(idxv[0], g0);
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; kk += 2) {
-        if (kk < kc) {
-          if (kk + 1 < kc) gather(idxv[kk + 1 < DW_KPB ? kk + 1 : kk], g1);
+        if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1);          // compile-time conditions only
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float *p = xs + (m * 16 + i16) * CINP + q * V;
+        for (int m = 0; m < 4; ++m) {
+          float *p = xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
-            for (int s = 0; s < V; ++s) p[s] = g0[m][s];
-          }
-          mma_chunk(kk, b);
+          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
         }
-        if (kk + 1 < DW_KPB && kk + 1 < kc) {
-          if (kk + 2 < kc) gather(idxv[kk + 2 < DW_KPB ? kk + 2 : kk], g0);
+        mma_chunk(kk, b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < DW_KPB) {
+          if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             float *p = xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
             for (int s = 0; s < V; ++s) p[s] = g1[m][s];
           }
-          mma_chunk(kk + 1 < DW_KPB ? kk + 1 : kk, b);
+          mma_chunk(kk + 1, b);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else {
@@ -711,16 +713,14 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       float g0[4][V];
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; ++kk) {
-        if (kk < kc) {
-          gather(idxv[kk], g0);
+        gather(idxv[kk], g0);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float *p = xs + (m * 16 + i16) * CINP + q * V;
+        for (int m = 0; m < 4; ++m) {
+          float *p = xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
-            for (int s = 0; s < V; ++s) p[s] = g0[m][s];
-          }
-          mma_chunk(kk, b);
+          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
         }
+        mma_chunk(kk, b);
       }
     }
   }

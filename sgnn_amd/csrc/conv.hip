@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   // of the next offset in every second step.
   const int klast = K - 1;
   auto idx_at = [&](int k) { return load_idx(k < klast ? k : klast); };
-  if constexpr (V <= 4 && NT >= 2) {
+  if constexpr (V <= 4 && (NT >= 2 || M == 1)) {
     // narrow rows, several output tiles (long MFMA phase per offset): three register sets, rows gathered TWO offsets
     // ahead of their MFMAs.  Measured at N = 366 k: <16,48> 228 -> 187 us; <16,16> (NT = 1) is 3 % faster with two sets
     float a0[M][V], a1[M][V], a2[M][V];

@@ -216,22 +216,32 @@ struct BnFuse {
   float *dgamma, *dbeta;                                          // backward
 };
 
-// sums of channel ch over the block partials, ascending block order
-__device__ __forceinline__ void bn_fuse_sums(const BnFuse &f, int c, int ch, double &s1, double &s2) {
-  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-  int blk = 0;
-  for (; blk + 1 < f.nblk; blk += 2) {
-    a0 += f.partial[((size_t)blk * 2 + 0) * c + ch];
-    b0 += f.partial[((size_t)blk * 2 + 1) * c + ch];
-    a1 += f.partial[((size_t)blk * 2 + 2) * c + ch];
-    b1 += f.partial[((size_t)blk * 2 + 3) * c + ch];
+// Per-channel totals of the block partials, computed by the whole workgroup: 256/c threads share a channel (strided
+// partial sums), their pieces are added in thread order — a fixed order, identical in every workgroup.
+// tot[0..c) = sum_a, tot[c..2c) = sum_b;  scratch: 512 doubles.  Contains two barriers.
+__device__ __forceinline__ void bn_fuse_totals(const BnFuse &f, int c, double *scratch, double *tot) {
+  const int tid = threadIdx.x;
+  const int tpc = 256 / c;                       // >= 4 for c <= BN_FUSE_MAXC
+  const int ch = tid % c, part = tid / c;
+  double a = 0.0, b = 0.0;
+  if (part < tpc)
+    for (int blk = part; blk < f.nblk; blk += tpc) {
+      a += f.partial[((size_t)blk * 2 + 0) * c + ch];
+      b += f.partial[((size_t)blk * 2 + 1) * c + ch];
+    }
+  scratch[tid] = a;
+  scratch[256 + tid] = b;
+  __syncthreads();
+  if (tid < c) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < tpc; ++p) {
+      s1 += scratch[p * c + tid];
+      s2 += scratch[256 + p * c + tid];
+    }
+    tot[tid] = s1;
+    tot[c + tid] = s2;
   }
-  if (blk < f.nblk) {
-    a0 += f.partial[((size_t)blk * 2 + 0) * c + ch];
-    b0 += f.partial[((size_t)blk * 2 + 1) * c + ch];
-  }
-  s1 = a0 + a1;
-  s2 = b0 + b1;
+  __syncthreads();
 }
 
 template <int VEC>
@@ -242,10 +252,11 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
                                                  const float *__restrict__ beta, float leak,
                                                  float *__restrict__ y, BnFuse fuse) {
   __shared__ float s_mean[BN_FUSE_MAXC], s_inv[BN_FUSE_MAXC];
+  __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   if (fuse.partial) {
+    bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
-      double s1, s2;
-      bn_fuse_sums(fuse, c, ch, s1, s2);
+      const double s1 = s_tot[ch], s2 = s_tot[c + ch];
       const double mu = s1 / (double)n;
       double var = s2 / (double)n - mu * mu;
       if (var < 0.0) var = 0.0;
@@ -309,10 +320,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                      const float *__restrict__ coef, float *dx, BnFuse fuse,
                                                      const float *addend) {
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
+  __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   if (fuse.partial) {
+    bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
-      double s1, s2;
-      bn_fuse_sums(fuse, c, ch, s1, s2);
+      const double s1 = s_tot[ch], s2 = s_tot[c + ch];
       s_coef[ch] = (float)(s1 / (double)n);
       s_coef[c + ch] = (float)(s2 / (double)n);
       if (blockIdx.x == 0) {

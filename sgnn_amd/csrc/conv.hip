@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CONV_MREP 4                        // 16-row MFMA tiles per wave in the large-grid variant
 #define CONV_ROWS_PER_WAVE (16 * CONV_MREP)
 #define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)   // also the required multiple of the table's ld
-#define CONV_SMALL_GRID 768                // below this many 256-row workgroups use the 64-row variant
+#define CONV_SMALL_GRID 160                // below this many 256-row workgroups (~40 k rows) the 64-row variant wins (measured crossover)
 
 template <int CIN, int COUT>
 struct ConvCfg {

@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__
 // Small levels (few block partials, C <= BN_FUSE_MAXC): the apply kernels finalise the statistics themselves — every
 // workgroup sums the short partial table in the same fixed order into LDS, workgroup 0 also stores the results the
 // later passes / the caller need — and the separate finalize launch disappears.
+#define BN_LDS_MAXC 256   // per-channel constants are staged in LDS up to this many channels
+#define BN_U 2            // row groups a thread loads before it uses the first one
 #define BN_FUSE_BLOCKS 128
 #define BN_FUSE_MAXC 64
 
@@ -277,21 +279,48 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
     mean = s_mean;
     invstd = s_inv;
   }
+  // per-channel constants live in LDS (a per-lane global load per constant per element made the texture addresser, not
+  // HBM, the limit of this kernel); BN_U independent row loads are in flight per thread before the first use
+  __shared__ __attribute__((aligned(16))) float s_k[4 * BN_LDS_MAXC];
+  const bool lds_k = c <= BN_LDS_MAXC;
+  if (lds_k) {
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      s_k[ch] = mean[ch];
+      s_k[BN_LDS_MAXC + ch] = invstd[ch];
+      s_k[2 * BN_LDS_MAXC + ch] = gamma ? gamma[ch] : 1.f;
+      s_k[3 * BN_LDS_MAXC + ch] = beta ? beta[ch] : 0.f;
+    }
+    __syncthreads();
+  }
+  auto K_ = [&](int which, int ch) -> float {
+    if (lds_k) return s_k[which * BN_LDS_MAXC + ch];
+    return which == 0 ? mean[ch] : which == 1 ? invstd[ch] : which == 2 ? (gamma ? gamma[ch] : 1.f) : (beta ? beta[ch] : 0.f);
+  };
   // flat element-group index; channel group = g % cq
   const int64_t groups = n * cq;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
-    const int col = (int)(g % cq);
-    float xv[VEC], yv[VEC];
-    load_vec<VEC>(x + g * VEC, xv);
+  for (int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x; g0 < groups; g0 += stride * BN_U) {
+    float xv[BN_U][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const int ch = col * VEC + v;
-      const float xh = (xv[v] - mean[ch]) * invstd[ch];
-      const float t = fmaf(xh, gamma ? gamma[ch] : 1.f, beta ? beta[ch] : 0.f);
-      yv[v] = t > 0.f ? t : t * leak;
+    for (int u = 0; u < BN_U; ++u) {
+      const int64_t g = g0 + u * stride;
+      load_vec<VEC>(x + (g < groups ? g : g0) * VEC, xv[u]);      // clamped: the load itself is unconditional
     }
-    store_vec<VEC>(y + g * VEC, yv);
+#pragma unroll
+    for (int u = 0; u < BN_U; ++u) {
+      const int64_t g = g0 + u * stride;
+      if (g >= groups) break;
+      const int col = (int)(g % cq);
+      float yv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int ch = col * VEC + v;
+        const float xh = (xv[u][v] - K_(0, ch)) * K_(1, ch);
+        const float t = fmaf(xh, K_(2, ch), K_(3, ch));
+        yv[v] = t > 0.f ? t : t * leak;
+      }
+      store_vec<VEC>(y + g * VEC, yv);
+    }
   }
 }
 
@@ -335,31 +364,61 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     __syncthreads();
     coef = s_coef;
   }
+  __shared__ __attribute__((aligned(16))) float s_k[6 * BN_LDS_MAXC];
+  const bool lds_k = c <= BN_LDS_MAXC;
+  if (lds_k) {
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      s_k[ch] = mean[ch];
+      s_k[BN_LDS_MAXC + ch] = invstd[ch];
+      s_k[2 * BN_LDS_MAXC + ch] = gamma ? gamma[ch] : 1.f;
+      s_k[3 * BN_LDS_MAXC + ch] = beta ? beta[ch] : 0.f;
+      s_k[4 * BN_LDS_MAXC + ch] = training ? coef[ch] : 0.f;
+      s_k[5 * BN_LDS_MAXC + ch] = training ? coef[c + ch] : 0.f;
+    }
+    __syncthreads();
+  }
+  auto K_ = [&](int which, int ch) -> float {
+    if (lds_k) return s_k[which * BN_LDS_MAXC + ch];
+    switch (which) {
+      case 0: return mean[ch];
+      case 1: return invstd[ch];
+      case 2: return gamma ? gamma[ch] : 1.f;
+      case 3: return beta ? beta[ch] : 0.f;
+      case 4: return training ? coef[ch] : 0.f;
+      default: return training ? coef[c + ch] : 0.f;
+    }
+  };
   const int64_t groups = n * cq;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
-    const int col = (int)(g % cq);
-    float xv[VEC], dv[VEC], ov[VEC];
-    load_vec<VEC>(x + g * VEC, xv);
-    load_vec<VEC>(dy + g * VEC, dv);
+  for (int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x; g0 < groups; g0 += stride * BN_U) {
+    float xv[BN_U][VEC], dv[BN_U][VEC], av[BN_U][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const int ch = col * VEC + v;
-      const float gm = gamma ? gamma[ch] : 1.f;
-      const float xh = (xv[v] - mean[ch]) * invstd[ch];
-      const float t = fmaf(xh, gm, beta ? beta[ch] : 0.f);
-      const float dz = t > 0.f ? dv[v] : dv[v] * leak;
-      float d = dz;
-      if (training) d = dz - coef[ch] - xh * coef[c + ch];
-      ov[v] = d * gm * invstd[ch];
+    for (int u = 0; u < BN_U; ++u) {
+      const int64_t g = g0 + u * stride, gc = (g < groups ? g : g0);
+      load_vec<VEC>(x + gc * VEC, xv[u]);
+      load_vec<VEC>(dy + gc * VEC, dv[u]);
+      if (addend) load_vec<VEC>(addend + gc * VEC, av[u]);      // uniform over the launch
     }
-    if (addend) {   // gradient already accumulated for this buffer (may be dx itself: element-wise, in place)
-      float av[VEC];
-      load_vec<VEC>(addend + g * VEC, av);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) ov[v] += av[v];
+    for (int u = 0; u < BN_U; ++u) {
+      const int64_t g = g0 + u * stride;
+      if (g >= groups) break;
+      const int col = (int)(g % cq);
+      float ov[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int ch = col * VEC + v;
+        const float gm = K_(2, ch), is = K_(1, ch);
+        const float xh = (xv[u][v] - K_(0, ch)) * is;
+        const float t = fmaf(xh, gm, K_(3, ch));
+        const float dz = t > 0.f ? dv[u][v] : dv[u][v] * leak;
+        float d = dz;
+        if (training) d = dz - K_(4, ch) - xh * K_(5, ch);
+        ov[v] = d * gm * is;
+        if (addend) ov[v] += av[u][v];   // gradient already accumulated for this buffer (may be dx itself: in place)
+      }
+      store_vec<VEC>(dx + g * VEC, ov);
     }
-    store_vec<VEC>(dx + g * VEC, ov);
   }
 }
 

@@ -94,29 +94,39 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
       float fa[VEC], fb[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) fa[v] = fb[v] = 0.f;
-#pragma unroll 4
-      for (int it = 0; it < BN_FLUSH && row < n; ++it, row += step) {
-        float xv[VEC];
-        load_vec<VEC>(x + row * c + col * VEC, xv);
+      // BN_FLUSH rows per pass: all their loads are issued first (row index clamped, contribution masked), so several
+      // rows are in flight per thread instead of one load -> wait -> add chain
+      float xv[BN_FLUSH][VEC], dv[BN_FLUSH][VEC];
+      bool keep[BN_FLUSH];
+#pragma unroll
+      for (int it = 0; it < BN_FLUSH; ++it) {
+        const int64_t rr = row + it * step;
+        keep[it] = rr < n;
+        const int64_t rc = rr < n ? rr : row;
+        load_vec<VEC>(x + rc * c + col * VEC, xv[it]);
+        if (MODE == 1) load_vec<VEC>(dy + rc * c + col * VEC, dv[it]);
+      }
+#pragma unroll
+      for (int it = 0; it < BN_FLUSH; ++it) {
         if (MODE == 0) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            fa[v] += xv[v];
-            fb[v] = fmaf(xv[v], xv[v], fb[v]);
+            const float xm = keep[it] ? xv[it][v] : 0.f;
+            fa[v] += xm;
+            fb[v] = fmaf(xm, xm, fb[v]);
           }
         } else {
-          float dv[VEC];
-          load_vec<VEC>(dy + row * c + col * VEC, dv);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            const float xh = (xv[v] - m_[v]) * is_[v];
+            const float xh = (xv[it][v] - m_[v]) * is_[v];
             const float yv = fmaf(xh, g_[v], b_[v]);
-            const float dz = yv > 0.f ? dv[v] : dv[v] * leak;
+            const float dz = keep[it] ? (yv > 0.f ? dv[it][v] : dv[it][v] * leak) : 0.f;
             fa[v] += dz;
             fb[v] = fmaf(dz, xh, fb[v]);
           }
         }
       }
+      row += (int64_t)BN_FLUSH * step;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         sa[v] += (double)fa[v];

@@ -29,13 +29,27 @@ if which == 'c5':
 else:
     dims = (128, 512, 512)
     t0 = time.time()
-    data = synth.make_batch(1, dims, cfg=4, occupancy=0.05, dist='iid')
-    print('C4 data: %d sites (%.1f s)' % (data['input'][0].shape[0], time.time() - t0))
-    m = GenModel(8, (128, 128, 128), 1, 16, 16, 4, True, True, 1, 1).cuda().eval()
+    scene = synth.make_scene(dims, cfg=4, occupancy=0.05)              # 128 surface tiles of 64^3
+    print('C4 data: %d sites (%.1f s)' % (scene[0].shape[0], time.time() - t0))
+    m = GenModel(8, (128, 128, 128), 1, 16, 16, 4, True, True, 1, 1).cuda()
     m.update_sizes(np.array(dims), np.array(dims) // 8)
-    locs, feats = data['input'][0], data['input'][1].cuda()
+    locs, feats = scene[0], scene[1].cuda()
+    # random-init weights with the default running statistics (mean 0, var 1) predict empty levels in eval mode; one
+    # training-mode pass with "replace" momentum sets the running statistics to this scene's batch statistics, which
+    # makes the eval pass generate what a training step would (a trained checkpoint is not available offline)
+    saved = []
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm3d):
+            saved.append((mod, mod.momentum)); mod.momentum = 1.0
+        elif hasattr(mod, 'running_mean') and hasattr(mod, 'momentum'):
+            saved.append((mod, mod.momentum)); mod.momentum = 0.0
     with torch.no_grad():
-        for i in range(4):
+        m.train()
+        m([locs, feats], lw)
+        for mod, mom in saved:
+            mod.momentum = mom
+        m.eval()
+        for i in range(5):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             osdf, oocc = m([locs, feats], lw)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -128,3 +128,22 @@ def write_scene_triple(in_path, tgt_path, dims, seed, **kw):
     data.write_scene(tgt_path, a['dims'], a['voxelsize'], a['world2grid'], a['target'])
     data.write_known(os.path.splitext(tgt_path)[0] + '.knw', a['dims'], a['voxelsize'], a['world2grid'], a['known'])
     return a
+
+
+def make_scene(dims=(128, 512, 512), cfg=4, occupancy=0.05, truncation=3.0, tile=64):
+    """One whole-scene input [locs (N,4) int64 [z,y,x,0], feats (N,1)] for BASELINE configs[3]: the volume is tiled
+    with independent synthetic surface blocks (make_block), ~N = 13 k sites per 64^3 tile -> ~1.7 M at (128,512,512)."""
+    dims = tuple(int(d) for d in dims)
+    locs, feats, t = [], [], 0
+    for z0 in range(0, dims[0], tile):
+        for y0 in range(0, dims[1], tile):
+            for x0 in range(0, dims[2], tile):
+                td = (min(tile, dims[0] - z0), min(tile, dims[1] - y0), min(tile, dims[2] - x0))
+                il, isdf, _, _, _ = make_block(td, 1000 * cfg + t, occupancy, truncation)
+                il = il + np.array([z0, y0, x0], dtype=np.int64)
+                locs.append(np.concatenate([il, np.zeros((len(il), 1), np.int64)], 1))
+                feats.append(isdf[:, None])
+                t += 1
+    locs, feats = np.concatenate(locs), np.concatenate(feats)
+    order = np.lexsort((locs[:, 2], locs[:, 1], locs[:, 0]))          # file order: z-major raster (VoxelGrid.h:133-143)
+    return [torch.from_numpy(locs[order]), torch.from_numpy(feats[order].astype(np.float32))]

@@ -193,9 +193,9 @@ def main():
             else:
                 roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / HBM_PEAK_GBS, 4)}
-            # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE*2 + WRITE_SIZE, gfx950 correction) are
-            # collected in separate rocprofv3 runs on a fixed level (profiles/r01c_conv_pmc.txt: 85 MiB vs 86 MB
-            # algorithmic for conv_fwd<16,16> at N=366085); the bench mixes launch sizes, so no single per-launch figure
+            # traffic: the PMC passes need their own rocprofv3 runs (profiles/r01i_conv_pmc.txt: 87.5 MB moved vs 86.1 MB
+            # algorithmic for conv_fwd<16,16> at N = 366 085, 478 vs 476 MB on a generated level of 2.0 M sites); the bench
+            # mixes level sizes and K = 27 / K = 8 launches under one kernel name, so there is no single per-launch figure
             roof.update({'traffic': None, 'kernel': kernels[0]['kernel'],
                          'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2), 'launches': dom['launches'],
                          'alg_GBps': round(gbs, 1), 'alg_frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4),

@@ -61,3 +61,38 @@ def test_single_process_is_a_noop():
     FlatGradAllReduce(m.parameters())()
     for a, b in zip(before, (p.grad for p in m.parameters())):
         assert torch.equal(a, b)
+
+
+def _worker_step(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sgnn_amd.train import FlatGradAllReduce, make_optimizer
+    m = _make_model()
+    opt = make_optimizer(m.parameters(), lr=1e-2)
+    sync = FlatGradAllReduce(m.parameters())
+    for it in range(3):                                   # step 1: rank 1 skips the last layer
+        opt.zero_grad(set_to_none=True)
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        h = m[2](m[1](m[0](torch.randn(5 + rank, 6, generator=g))))
+        ((h ** 2).mean() if (rank == 1 and it == 1) else (m[3](h) ** 2).mean()).backward()
+        sync()
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    if rank == 0:
+        torch.save(both, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_stay_identical_after_optimizer_steps(tmp_path):
+    """Data parallelism as bench.py runs it: per-rank batches, flat gradient all-reduce, FastAdam — the replicas'
+    parameters must be bit-identical after every step, also when a rank did not reach a layer."""
+    out = str(tmp_path / 'p.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_step, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out)
+    assert torch.equal(a, b) and torch.isfinite(a).all()

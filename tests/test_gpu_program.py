@@ -109,3 +109,32 @@ def test_fused_level_loss_equals_torch_loss(masking, wgeo):
     assert np.allclose(lsa, lsb, rtol=1e-5, atol=1e-6)
     for x, y in zip(ga, gb):
         assert (x - y).abs().max().item() < 1e-6
+
+
+def test_training_step_is_bitwise_reproducible():
+    """No atomics on floats anywhere, the weight-gradient lane joins before gradients are read, aliased gradients are
+    never written: two runs of the same step give identical bits (loss, every gradient, BN buffers)."""
+    import numpy as np
+    from sgnn_amd import synth, loss as L
+    from sgnn_amd.model import GenModel
+    from util import param_fill
+    dims = (32, 32, 32)
+    data = synth.make_batch(3, dims, cfg=21, occupancy=0.08)
+    lw = np.ones(5, dtype=np.float32)
+    runs = []
+    for _ in range(2):
+        m = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), 21).train().cuda()
+        t = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
+                              data['known'].cuda())
+        locs, feats = data['input'][0].cuda(), data['input'][1].cuda()
+        osdf, oocc = m([locs, feats], lw)
+        loss, _ = L.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, locs, True, data['known'].cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), [p.grad.clone() for p in m.parameters()],
+                     [b.clone() for b in m.buffers()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(a, b)

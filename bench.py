@@ -123,7 +123,8 @@ def main():
 
     from sgnn_amd import _lib, synth
     from sgnn_amd.model import GenModel
-    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce, make_optimizer
+    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce, make_optimizer, bind_to_device_numa
+    bound = bind_to_device_numa(dev)          # one process per GPU, on that GPU's NUMA node
     lib = _lib.load()
     _lib.require_gpu()
 
@@ -227,7 +228,7 @@ def main():
             'config': {'workload': 'configs[1]: full SG-NN 4-level GenModel (643735 params, random init), %d synthetic '
                                    '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam'
                                    % (args.batch, args.dim, 100 * args.occupancy),
-                       'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
+                       'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
                        'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world},
             'roofline': roof, 'cpu_baseline': cpu,
         }

@@ -13,6 +13,39 @@ import torch.distributed as dist
 from . import loss as loss_util
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_device_numa(device=None):
+    """One process per GPU: run it on the CPUs of the NUMA node that GPU hangs off (sysfs local_cpulist of its PCI
+    function).  The training step is a stream of ~1 350 kernel launches; issued from the remote socket every launch
+    and every count read-back crosses the inter-socket link (measured on a 2-socket MI355X host: 9.4 vs 10.4 ms per
+    step, at random, until pinned).  Returns the CPU set, or None when the topology cannot be read (then nothing is
+    changed).  SGNN_NO_BIND=1 disables it."""
+    import os
+    if os.environ.get('SGNN_NO_BIND') == '1' or not torch.cuda.is_available() or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        p = torch.cuda.get_device_properties(idx)
+        bdf = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id)
+        with open('/sys/bus/pci/devices/%s/local_cpulist' % bdf) as f:
+            cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
 class FlatGradAllReduce(object):
     """Averages gradients across ranks with a single collective on one flat buffer."""
 

@@ -111,3 +111,14 @@ def test_fast_adam_matches_torch_adam():
         assert float(oa.state[pa]['step']) == float(ob.state[pb]['step'])
         assert torch.equal(oa.state[pa]['exp_avg_sq'], ob.state[pb]['exp_avg_sq'])
     assert oa.state_dict()['param_groups'][0]['lr'] == 1e-2
+
+
+def test_numa_cpulist_parsing_and_binding_is_harmless_without_a_gpu():
+    from sgnn_amd.train import _parse_cpulist, bind_to_device_numa
+    assert _parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    assert _parse_cpulist('') == set()
+    import os
+    before = os.sched_getaffinity(0)
+    assert bind_to_device_numa() is None or torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        assert os.sched_getaffinity(0) == before

@@ -130,14 +130,18 @@ def _fusable(vals, *dense):
 
 
 def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights, truncation,
-                 use_log_transform=True, weight_missing_geo=1, input_locs=None, use_loss_masking=True, known=None):
+                 use_log_transform=True, weight_missing_geo=1, input_locs=None, use_loss_masking=True, known=None,
+                 weights=None):
     """Returns (loss tensor, per-level loss tensors or -1).  Unlike loss.py:185 the per-level values are
-    left on the device (no .item() sync inside the step); callers convert when they log."""
+    left on the device (no .item() sync inside the step); callers convert when they log.
+    `weights`: the result of compute_weights_missing_geo if the caller already has it (train_step computes targets
+    and weights on a second stream while the encoder runs)."""
     assert len(output_occs) == len(target_for_occs)
     loss, losses = 0.0, []
-    weights = [None] * len(target_for_occs)
-    if weight_missing_geo > 1:
-        weights = compute_weights_missing_geo(weight_missing_geo, input_locs, target_for_occs, truncation)
+    if weights is None:
+        weights = [None] * len(target_for_occs)
+        if weight_missing_geo > 1:
+            weights = compute_weights_missing_geo(weight_missing_geo, input_locs, target_for_occs, truncation)
     for h in range(len(output_occs)):
         if len(output_occs[h][0]) == 0 or loss_weights[h] == 0:
             losses.append(-1)

@@ -139,20 +139,51 @@ def to_device(batch, device):
     return out
 
 
+OVERLAP_TARGETS = True
+_target_streams = {}
+
+
+def _target_stream(dev):
+    s = _target_streams.get(dev)
+    if s is None:
+        s = _target_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, truncation=3.0,
                use_log_transform=True, weight_missing_geo=5.0, use_loss_masking=True, grad_sync=None):
     """batch: device-resident dict in scene_dataloader.collate layout.  Returns (loss, losses, outputs)."""
     inputs = batch['input']
     known = batch['known'] if use_loss_masking else None
-    sdf = batch['sdf'].clone()
-    hierarchy = [h.clone() for h in batch['hierarchy']]
-    tgt_sdf, tgt_occs, tgt_hier = loss_util.compute_targets(sdf, hierarchy, num_hierarchy_levels, truncation,
-                                                            use_loss_masking, known)
+    dev = batch['sdf'].device
+
+    def targets():
+        sdf = batch['sdf'].clone()
+        hierarchy = [h.clone() for h in batch['hierarchy']]
+        t = loss_util.compute_targets(sdf, hierarchy, num_hierarchy_levels, truncation, use_loss_masking, known)
+        w = None
+        if weight_missing_geo > 1:
+            w = loss_util.compute_weights_missing_geo(weight_missing_geo, inputs[0], t[1], truncation)
+        return t, w
+
     optimizer.zero_grad(set_to_none=True)
-    output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(sdf.shape[0]))
+    if dev.type == 'cuda' and OVERLAP_TARGETS:
+        # targets and loss weights depend on the batch only (a dozen dense element-wise / pooling passes over the
+        # (B,1,D,D,D) volumes): they run on a second stream underneath the encoder, whose small launches leave the
+        # memory system idle; the loss waits for them
+        side = _target_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            (tgt_sdf, tgt_occs, tgt_hier), weights = targets()
+        output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]))
+        main.wait_stream(side)
+    else:
+        (tgt_sdf, tgt_occs, tgt_hier), weights = targets()
+        output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]))
     loss, losses = loss_util.compute_loss(output_sdf, output_occs, tgt_sdf, tgt_occs, tgt_hier, loss_weights,
                                           truncation, use_log_transform, weight_missing_geo, inputs[0],
-                                          use_loss_masking, known)
+                                          use_loss_masking, known, weights=weights)
     loss.backward()
     if grad_sync is not None:
         grad_sync()

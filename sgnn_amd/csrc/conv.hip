@@ -40,7 +40,7 @@ struct ConvCfg {
 };
 
 // optional generalisation of the rulebook walk (sgnn_conv_*_ex): offset k of group g reads table row
-// kmap[g*K + k] (NULL: k), gathers feature row idx*in_mul + kadd[k] (NULL: +0) and group g owns output rows
+// kmap[g*K + k] (NULL: k), gathers feature row idx*in_mul + kadd[g*K + k] (NULL: +0) and group g owns output rows
 // row*groups + g and the weight block g.  Plain convolutions use {NULL, NULL, 1, 1}.
 struct ConvEx {
   const int32_t *kmap;
@@ -99,10 +99,11 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const unsigned groups = EX ? (unsigned)ex.groups : 1u;
   const unsigned tile = lin / groups, grp = lin % groups;
   const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
-  const int32_t *kmap = nullptr;
+  const int32_t *kmap = nullptr, *kadd_g = nullptr;
   if constexpr (EX) {
     w += (int64_t)grp * K * CIN * COUT;
     kmap = ex.kmap ? ex.kmap + grp * K : nullptr;
+    kadd_g = ex.kadd ? ex.kadd + grp * K : nullptr;      // like kmap: one entry per (group, offset)
   }
   const int table_rows = EX ? ex.table_rows : K;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
       const int trow = kmap ? kmap[k] : k;
       int32_t id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, trow * ld4, 0);
       // fold the row transform in here (once per rule entry): -1 stays negative -> out of range -> zeros
-      return (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[k] : 0);
+      return (id >> in_shift) * ex.in_mul + ((kadd_g && id >= 0) ? kadd_g[k] : 0);
     } else {
       return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
     }
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
   for (int k = 0; k < K; ++k) {
     const int32_t idx = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + row];
     if (idx < 0) continue;
-    const float *xr = x + ((int64_t)(idx >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[k] : 0)) * cin;
+    const float *xr = x + ((int64_t)(idx >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin;
     const int ks = flip ? (K - 1 - k) : k;
     for (int c = 0; c < cin; ++c) {
       const float wv = transpose ? w[((int64_t)ks * cout + n) * cin + c] : w[((int64_t)ks * cin + c) * cout + n];

@@ -144,6 +144,9 @@ def expand_maps(device):
     return m
 
 
+EXPAND_DX_SPLIT = 4
+
+
 class ExpandConv(Function):
     """SubmanifoldConvolution(3x3x3) over the 8-child expansion of a level whose children all carry their parent's
     features (torch/model.py:192-207 followed by n0/n1, :220-222), evaluated on the PARENT rulebook:
@@ -172,9 +175,13 @@ class ExpandConv(Function):
         _, S, ST, PAR = expand_maps(f.device)
         df = dwc = None
         if ctx.needs_input_grad[0]:
-            df = torch.empty(n, cin, dtype=torch.float32, device=f.device)
-            _lib.call('sgnn_conv_fwd_ex', ptr(dy), 8 * n, cout, ptr(wc), 64, ptr(table), ld, n, cin, ptr(df),
-                      CONV_TRANSPOSE_W, 0, ptr(ST), ptr(PAR), 8, 1, 27)
+            # 64 offsets per parent row: cut into G slices that run as conv groups (G x the workgroups, 1/G of the
+            # serial offset walk per workgroup), slices added by sgnn_sum_groups — as for the dense bottleneck
+            G = EXPAND_DX_SPLIT
+            part = torch.empty(n, G * cin, dtype=torch.float32, device=f.device)
+            _lib.call('sgnn_conv_fwd_ex', ptr(dy), 8 * n, cout, ptr(wc), 64 // G, ptr(table), ld, n, cin, ptr(part),
+                      CONV_TRANSPOSE_W, 0, ptr(ST), ptr(PAR), 8, G, 27)
+            df = part if G == 1 else sum_groups_raw(part, cin, n, G)
         if ctx.needs_input_grad[1]:
             rt = runtime(f.device)
             dwc = torch.empty_like(wc)

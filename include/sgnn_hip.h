@@ -129,15 +129,16 @@ int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, 
 
 /* Generalised rulebook walk (used for the generative up-sampling convolution, see below):
  *   offset k of group g reads table row kmap[g*K + k]       (kmap NULL: row k)
- *   and gathers feature row  (entry >> in_shift)*in_mul + kadd[k]   (kadd NULL: + 0)
+ *   and gathers feature row  (entry >> in_shift)*in_mul + kadd[g*K + k]   (kadd NULL: + 0)
  *   group g uses the weight block w + g*K*cin*cout and owns output rows  row*groups + g
- * so y has n_out*groups rows.  kmap (groups*K ints) and kadd (K ints) are device arrays; table_rows =
+ * so y has n_out*groups rows.  kmap and kadd (groups*K ints each) are device arrays; table_rows =
  * number of offset rows the table really has (27 for a 3x3x3 rulebook).
  * Generative up-sampling (Refinement.n0/n1, torch/model.py:185-186,220-223): all 8 children of a site
  * carry its features (model.py:203), so SubmanifoldConvolution on the 8N children collapses, per child
  * parity g, into 8 parent-level offsets with pre-summed weights: forward = one launch with groups = 8,
  * K = 8 on the PARENT table (3.4x fewer gathers and flops than 27 offsets on 8N rows; the children
- * grid and its rulebook are never built); data gradient = one launch with K = 64, in_mul = 8, kadd = parity. */
+ * grid and its rulebook are never built); data gradient = K = 64 offsets with in_mul = 8, kadd = parity, run as 4 groups of 16 offsets whose
+ * partial rows are added by sgnn_sum_groups (more workgroups, shorter offset walk per workgroup). */
 int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
                      int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                      const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows,

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       if constexpr (EX) {
         const int trow = kmap ? kmap[ko] : ko;
         id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, trow * ld4, 0);
-        id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[ko] : 0);
+        id = (id >> in_shift) * ex.in_mul + ((ex.kadd && id >= 0) ? ex.kadd[grp * K + ko] : 0);
       } else {
         id = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(base + lane) * 4u, ko * ld4, 0) >> in_shift;
       }
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
   for (int64_t j = 0; j < n_out; ++j) {
     const int32_t id = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + j];
     if (id >= 0)
-      s = fmaf(x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[k] : 0)) * cin + ci],
+      s = fmaf(x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin + ci],
                dy[(j * ex.groups + grp) * cout + co], s);
   }
   dw[e] = s;

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--occupancy', type=float, default=0.05)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: run the CPU leg alone, print its JSON')
     ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -107,8 +108,29 @@ def cpu_baseline(args):
                       'best of 2 timed steps after 1 warm-up (%.2f s/step)' % (nb, args.dim, best)}
 
 
+def cpu_baseline_subprocess(args):
+    """The CPU leg in its own process: the GPU process is pinned to its GPU's NUMA node (train.bind_to_device_numa), and
+    threads created after that inherit the mask — the host baseline must see every host core."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--dim', str(args.dim), '--occupancy',
+           str(args.occupancy), '--cpu-blocks', str(args.cpu_blocks)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            return json.loads(line)
+    raise RuntimeError('cpu baseline leg failed: %s' % out.stderr[-400:])
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        if hasattr(os, 'sched_setaffinity'):
+            try:
+                os.sched_setaffinity(0, range(os.cpu_count()))     # undo an inherited NUMA pin
+            except OSError:
+                pass
+        print(json.dumps(cpu_baseline(args)))
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -218,7 +240,7 @@ def main():
             levels = [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs[1]] + [int(outs[0][0].shape[0]) if len(outs[0][0]) else 0]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(args)
+            cpu = cpu_baseline_subprocess(args)
         total_blocks = args.batch * world * args.steps
         res = {
             'metric': 'TSDF blocks/sec fwd+bwd (64^3@5% occ, bs32)', 'value': round(total_blocks / elapsed, 2),

@@ -84,9 +84,18 @@ def cpu_baseline(args):
     timed on this host on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import model_oracle as mo
+    import scn_oracle
+    from scn_oracle import _fast
     from sgnn_amd import synth
     torch.manual_seed(0)
     nthreads = torch.get_num_threads()
+    # the oracle's convolutions and 3x3x3 rulebooks through its C/OpenMP kernels when they are built (same algorithm:
+    # explicit rulebook, per-offset gather -> small GEMM -> scatter-add; oracle/csrc/scn_cpu.c) — torch's single-threaded
+    # index_select/index_add otherwise take half of the step
+    scn_oracle.FAST = _fast.available
+    how = ('convolutions + rulebooks in C/OpenMP (%d threads), the rest torch-CPU (%d threads)' % (_fast.threads(), nthreads)
+           if _fast.available else 'torch-CPU ops only (%d threads)' % nthreads)
+    nthreads = max(nthreads, _fast.threads())
     nb = args.cpu_blocks
     m = mo.GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
@@ -104,8 +113,8 @@ def cpu_baseline(args):
         times.append(time.time() - t0)
     best = min(times[1:]) if len(times) > 1 else times[0]
     return {'value': nb / best, 'unit': 'blocks/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel fwd+bwd+Adam on the torch-CPU oracle, '
-                      'best of 2 timed steps after 1 warm-up (%.2f s/step)' % (nb, args.dim, best)}
+            'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel fwd+bwd+Adam on the CPU oracle [%s], '
+                      'best of 2 timed steps after 1 warm-up (%.2f s/step)' % (nb, args.dim, how, best)}
 
 
 def cpu_baseline_subprocess(args):

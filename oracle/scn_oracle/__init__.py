@@ -89,6 +89,10 @@ class Grid(object):
     def subm_rules(self, filter_size=3):
         """Neighbour table nbr[k, j] = row of site at p_j + d_k, or -1.  k order: z-major."""
         assert filter_size == 3
+        if self._subm is None and FAST:
+            from . import _fast
+            if _fast.available:
+                self._subm = _fast.subm_rules(self.coords, self.sorted_keys, self.order)
         if self._subm is None:
             nbr = np.full((27, self.n), -1, dtype=np.int64)
             k = 0
@@ -172,9 +176,17 @@ class SparseConvNetTensor(object):
 # ----------------------------------------------------------------------------
 # functional forms (autograd through torch ops)
 # ----------------------------------------------------------------------------
+FAST = False   # True: convolutions and 3x3x3 rulebooks through the C/OpenMP kernels (oracle/csrc/scn_cpu.c) — only the
+               # cpu_baseline leg of bench.py switches it on; parity tests and fixtures use the torch-op path below
+
+
 def rule_conv(x, weight, nbr_or_pairs, n_out):
     """Per-offset gather -> mm -> index_add (upstream CPU algorithm).
     nbr_or_pairs: list over offsets of (in_idx, out_idx) LongTensors."""
+    if FAST and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        from . import _fast
+        if _fast.available:
+            return _fast.RuleConv.apply(x, weight, nbr_or_pairs, n_out)
     out = x.new_zeros(n_out, weight.shape[2])
     for k, (i_idx, o_idx) in enumerate(nbr_or_pairs):
         if i_idx.numel() == 0:

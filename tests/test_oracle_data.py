@@ -126,15 +126,20 @@ def test_readers_match_live_reference_on_random_files(tmp_path, seed):
     if not os.path.isdir(ref_dir):
         pytest.skip('reference sources not present on this machine')
     import types
-    for name in ('plyfile', 'marching_cubes_cpp'):
-        sys.modules.setdefault(name, types.ModuleType(name))
-    if 'marching_cubes' not in sys.modules:
-        pkg = types.ModuleType('marching_cubes')
-        pkg.marching_cubes = types.ModuleType('marching_cubes.marching_cubes')
-        sys.modules['marching_cubes'] = pkg
-        sys.modules['marching_cubes.marching_cubes'] = pkg.marching_cubes
+    # stubs only for the duration of the import (other tests import the REAL marching_cubes_cpp of oracle/_ref)
+    added = []
+    for name in ('plyfile', 'marching_cubes', 'marching_cubes.marching_cubes'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+            added.append(name)
+    sys.modules['marching_cubes'].marching_cubes = sys.modules['marching_cubes.marching_cubes']
     sys.path.insert(0, ref_dir)
-    import data_util as ref_data
+    try:
+        import data_util as ref_data
+    finally:
+        sys.path.remove(ref_dir)
+        for name in added:
+            sys.modules.pop(name, None)
     from sgnn_amd import synth
     rng = np.random.default_rng(seed)
     dims = tuple(int(8 * v) for v in rng.integers(1, 4, 3))

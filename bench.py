@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--occupancy', type=float, default=0.05)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: run the CPU leg alone, print its JSON')
+    ap.add_argument('--cpu-fast', action='store_true',
+                    help='CPU leg: also try the oracle\'s C/OpenMP kernels (oracle/csrc/scn_cpu.c) and time the faster mode')
     ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -108,12 +110,13 @@ def cpu_baseline(args):
         opt.step()
         return time.time() - t0
 
-    # one untimed step per mode decides which one the host runs faster (two OpenMP pools share the cores in the C
-    # mode: it wins by 3x on the 8-core authoring container, the many-core GPU host has not been measured)
+    # default: the torch-op oracle (the mode every round-1 number was taken with).  --cpu-fast: one untimed step per
+    # mode decides which one this host runs faster — the C/OpenMP kernels win by 3x on the 8-core authoring container;
+    # on the 256-thread GPU host the two OpenMP pools (torch's and the C kernels') have not been tuned yet
     scn_oracle.FAST = False
     t_torch = step()
     t_c = None
-    if _fast.available:
+    if args.cpu_fast and _fast.available:
         scn_oracle.FAST = True
         t_c = step()
         scn_oracle.FAST = t_c < t_torch
@@ -134,7 +137,7 @@ def cpu_baseline_subprocess(args):
     threads created after that inherit the mask — the host baseline must see every host core."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--dim', str(args.dim), '--occupancy',
-           str(args.occupancy), '--cpu-blocks', str(args.cpu_blocks)]
+           str(args.occupancy), '--cpu-blocks', str(args.cpu_blocks)] + (['--cpu-fast'] if args.cpu_fast else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     for line in reversed(out.stdout.strip().splitlines()):
         if line.startswith('{'):

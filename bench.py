@@ -145,6 +145,25 @@ def cpu_baseline_subprocess(args):
     raise RuntimeError('cpu baseline leg failed: %s' % out.stderr[-400:])
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with one rank per GPU
+    (the same command line the driver uses); rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get('SGNN_BENCH_SHARE_GPU') != '1':
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) are visible' % (args.gpus, n_dev))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -155,14 +174,24 @@ def main():
                 pass
         print(json.dumps(cpu_baseline(args)))
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('SGNN_BENCH_SHARE_GPU') == '1':
+            # test hook for 1-GPU boxes: every rank on a visible GPU (round robin), gradients exchanged through gloo
+            # (RCCL refuses two ranks on one device); exercises the launch + lock-step path, not xGMI
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -275,7 +304,8 @@ def main():
                                    '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam'
                                    % (args.batch, args.dim, 100 * args.occupancy),
                        'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
-                       'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world},
+                       'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world,
+                       'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if cpu:

@@ -107,6 +107,18 @@ int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t
                       int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
                       sgnn_stream_t stream);
 
+/* Phase 1 for `depth` successive levels in one submission (a U-Net's whole stride-2 pyramid), row counts staying on
+ * the device: level 0 = fine_coords with *n0_dev rows (n0_dev NULL: n0 rows), at most `cap` rows; for l < depth it
+ * writes parent[l] (cap ints: coarse row of every site of level l), coarse_coords[l] (cap x 4), the hash of level l+1
+ * (ckeys[l], cvals[l]; ccap = sgnn_hash_capacity(cap) each) and counts_dev[l] = rows of level l+1.  ckeys .. coarse_coords
+ * are HOST arrays of device pointers.  Results are identical to `depth` calls of sgnn_rulebook_down2 (first-touch
+ * order); the host reads all counts with one copy and then calls sgnn_down2_tables per level. */
+int64_t sgnn_down2_chain_ws_bytes(int64_t cap);
+int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_dev, int64_t cap, int depth,
+                     void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
+                     void *const *coarse_coords, int64_t *counts_dev, void *ws, int64_t ws_bytes,
+                     sgnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Sparse convolution: out[j] = sum_k W[k]^T x[table[k][j]]   (fp32 MFMA 16x16x4)
  * serves SubmanifoldConvolution fwd (table = nbr, K = 27), Convolution(2,2) fwd
@@ -148,9 +160,23 @@ int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *
                             const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows,
                             void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
-/* Large 3x3x3 levels of narrow layers run a variant that reuses gathered rows along x (lane rotates instead
- * of repeated gathers, conv.hip); 0 switches it off (A/B measurements, parity test).  Returns the old value. */
-int sgnn_conv_set_dxr(int on);
+/* Plain rulebook walk with strided rows and a fused epilogue (what the program executor uses to remove the
+ * AddTable / BatchNorm-statistics passes around a convolution, torch/model.py:33-42 and the FullyConvolutionalNet
+ * blocks):
+ *   x rows have stride ldx floats, y rows ldy, addend rows ld_add (0 = contiguous);
+ *   y = conv + addend when addend != NULL (addend may be y itself: accumulate in place);
+ *   stats = 1: partial[blk][0][c] = sum over the workgroup's rows of y, [1][c] = sum of y*y;
+ *   stats = 2: y is the gradient w.r.t. a BatchNormReLU output whose INPUT rows are bn_x (stride ld_bnx) with
+ *              mean / invstd / gamma / beta (gamma, beta may be NULL) and leak: partial = sum dz, sum dz*xhat with
+ *              dz = y * (bn_out > 0 ? 1 : leak) — the reduction BatchNorm backward starts with.
+ * partial holds sgnn_conv_stats_blocks(n_out) * 2 * cout doubles; sgnn_bn_fwd_ex / sgnn_bn_bwd_ex accept it as
+ * pre_partial.  Only for the compiled (cin, cout) shapes; SGNN_EINVAL otherwise. */
+int64_t sgnn_conv_stats_blocks(int64_t n_out);
+int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
+                      const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
+                      const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,
+                      int64_t ld_bnx, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                      float leak, sgnn_stream_t stream);
 
 /* weight gradient dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]; deterministic
  * two-stage reduction through the workspace. */
@@ -180,12 +206,27 @@ int sgnn_bn_bwd_add(const float *x, const float *dy, int64_t n, int c, const flo
                     const float *addend, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
                     sgnn_stream_t stream);
 
+/* strided rows (ldx, ldy, ... in floats; 0 = c) and optional statistics partials from a convolution epilogue
+ * (pre_partial / pre_nblk, see sgnn_conv_fwd_epi): the statistics pass is skipped */
+int sgnn_bn_fwd_ex(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
+                   float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
+                   float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
+                   int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_bn_bwd_ex(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
+                   const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
+                   const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
+                   const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Row movement (all pure copies / sums, fp32 rows of c floats)
  * ------------------------------------------------------------------------- */
 /* dst[r] = src[idx[r]]  (UnPooling fwd: idx = parent; mask compaction: idx = sel) */
 int sgnn_gather_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
                      sgnn_stream_t stream);
+/* the same with the row count read from device memory (*m_dev <= m_cap): no host round trip between a mask
+ * compaction and the consumers of the compacted coordinates */
+int sgnn_gather_rows_dn(const float *src, int c, const int32_t *idx, const int64_t *m_dev, int64_t m_cap,
+                        float *dst, sgnn_stream_t stream);
 /* dst (n_dst rows, zero-filled here) ; dst[idx[r]] = src[r]   (idx unique) */
 int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
                       int64_t n_dst, sgnn_stream_t stream);
@@ -286,7 +327,12 @@ int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int
  * Feature buffers live in a caller-owned arena (sgnn_prog_arena_floats floats; layout via
  * sgnn_prog_buffer_offset); `input` optionally points buffer 0 outside the arena.  Backward: garena has the
  * same layout, the caller fills the output gradients and flags them in ginit[nbuf].
+ * keep[nbuf] (host, may be NULL) flags the buffers the caller reads after the forward call (outputs / taps): the
+ * executor fuses conv -> AddTable and conv -> BatchNorm statistics into the convolution epilogue and then never
+ * materialises the convolution's own output buffer unless it is flagged.  sgnn_prog_set_fusion(0) switches the
+ * fusions off (A/B measurements, parity tests); it returns the previous setting.
  * ------------------------------------------------------------------------- */
+int sgnn_prog_set_fusion(int on);
 int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
                                const int64_t *lev_n, int nlev);
 int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
@@ -296,7 +342,8 @@ int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int3
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
                       int nlev, void *const *params, int nparams, const float *input, float *arena,
-                      int64_t arena_floats, int training, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+                      int64_t arena_floats, const int32_t *keep, int training, void *ws, int64_t ws_bytes,
+                      sgnn_stream_t stream);
 int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,

@@ -16,10 +16,8 @@ ap.add_argument('--dim', type=int, default=64)
 ap.add_argument('--kind', default='surface')
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--cases', default='16x16,48x16,16x48,8x8,26x16')
-ap.add_argument('--dxr', type=int, default=0, help='1: use the retired x-reuse conv kernel for <16,16> (library default: off)')
 args = ap.parse_args()
 dev = torch.device('cuda')
-_lib.load().sgnn_conv_set_dxr(args.dxr)
 d = args.dim if args.kind == 'surface' else args.dim // 2
 data = synth.make_batch(args.batch, (d,) * 3, cfg=2, occupancy=0.05 if args.kind == 'surface' else 0.2)
 coords = coords_from_locs(data['input'][0], dev)

@@ -9,7 +9,8 @@ from sgnn_amd.train import train_step, to_device, make_optimizer
 torch.manual_seed(1234)
 m = GenModel(8, (64,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
 opt = make_optimizer(m.parameters(), lr=1e-3)
-batch = to_device(synth.make_batch(2, (64,) * 3, cfg=2), 'cuda')
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+batch = to_device(synth.make_batch(NB, (64,) * 3, cfg=2), 'cuda')
 lw = np.ones(5, dtype=np.float32)
 for _ in range(3): train_step(m, opt, batch, lw)
 torch.cuda.synchronize()

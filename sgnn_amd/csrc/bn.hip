@@ -29,6 +29,15 @@ static BnGeom bn_geom(int c) {
   return g;
 }
 
+static BnGeom bn_geom_scalar(int c) {   // unaligned views: one float per thread-column
+  BnGeom g;
+  g.vec = 1;
+  g.cq = c;
+  g.rpb = 256 / c;
+  if (g.rpb < 1) g.rpb = 1;
+  return g;
+}
+
 static int bn_blocks(int64_t n, const BnGeom &g) {
   int64_t b = (n + (int64_t)g.rpb * BN_FLUSH - 1) / ((int64_t)g.rpb * BN_FLUSH);
   if (b < 1) b = 1;
@@ -62,10 +71,11 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
 // partial[blk][0][c] = sum_a, partial[blk][1][c] = sum_b over this block's rows where
 //   MODE 0 (forward stats):  a = x,            b = x*x
 //   MODE 1 (backward):       a = dz,           b = dz * xhat      (dz = dy masked by the ReLU/leak)
+// ldx / ld_dy: row strides in floats (>= c; rows of a column range of a wider buffer)
 template <int VEC, int MODE>
-__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, const float *__restrict__ dy,
-                                                   int64_t n, int c, int cq, int rpb,
-                                                   const float *__restrict__ mean,
+__global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, int64_t ldx,
+                                                   const float *__restrict__ dy, int64_t ld_dy, int64_t n, int c,
+                                                   int cq, int rpb, const float *__restrict__ mean,
                                                    const float *__restrict__ invstd,
                                                    const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float leak,
@@ -103,8 +113,8 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
         const int64_t rr = row + it * step;
         keep[it] = rr < n;
         const int64_t rc = rr < n ? rr : row;
-        load_vec<VEC>(x + rc * c + col * VEC, xv[it]);
-        if (MODE == 1) load_vec<VEC>(dy + rc * c + col * VEC, dv[it]);
+        load_vec<VEC>(x + rc * ldx + col * VEC, xv[it]);
+        if (MODE == 1) load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[it]);
       }
 #pragma unroll
       for (int it = 0; it < BN_FLUSH; ++it) {
@@ -215,9 +225,8 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__
 // Small levels (few block partials, C <= BN_FUSE_MAXC): the apply kernels finalise the statistics themselves — every
 // workgroup sums the short partial table in the same fixed order into LDS, workgroup 0 also stores the results the
 // later passes / the caller need — and the separate finalize launch disappears.
-#define BN_LDS_MAXC 256   // per-channel constants are staged in LDS up to this many channels
 #define BN_U 2            // row groups a thread loads before it uses the first one
-#define BN_FUSE_BLOCKS 128
+#define BN_FUSE_BLOCKS 192
 #define BN_FUSE_MAXC 64
 
 struct BnFuse {
@@ -256,13 +265,15 @@ __device__ __forceinline__ void bn_fuse_totals(const BnFuse &f, int c, double *s
   __syncthreads();
 }
 
+// Thread mapping of the apply passes = the one of the statistics pass: a thread owns one column group (VEC channels, its
+// constants live in registers) and walks rows row0 + i*step, BN_U rows in flight; ldx / ldy = row strides (floats).
 template <int VEC>
-__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t n, int c, int cq,
-                                                 const float *__restrict__ mean,
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t ldx, int64_t n, int c, int cq,
+                                                 int rpb, const float *__restrict__ mean,
                                                  const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma,
                                                  const float *__restrict__ beta, float leak,
-                                                 float *__restrict__ y, BnFuse fuse) {
+                                                 float *__restrict__ y, int64_t ldy, BnFuse fuse) {
   __shared__ float s_mean[BN_FUSE_MAXC], s_inv[BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   if (fuse.partial) {
@@ -289,47 +300,38 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
     mean = s_mean;
     invstd = s_inv;
   }
-  // per-channel constants live in LDS (a per-lane global load per constant per element made the texture addresser, not
-  // HBM, the limit of this kernel); BN_U independent row loads are in flight per thread before the first use
-  __shared__ __attribute__((aligned(16))) float s_k[4 * BN_LDS_MAXC];
-  const bool lds_k = c <= BN_LDS_MAXC;
-  if (lds_k) {
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-      s_k[ch] = mean[ch];
-      s_k[BN_LDS_MAXC + ch] = invstd[ch];
-      s_k[2 * BN_LDS_MAXC + ch] = gamma ? gamma[ch] : 1.f;
-      s_k[3 * BN_LDS_MAXC + ch] = beta ? beta[ch] : 0.f;
-    }
-    __syncthreads();
+  const int tid = threadIdx.x;
+  const int col = tid % cq, rloc = tid / cq;
+  if (rloc >= rpb) return;
+  float km[VEC], ki[VEC], kg[VEC], kb[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int ch = col * VEC + v;
+    km[v] = mean[ch];
+    ki[v] = invstd[ch];
+    kg[v] = gamma ? gamma[ch] : 1.f;
+    kb[v] = beta ? beta[ch] : 0.f;
   }
-  auto K_ = [&](int which, int ch) -> float {
-    if (lds_k) return s_k[which * BN_LDS_MAXC + ch];
-    return which == 0 ? mean[ch] : which == 1 ? invstd[ch] : which == 2 ? (gamma ? gamma[ch] : 1.f) : (beta ? beta[ch] : 0.f);
-  };
-  // flat element-group index; channel group = g % cq
-  const int64_t groups = n * cq;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x; g0 < groups; g0 += stride * BN_U) {
+  const int64_t step = (int64_t)gridDim.x * rpb;
+  for (int64_t r0 = (int64_t)blockIdx.x * rpb + rloc; r0 < n; r0 += step * BN_U) {
     float xv[BN_U][VEC];
 #pragma unroll
     for (int u = 0; u < BN_U; ++u) {
-      const int64_t g = g0 + u * stride;
-      load_vec<VEC>(x + (g < groups ? g : g0) * VEC, xv[u]);      // clamped: the load itself is unconditional
+      const int64_t r = r0 + u * step;
+      load_vec<VEC>(x + (r < n ? r : r0) * ldx + col * VEC, xv[u]);      // clamped: the load itself is unconditional
     }
 #pragma unroll
     for (int u = 0; u < BN_U; ++u) {
-      const int64_t g = g0 + u * stride;
-      if (g >= groups) break;
-      const int col = (int)(g % cq);
+      const int64_t r = r0 + u * step;
+      if (r >= n) break;
       float yv[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const int ch = col * VEC + v;
-        const float xh = (xv[u][v] - K_(0, ch)) * K_(1, ch);
-        const float t = fmaf(xh, K_(2, ch), K_(3, ch));
+        const float xh = (xv[u][v] - km[v]) * ki[v];
+        const float t = fmaf(xh, kg[v], kb[v]);
         yv[v] = t > 0.f ? t : t * leak;
       }
-      store_vec<VEC>(y + g * VEC, yv);
+      store_vec<VEC>(y + r * ldy + col * VEC, yv);
     }
   }
 }
@@ -351,13 +353,14 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restric
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ dy,
-                                                     int64_t n, int c, int cq, const float *__restrict__ mean,
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, int64_t ldx,
+                                                     const float *__restrict__ dy, int64_t ld_dy, int64_t n, int c,
+                                                     int cq, int rpb, const float *__restrict__ mean,
                                                      const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float leak, int training,
-                                                     const float *__restrict__ coef, float *dx, BnFuse fuse,
-                                                     const float *addend) {
+                                                     const float *__restrict__ coef, float *dx, int64_t ld_dx,
+                                                     BnFuse fuse, const float *addend, int64_t ld_add) {
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   if (fuse.partial) {
@@ -374,91 +377,95 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     __syncthreads();
     coef = s_coef;
   }
-  __shared__ __attribute__((aligned(16))) float s_k[6 * BN_LDS_MAXC];
-  const bool lds_k = c <= BN_LDS_MAXC;
-  if (lds_k) {
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-      s_k[ch] = mean[ch];
-      s_k[BN_LDS_MAXC + ch] = invstd[ch];
-      s_k[2 * BN_LDS_MAXC + ch] = gamma ? gamma[ch] : 1.f;
-      s_k[3 * BN_LDS_MAXC + ch] = beta ? beta[ch] : 0.f;
-      s_k[4 * BN_LDS_MAXC + ch] = training ? coef[ch] : 0.f;
-      s_k[5 * BN_LDS_MAXC + ch] = training ? coef[c + ch] : 0.f;
-    }
-    __syncthreads();
+  const int tid = threadIdx.x;
+  const int col = tid % cq, rloc = tid / cq;
+  if (rloc >= rpb) return;
+  float km[VEC], ki[VEC], kg[VEC], kb[VEC], k4[VEC], k5[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int ch = col * VEC + v;
+    km[v] = mean[ch];
+    ki[v] = invstd[ch];
+    kg[v] = gamma ? gamma[ch] : 1.f;
+    kb[v] = beta ? beta[ch] : 0.f;
+    k4[v] = training ? coef[ch] : 0.f;
+    k5[v] = training ? coef[c + ch] : 0.f;
   }
-  auto K_ = [&](int which, int ch) -> float {
-    if (lds_k) return s_k[which * BN_LDS_MAXC + ch];
-    switch (which) {
-      case 0: return mean[ch];
-      case 1: return invstd[ch];
-      case 2: return gamma ? gamma[ch] : 1.f;
-      case 3: return beta ? beta[ch] : 0.f;
-      case 4: return training ? coef[ch] : 0.f;
-      default: return training ? coef[c + ch] : 0.f;
-    }
-  };
-  const int64_t groups = n * cq;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x; g0 < groups; g0 += stride * BN_U) {
+  const int64_t step = (int64_t)gridDim.x * rpb;
+  for (int64_t r0 = (int64_t)blockIdx.x * rpb + rloc; r0 < n; r0 += step * BN_U) {
     float xv[BN_U][VEC], dv[BN_U][VEC], av[BN_U][VEC];
 #pragma unroll
     for (int u = 0; u < BN_U; ++u) {
-      const int64_t g = g0 + u * stride, gc = (g < groups ? g : g0);
-      load_vec<VEC>(x + gc * VEC, xv[u]);
-      load_vec<VEC>(dy + gc * VEC, dv[u]);
-      if (addend) load_vec<VEC>(addend + gc * VEC, av[u]);      // uniform over the launch
+      const int64_t r = r0 + u * step, rc = (r < n ? r : r0);
+      load_vec<VEC>(x + rc * ldx + col * VEC, xv[u]);
+      load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[u]);
+      if (addend) load_vec<VEC>(addend + rc * ld_add + col * VEC, av[u]);      // uniform over the launch
     }
 #pragma unroll
     for (int u = 0; u < BN_U; ++u) {
-      const int64_t g = g0 + u * stride;
-      if (g >= groups) break;
-      const int col = (int)(g % cq);
+      const int64_t r = r0 + u * step;
+      if (r >= n) break;
       float ov[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const int ch = col * VEC + v;
-        const float gm = K_(2, ch), is = K_(1, ch);
-        const float xh = (xv[u][v] - K_(0, ch)) * is;
-        const float t = fmaf(xh, gm, K_(3, ch));
+        const float xh = (xv[u][v] - km[v]) * ki[v];
+        const float t = fmaf(xh, kg[v], kb[v]);
         const float dz = t > 0.f ? dv[u][v] : dv[u][v] * leak;
         float d = dz;
-        if (training) d = dz - K_(4, ch) - xh * K_(5, ch);
-        ov[v] = d * gm * is;
+        if (training) d = dz - k4[v] - xh * k5[v];
+        ov[v] = d * kg[v] * ki[v];
         if (addend) ov[v] += av[u][v];   // gradient already accumulated for this buffer (may be dx itself: in place)
       }
-      store_vec<VEC>(dx + g * VEC, ov);
+      store_vec<VEC>(dx + r * ld_dx + col * VEC, ov);
     }
   }
 }
 
-SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
-                            float *running_mean, float *running_var, float eps, float momentum, int training,
-                            float leak, float *save_mean, float *save_invstd, float *y, void *ws,
-                            int64_t ws_bytes, sgnn_stream_t stream) {
+static int bn_apply_grid(int64_t n, const BnGeom &g) {
+  int64_t b = (n + (int64_t)g.rpb * BN_U - 1) / ((int64_t)g.rpb * BN_U);
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+
+// pre_partial / pre_nblk: statistics partials already produced by the convolution that wrote x (ConvEpi.stats = 1):
+// the statistics pass is skipped.  ldx / ldy: row strides (0 = c).
+int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
+                     float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
+                     float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
-  const BnGeom g = bn_geom(c);
+  if (ldx <= 0) ldx = c;
+  if (ldy <= 0) ldy = c;
+  SGNN_CHECK_ARG(ldx >= c && ldy >= c);
+  BnGeom g = bn_geom(c);
+  if (g.vec == 4 && (ldx % 4 || ldy % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))) g = bn_geom_scalar(c);
   BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (training && n > 0) {
     SGNN_CHECK_ARG(x);
-    if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
-      sgnn_set_error("sgnn_bn_fwd: workspace too small");
-      return SGNN_ENOWS;
+    const double *partial = pre_partial;
+    int64_t nblk = pre_nblk;
+    if (!partial) {
+      if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
+        sgnn_set_error("sgnn_bn_fwd: workspace too small");
+        return SGNN_ENOWS;
+      }
+      nblk = bn_blocks(n, g);
+      const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
+      if (g.vec == 4)
+        hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+      else
+        hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+      partial = (const double *)ws;
     }
-    const int nblk = bn_blocks(n, g);
-    const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
-    if (g.vec == 4)
-      hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
-                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
-    else
-      hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3(nblk), dim3(256), shbytes, s, x, nullptr, n, c, g.cq, g.rpb,
-                         nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
     if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)   // small level: k_bn_apply finalises
-      fuse = BnFuse{(const double *)ws, nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
+      fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
-      hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, (const double *)ws, nblk, n, c, eps, momentum,
+      hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
                          running_mean, running_var, save_mean, save_invstd);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
@@ -469,30 +476,66 @@ SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma
   }
   if (n > 0) {
     SGNN_CHECK_ARG(x && y);
-    const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
+    const int grid = bn_apply_grid(n, g);
     if (g.vec == 4)
-      hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
-                         (const float *)save_invstd, gamma, beta, leak, y, fuse);
+      hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
+                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse);
     else
-      hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, n, c, g.cq, (const float *)save_mean,
-                         (const float *)save_invstd, gamma, beta, leak, y, fuse);
+      hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
+                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_bn_fwd(const float *x, int64_t n, int c, const float *gamma, const float *beta,
+                            float *running_mean, float *running_var, float eps, float momentum, int training,
+                            float leak, float *save_mean, float *save_invstd, float *y, void *ws,
+                            int64_t ws_bytes, sgnn_stream_t stream) {
+  return sgnn_bn_fwd_impl(x, c, n, c, gamma, beta, running_mean, running_var, eps, momentum, training, leak, save_mean,
+                          save_invstd, y, c, nullptr, 0, ws, ws_bytes, stream);
+}
+
+SGNN_EXPORT int sgnn_bn_fwd_ex(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
+                               float *running_mean, float *running_var, float eps, float momentum, int training,
+                               float leak, float *save_mean, float *save_invstd, float *y, int64_t ldy,
+                               const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes,
+                               sgnn_stream_t stream) {
+  return sgnn_bn_fwd_impl(x, ldx, n, c, gamma, beta, running_mean, running_var, eps, momentum, training, leak,
+                          save_mean, save_invstd, y, ldy, pre_partial, pre_nblk, ws, ws_bytes, stream);
 }
 
 SGNN_EXPORT int sgnn_bn_bwd(const float *x, const float *dy, int64_t n, int c, const float *gamma,
                             const float *beta, const float *save_mean, const float *save_invstd, int training,
                             float leak, float *dx, float *dgamma, float *dbeta, void *ws, int64_t ws_bytes,
                             sgnn_stream_t stream) {
-  return sgnn_bn_bwd_add(x, dy, n, c, gamma, beta, save_mean, save_invstd, training, leak, nullptr, dx, dgamma, dbeta,
-                         ws, ws_bytes, stream);
+  return sgnn_bn_bwd_impl(x, c, dy, c, n, c, gamma, beta, save_mean, save_invstd, training, leak, nullptr, c, dx, c,
+                          dgamma, dbeta, nullptr, 0, ws, ws_bytes, stream);
 }
 
 SGNN_EXPORT int sgnn_bn_bwd_add(const float *x, const float *dy, int64_t n, int c, const float *gamma,
                                 const float *beta, const float *save_mean, const float *save_invstd, int training,
                                 float leak, const float *addend, float *dx, float *dgamma, float *dbeta, void *ws,
                                 int64_t ws_bytes, sgnn_stream_t stream) {
+  return sgnn_bn_bwd_impl(x, c, dy, c, n, c, gamma, beta, save_mean, save_invstd, training, leak, addend, c, dx, c,
+                          dgamma, dbeta, nullptr, 0, ws, ws_bytes, stream);
+}
+
+SGNN_EXPORT int sgnn_bn_bwd_ex(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd, int training, float leak, const float *addend,
+                               int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
+                               const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes,
+                               sgnn_stream_t stream) {
+  return sgnn_bn_bwd_impl(x, ldx, dy, ld_dy, n, c, gamma, beta, save_mean, save_invstd, training, leak, addend, ld_add,
+                          dx, ld_dx, dgamma, dbeta, pre_partial, pre_nblk, ws, ws_bytes, stream);
+}
+
+// pre_partial: sum dz / sum dz*xhat partials produced by the data-gradient convolution that wrote dy (ConvEpi.stats = 2)
+int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
+                     const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
+                     const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
+                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   if (n == 0) {
@@ -501,34 +544,46 @@ SGNN_EXPORT int sgnn_bn_bwd_add(const float *x, const float *dy, int64_t n, int 
     return SGNN_OK;
   }
   SGNN_CHECK_ARG(x && dy && dx);
+  if (ldx <= 0) ldx = c;
+  if (ld_dy <= 0) ld_dy = c;
+  if (ld_dx <= 0) ld_dx = c;
+  if (ld_add <= 0) ld_add = c;
+  SGNN_CHECK_ARG(ldx >= c && ld_dy >= c && ld_dx >= c && ld_add >= c);
   if (!ws || ws_bytes < sgnn_bn_ws_bytes(n, c)) {
     sgnn_set_error("sgnn_bn_bwd: workspace too small");
     return SGNN_ENOWS;
   }
-  const BnGeom g = bn_geom(c);
-  const int nblk = bn_blocks(n, g);
-  const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
-  double *partial = (double *)ws;
+  BnGeom g = bn_geom(c);
+  if (g.vec == 4 && (ldx % 4 || ld_dy % 4 || ld_dx % 4 || ld_add % 4 || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) ||
+                     ((uintptr_t)dx & 15) || ((uintptr_t)addend & 15)))
+    g = bn_geom_scalar(c);
+  const double *partial = pre_partial;
+  int64_t nblk = pre_nblk;
+  // the coefficient block always lives behind the largest partial table this library writes into ws
   float *coef = (float *)((char *)ws + (size_t)BN_MAX_BLOCKS * 2 * c * sizeof(double));
-  if (g.vec == 4)
-    hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, partial);
-  else
-    hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3(nblk), dim3(256), shbytes, s, x, dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, partial);
+  if (!partial) {
+    nblk = bn_blocks(n, g);
+    const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
+    if (g.vec == 4)
+      hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws);
+    else
+      hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws);
+    partial = (const double *)ws;
+  }
   BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)
-    fuse = BnFuse{(const double *)partial, nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
+    fuse = BnFuse{partial, (int)nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   else
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, (const double *)partial, nblk, n, c, dgamma, dbeta,
-                       coef);
-  const int grid = sgnn_grid_for(n * g.cq, 256, 2048);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef);
+  const int grid = bn_apply_grid(n, g);
   if (g.vec == 4)
-    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx, fuse, addend);
+    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, dy, n, c, g.cq, save_mean, save_invstd,
-                       gamma, beta, leak, training, (const float *)coef, dx, fuse, addend);
+    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -12,6 +12,42 @@ void sgnn_set_error(const char *fmt, ...);
 int sgnn_prof_begin_launch(int kind, int64_t n_out, int cin, int cout, int K, int flags, hipStream_t s);
 void sgnn_prof_end_launch(int slot, hipStream_t s);
 
+// Epilogue / layout options of the output-stationary kernel (sgnn_conv_fwd_epi; prog.hip fuses with them):
+//  * ldx / ldy / ld_add: row strides (floats) of x, y and addend, so that a convolution can read from and write
+//    into a column range of a wider buffer (JoinTable without a copy);
+//  * addend: y = conv + addend (the residual AddTable, or gradient accumulation in place: addend may alias y);
+//  * stats = 1: per-workgroup column sums of y and y*y (the statistics the next BatchNorm needs);
+//    stats = 2: y is the gradient reaching a BatchNormReLU output; column sums of dz and dz*xhat with
+//    dz = y * (bn_out > 0 ? 1 : leak), xhat from bn_x / mean / invstd (what BatchNorm backward reduces first).
+//    partial[blk][2][COUT] doubles, blk = workgroup; summed later in fixed order (deterministic).
+struct ConvEpi {
+  int64_t ldx, ldy, ld_add;
+  const float *addend;
+  int stats;
+  double *partial;
+  const float *bn_x;
+  int64_t ld_bnx;
+  const float *mean, *invstd, *gamma, *beta;
+  float leak;
+};
+
+// conv.hip internals used by prog.hip
+int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                       int64_t n_out, int cout, float *y, int flags, int in_shift, const int32_t *kmap,
+                       const int32_t *kadd, int in_mul, int groups, int table_rows, const ConvEpi *epi,
+                       sgnn_stream_t stream);
+int64_t sgnn_conv_grid_blocks(int64_t n_out);
+// bn.hip internals used by prog.hip (strided rows, statistics partials supplied by a convolution epilogue)
+int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
+                     float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
+                     float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
+                     const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
+                     const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
+                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+bool sgnn_conv_epi_supported(int cin, int cout);
+
 #define SGNN_CHECK_ARG(cond)                                                    \
   do {                                                                          \
     if (!(cond)) {                                                              \

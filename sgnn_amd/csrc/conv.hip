@@ -85,8 +85,8 @@ __device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint3
 template <int CIN, int COUT, int M, bool EX>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
-                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ y, int flags,
-                                                 int in_shift, ConvEx ex) {
+                                                 int64_t ld, int K, int64_t n_out, float *y, int flags,
+                                                 int in_shift, ConvEx ex, ConvEpi epi) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
   constexpr int RPW = 16 * M;   // rows per wave: M = 4 normally, 1 when the level is too small to fill the chip
@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const int table_rows = EX ? ex.table_rows : K;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
+  const uint32_t ldx4 = (uint32_t)epi.ldx * 4u, ldy4 = (uint32_t)epi.ldy * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)table_rows * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * groups * COUT * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(((n_out * groups - 1) * epi.ldy + COUT) * 4));
   const uint32_t lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;   // this lane's rule entry in an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];                                               // ds_bpermute byte address of tile m's entry
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
-      buf_load_floats<V>(rs_x, (uint32_t)id * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a[m]);
+      buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[m]);
       if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
 #pragma unroll
         for (int s = 0; s < V; ++s)
@@ -246,176 +247,81 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   }
 
   // C/D layout: col = lane&15, row = (lane>>4)*4 + reg; out-of-range rows/cols are dropped by the buffer bounds
+  const bool has_add = epi.addend != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(has_add ? epi.addend : x, has_add ? (uint32_t)(((n_out * groups - 1) * epi.ld_add + COUT) * 4) : 0u);
+  const uint32_t lda4 = (uint32_t)epi.ld_add * 4u;
+  const int stats = EX ? 0 : epi.stats;
+  const __amdgpu_buffer_rsrc_t rs_b =
+      make_rsrc(stats == 2 ? epi.bn_x : x, stats == 2 ? (uint32_t)(((n_out - 1) * epi.ld_bnx + COUT) * 4) : 0u);
+  const uint32_t ldb4 = (uint32_t)epi.ld_bnx * 4u;
+  double s1[NT], s2[NT];
 #pragma unroll
-  for (int m = 0; m < M; ++m)
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 16 + r;
+    float cm = 0.f, ci = 0.f, cg = 1.f, cb = 0.f;
+    if (stats == 2 && col < COUT) {
+      cm = epi.mean[col];
+      ci = epi.invstd[col];
+      cg = epi.gamma ? epi.gamma[col] : 1.f;
+      cb = epi.beta ? epi.beta[col] : 0.f;
+    }
+    // fp64 from the first addition on: E[x^2] - E[x]^2 downstream must stay exact to fp32 resolution
+    double f1 = 0.0, f2 = 0.0;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = nt * 16 + r;
+    for (int m = 0; m < M; ++m) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + m * 16 + q * 4 + i;
-        const uint32_t off =
-            (col < COUT && row < n_out) ? (uint32_t)((row * groups + grp) * COUT + col) * 4u : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nt][i]), rs_y, off, 0, 0);
+        const bool ok = col < COUT && row < n_out;
+        const uint32_t orow = (uint32_t)(row * groups + grp);
+        float v = acc[m][nt][i];
+        if (has_add) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, ok ? orow * lda4 + col * 4u : 0xFFFFFFFFu, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_y, ok ? orow * ldy4 + col * 4u : 0xFFFFFFFFu, 0, 0);
+        if (stats == 1) {
+          const double vm = ok ? (double)v : 0.0;
+          f1 += vm;
+          f2 = fma(vm, vm, f2);
+        } else if (stats == 2) {
+          const float xb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, ok ? orow * ldb4 + col * 4u : 0xFFFFFFFFu, 0, 0));
+          const float xh = (xb - cm) * ci;
+          const float t = fmaf(xh, cg, cb);
+          const float dz = ok ? (t > 0.f ? v : v * epi.leak) : 0.f;
+          f1 += (double)dz;
+          f2 = fma((double)dz, (double)xh, f2);
+        }
       }
     }
-}
-
-// ---------------------------------------------------------------------------
-// 3x3x3 forward / data-gradient with reuse along x.  Offsets 3g, 3g+1, 3g+2 are the dx = -1, 0, +1 taps of
-// the same (dz, dy).  When rows j and j+1 of a tile are x-adjacent sites, the dx = +1 neighbour of row j IS the
-// dx = 0 neighbour of row j+1 (and dx = -1 of j is dx = 0 of j-1), so its feature row is already in the
-// registers of the neighbouring lane: one 16-lane rotate (DPP) instead of another gather.  The rule entries
-// say exactly when this holds: lane j takes the shortcut iff its own entry equals the centre entry of the lane
-// it rotates from (the index takes the same rotate as the data, so the test is exact for any table and any
-// site order); all other lanes fall back to an exec-masked gather.  The texture addresser is the saturated
-// unit of the plain kernel (profiles/r01c_conv_pmc.txt); on raster-ordered surface blocks this removes about
-// half of its gather work.  Narrow layers only (CIN <= 16, one output tile): all 27 weight slices stay in LDS.
-// ---------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-#define DPP_ROW_ROR(n) (0x120 + (n))
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_conv_fwd_dxr(const float *__restrict__ x, int64_t n_in,
-                                                     const float *__restrict__ w, const int32_t *__restrict__ table,
-                                                     int64_t ld, int64_t n_out, float *__restrict__ y, int flags) {
-  using C = ConvCfg<CIN, COUT>;
-  constexpr int V = C::V, CINP = C::CINP, M = CONV_MREP, K = 27;
-  static_assert(C::NT == 1 && C::KC == 27, "dx-reuse kernel: one output tile, all offsets resident");
-  __shared__ __attribute__((aligned(16))) float wl[K * C::PER_K];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const unsigned tile = sgnn_xcd_tile(blockIdx.x, gridDim.x);
-  const int64_t row0 = ((int64_t)tile * 4 + wave) * (16 * M);
-  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * CIN * 4));
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(n_out * COUT * 4));
-  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;
-  const uint32_t ld4 = (uint32_t)ld * 4u;
-
-  for (int e = tid; e < K * C::PER_K; e += 256) {   // wl[k][n][c], zero padded
-    const int c = e % CINP, n = (e / CINP) % 16, k = e / C::PER_K;
-    float v = 0.f;
-    if (c < CIN && n < COUT) {
-      const int ks = flip ? (K - 1 - k) : k;
-      v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
-    }
-    wl[e] = v;
+    s1[nt] = f1;
+    s2[nt] = f2;
   }
-  __syncthreads();
-
-  f32x4 acc[M];
+  if (stats) {
+    // lanes r, r+16, r+32, r+48 hold the same column: fold them, then the four waves in fixed order through LDS
+    // (the weight tile is dead by now)
+    double *sred = reinterpret_cast<double *>(wl);   // [4 waves][2][NT*16]
+    static_assert(sizeof(wl) >= 4 * 2 * NT * 16 * sizeof(double), "weight tile too small for the statistics scratch");
+    __syncthreads();
 #pragma unroll
-  for (int m = 0; m < M; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto load_iv = [&](int k) -> int32_t { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0); };
-  auto row_id = [&](int32_t iv, int m) -> int32_t { return __builtin_amdgcn_ds_bpermute((m * 16 + r) * 4, iv); };
-  auto gather_row = [&](int32_t id, float(&a)[V]) {
-    buf_load_floats<V>(rs_x, (uint32_t)id * (uint32_t)(CIN * 4) + (uint32_t)(q * V * 4), a);
-    if constexpr (CINP != CIN) {
-#pragma unroll
-      for (int s = 0; s < V; ++s)
-        if (3 * V + s >= CIN) a[s] = (q == 3) ? 0.f : a[s];
-    }
-  };
-  auto mma = [&](int k, const float(&a)[M][V]) {
-    const float *bp = wl + (k * 16 + r) * CINP + q * V;
-    float b[V];
-#pragma unroll
-    for (int s = 0; s < V; ++s) b[s] = bp[s];
-#pragma unroll
-    for (int s = 0; s < V; ++s)
-#pragma unroll
-      for (int m = 0; m < M; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m], 0, 0, 0);
-  };
-
-  // rule entries of groups g and g+1 are resident; centre rows of group g are gathered one group ahead
-  int32_t ivL[2], ivC[2], ivR[2];
-  float aC[2][M][V];
-  int32_t idC[2][M];
-  ivL[0] = load_iv(0); ivC[0] = load_iv(1); ivR[0] = load_iv(2);
-  ivL[1] = load_iv(3); ivC[1] = load_iv(4); ivR[1] = load_iv(5);
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    idC[0][m] = row_id(ivC[0], m);
-    gather_row(idC[0][m], aC[0][m]);
-  }
-
-#pragma unroll
-  for (int g = 0; g < 9; ++g) {
-    const int cur = g & 1, nxt = cur ^ 1;
-    // side entries of this group; the entries the rotate would deliver come from the centre entries
-    int32_t idL[M], idR[M];
-    bool needL[M], needR[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      idL[m] = row_id(ivL[cur], m);
-      idR[m] = row_id(ivR[cur], m);
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int32_t fromPrev = dpp_i<DPP_ROW_ROR(1)>(idC[cur][m]);                       // lane r <- lane r-1 (mod 16)
-      const int32_t fromPrevTile = (m > 0) ? dpp_i<DPP_ROW_ROR(1)>(idC[cur][m > 0 ? m - 1 : 0]) : -2;
-      const int32_t fromNext = dpp_i<DPP_ROW_ROR(15)>(idC[cur][m]);                      // lane r <- lane r+1 (mod 16)
-      const int32_t fromNextTile = (m + 1 < M) ? dpp_i<DPP_ROW_ROR(15)>(idC[cur][m + 1 < M ? m + 1 : m]) : -2;
-      const int32_t eL = (r == 0) ? fromPrevTile : fromPrev;
-      const int32_t eR = (r == 15) ? fromNextTile : fromNext;
-      needL[m] = (idL[m] >= 0) && (idL[m] != eL);
-      needR[m] = (idR[m] >= 0) && (idR[m] != eR);
-    }
-    float aL[M][V], aR[M][V];
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int s = 0; s < V; ++s) {
-        const float p = dpp_f<DPP_ROW_ROR(1)>(aC[cur][m][s]);
-        const float pt = (m > 0) ? dpp_f<DPP_ROW_ROR(1)>(aC[cur][m > 0 ? m - 1 : 0][s]) : 0.f;
-        const float nx = dpp_f<DPP_ROW_ROR(15)>(aC[cur][m][s]);
-        const float nt = (m + 1 < M) ? dpp_f<DPP_ROW_ROR(15)>(aC[cur][m + 1 < M ? m + 1 : m][s]) : 0.f;
-        aL[m][s] = (idL[m] >= 0) ? ((r == 0) ? pt : p) : 0.f;
-        aR[m][s] = (idR[m] >= 0) ? ((r == 15) ? nt : nx) : 0.f;
-      }
-    // lanes whose neighbour is not in the adjacent lane: exec-masked gathers
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (needL[m]) gather_row(idL[m], aL[m]);
-      if (needR[m]) gather_row(idR[m], aR[m]);
-    }
-    // next group's centre rows and the rule entries after that
-    if (g + 1 < 9) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        idC[nxt][m] = row_id(ivC[nxt], m);
-        gather_row(idC[nxt][m], aC[nxt][m]);
+    for (int nt = 0; nt < NT; ++nt) {
+      double a = s1[nt], b = s2[nt];
+      a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+      a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+      if (q == 0) {
+        sred[(wave * 2 + 0) * NT * 16 + nt * 16 + r] = a;
+        sred[(wave * 2 + 1) * NT * 16 + nt * 16 + r] = b;
       }
     }
-    mma(3 * g + 1, aC[cur]);
-    if (g + 2 < 9) {
-      ivL[cur] = load_iv(3 * (g + 2));
-      ivC[cur] = load_iv(3 * (g + 2) + 1);
-      ivR[cur] = load_iv(3 * (g + 2) + 2);
+    __syncthreads();
+    for (int o = tid; o < 2 * NT * 16; o += 256) {
+      const int which = o / (NT * 16), col = o % (NT * 16);
+      if (col < COUT) {
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += sred[(wv * 2 + which) * NT * 16 + col];
+        epi.partial[((size_t)blockIdx.x * 2 + which) * COUT + col] = t;
+      }
     }
-    mma(3 * g, aL);
-    mma(3 * g + 2, aR);
   }
-
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t row = row0 + m * 16 + q * 4 + i;
-      const uint32_t off = (r < COUT && row < n_out) ? (uint32_t)(row * COUT + r) * 4u : 0xFFFFFFFFu;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][i]), rs_y, off, 0, 0);
-    }
 }
 
 // any (cin, cout): one thread per output element, plain FMA.  Correctness fallback for layer
@@ -453,35 +359,51 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 #define CONV_EX_CASES(X) \
   X(48, 16) X(16, 48) X(24, 8) X(8, 24) X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
-// layers that run the x-reuse kernel on large levels.  Measured at N = 366 k (scripts/bench_conv.py --dxr 0/1):
-// <16,16> 90.7 -> 78.1 us; <8,8> and <12,12> lose 12 % (too little MFMA work per row to pay for the rotates),
-// so only the 16-wide layers use it.
-#define CONV_DXR_CASES(X) X(16, 16)
-
-static int g_use_dxr = 0;   // off: with counted waits the plain kernel is faster (71.7 vs 78.8 us at N = 366 k)
-// 0 disables the x-reuse kernel (A/B measurements and its parity test); returns the previous setting
-SGNN_EXPORT int sgnn_conv_set_dxr(int on) {
-  const int prev = g_use_dxr;
-  g_use_dxr = on ? 1 : 0;
-  return prev;
-}
-
 #define CONV_FWD_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
   X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
   X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
 
-SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
-                                 int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
-                                 const int32_t *kmap, const int32_t *kadd, int in_mul, int groups,
-                                 int table_rows, sgnn_stream_t stream) {
+// number of workgroups (= statistics partial blocks) a plain launch over n_out rows uses
+int64_t sgnn_conv_grid_blocks(int64_t n_out) {
+  const int64_t grid4 = (n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK;
+  return grid4 < CONV_SMALL_GRID ? (n_out + 63) / 64 : grid4;
+}
+
+bool sgnn_conv_epi_supported(int cin, int cout) {
+#define X(CI, CO) \
+  if (cin == CI && cout == CO) return true;
+  CONV_FWD_CASES(X)
+#undef X
+  return false;
+}
+
+// the one implementation behind sgnn_conv_fwd / _ex / _epi (epi == NULL: contiguous rows, plain store)
+int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                       int64_t n_out, int cout, float *y, int flags, int in_shift, const int32_t *kmap,
+                       const int32_t *kadd, int in_mul, int groups, int table_rows, const ConvEpi *epi_in,
+                       sgnn_stream_t stream) {
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && in_shift >= 0 &&
                  in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
                  table_rows <= 64 && (kmap || table_rows >= K));
   if (n_out == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && table && y && n_in >= 1);
   SGNN_CHECK_ARG(ld % CONV_ROWS_PER_BLOCK == 0);  // and table[k][n_out..ld) must be -1 (see sgnn_hip.h)
-  if (n_in * cin * 4 > 0xFFFFF000ll || n_out * groups * cout * 4 > 0xFFFFF000ll ||
+  ConvEpi epi{};
+  if (epi_in) epi = *epi_in;
+  if (epi.ldx <= 0) epi.ldx = cin;
+  if (epi.ldy <= 0) epi.ldy = cout;
+  if (epi.ld_add <= 0) epi.ld_add = cout;
+  if (epi.ld_bnx <= 0) epi.ld_bnx = cout;
+  const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
+  const bool has_epi = epi.ldx != cin || epi.ldy != cout || epi.addend || epi.stats;
+  SGNN_CHECK_ARG(epi.ldx >= cin && epi.ldx <= 1024 && epi.ldy >= cout && epi.ldy <= 1024 && epi.ld_add >= cout &&
+                 epi.ld_add <= 1024 && epi.ld_bnx >= cout && epi.ld_bnx <= 1024);
+  SGNN_CHECK_ARG(epi.stats >= 0 && epi.stats <= 2 && (!epi.stats || (plain && epi.partial)));
+  SGNN_CHECK_ARG(epi.stats != 2 || (epi.bn_x && epi.mean && epi.invstd));
+  const int64_t lmax = epi.ldy > epi.ld_add ? (epi.ldy > epi.ld_bnx ? epi.ldy : epi.ld_bnx)
+                                            : (epi.ld_add > epi.ld_bnx ? epi.ld_add : epi.ld_bnx);
+  if (n_in * epi.ldx * 4 > 0xFFFFF000ll || n_out * groups * lmax * 4 > 0xFFFFF000ll ||
       (int64_t)table_rows * ld * 4 > 0xFFFFF000ll) {
     sgnn_set_error("sgnn_conv_fwd: a slab exceeds the 4 GiB raw-buffer window (n_in=%lld cin=%d n_out=%lld cout=%d)",
                    (long long)n_in, cin, (long long)n_out, cout);
@@ -494,26 +416,16 @@ SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const fl
   const bool small = grid4 < CONV_SMALL_GRID;   // too few 256-row workgroups for 256 CUs: 64-row workgroups
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
-  const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
 #define LAUNCH_FWD(CI, CO, EXV)                                                                         \
   do {                                                                                                  \
     if (small)                                                                                          \
       hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
-                         ld, K, n_out, y, flags, in_shift, ex);                                         \
+                         ld, K, n_out, y, flags, in_shift, ex, epi);                                    \
     else                                                                                                \
       hipLaunchKernelGGL((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in,   \
-                         w, table, ld, K, n_out, y, flags, in_shift, ex);                               \
+                         w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
     done = true;                                                                                        \
   } while (0)
-  const int use_dxr = g_use_dxr;
-#define X(CI, CO)                                                                                             \
-  if (!done && plain && use_dxr && !small && K == 27 && in_shift == 0 && cin == CI && cout == CO) {           \
-    hipLaunchKernelGGL((k_conv_fwd_dxr<CI, CO>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, \
-                       flags);                                                                                \
-    done = true;                                                                                              \
-  }
-  CONV_DXR_CASES(X)
-#undef X
 #define X(CI, CO) \
   if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)
@@ -523,6 +435,10 @@ SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const fl
   CONV_EX_CASES(X)
 #undef X
   if (!done) {
+    if (has_epi) {
+      sgnn_set_error("sgnn_conv_fwd_epi: strided / fused epilogues need one of the compiled (cin, cout) shapes, got (%d, %d)", cin, cout);
+      return SGNN_EINVAL;
+    }
     const int64_t total = n_out * groups * cout;
     hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
                        table, ld, n_out, cout, y, flags, in_shift, ex);
@@ -532,11 +448,32 @@ SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const fl
   return SGNN_OK;
 }
 
+SGNN_EXPORT int sgnn_conv_fwd_ex(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
+                                 int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
+                                 const int32_t *kmap, const int32_t *kadd, int in_mul, int groups,
+                                 int table_rows, sgnn_stream_t stream) {
+  return sgnn_conv_fwd_impl(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, kmap, kadd, in_mul,
+                            groups, table_rows, nullptr, stream);
+}
+
 SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table,
                               int64_t ld, int64_t n_out, int cout, float *y, int flags, int in_shift,
                               sgnn_stream_t stream) {
-  return sgnn_conv_fwd_ex(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, nullptr, nullptr, 1, 1,
-                          K, stream);
+  return sgnn_conv_fwd_impl(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, nullptr, nullptr, 1, 1,
+                            K, nullptr, stream);
+}
+
+SGNN_EXPORT int64_t sgnn_conv_stats_blocks(int64_t n_out) { return n_out > 0 ? sgnn_conv_grid_blocks(n_out) : 0; }
+
+// plain rulebook walk with strided rows and a fused epilogue (see ConvEpi; sgnn_hip.h)
+SGNN_EXPORT int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
+                                  const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy,
+                                  int flags, const float *addend, int64_t ld_add, int stats, double *partial,
+                                  const float *bn_x, int64_t ld_bnx, const float *mean, const float *invstd,
+                                  const float *gamma, const float *beta, float leak, sgnn_stream_t stream) {
+  ConvEpi epi{ldx, ldy, ld_add, addend, stats, partial, bn_x, ld_bnx, mean, invstd, gamma, beta, leak};
+  return sgnn_conv_fwd_impl(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, 0, nullptr, nullptr, 1, 1, K, &epi,
+                            stream);
 }
 
 // ---------------------------------------------------------------------------

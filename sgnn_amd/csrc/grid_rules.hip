@@ -480,6 +480,162 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
   return SGNN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// stride-2 rulebooks of several successive levels WITHOUT a host round trip in between: every kernel takes its row
+// count from device memory (the count the previous level / a mask compaction just wrote) and is launched for the
+// host-known upper bound `cap`.  One read-back then returns all counts (15 -> 5 host syncs per training step).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int64_t dev_n(const int64_t *n_dev, int64_t n_host) { return n_dev ? *n_dev : n_host; }
+
+__global__ __launch_bounds__(256) void k_chain_init(unsigned long long *__restrict__ ckeys, int32_t *__restrict__ owner,
+                                                   int64_t ccap, int32_t *__restrict__ rank_at, int64_t cap) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t top = ccap > cap ? ccap : cap;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < top; i += stride) {
+    if (i < ccap) {
+      ckeys[i] = ~0ull;
+      owner[i] = 0x7FFFFFFF;
+    }
+    if (i < cap) rank_at[i] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chain_insert(const int4 *__restrict__ fine, const int64_t *n_dev, int64_t n_host,
+                                                     unsigned long long *__restrict__ ckeys,
+                                                     int32_t *__restrict__ owner, uint64_t mask,
+                                                     int32_t *__restrict__ slot_of) {
+  const int64_t nf = dev_n(n_dev, n_host);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) {
+    const int4 c = fine[i];
+    const uint64_t key = sgnn_pack_key(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+    uint64_t slot = sgnn_hash64(key) & mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&ckeys[slot], SGNN_EMPTY_KEY, (unsigned long long)key);
+      if (prev == SGNN_EMPTY_KEY || prev == key) break;
+      slot = (slot + 1) & mask;
+    }
+    atomicMin(&owner[slot], (int32_t)i);  // first-touch owner = smallest fine row
+    slot_of[i] = (int32_t)slot;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chain_count(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ owner,
+                                                    const int64_t *n_dev, int64_t n_host,
+                                                    int32_t *__restrict__ block_sums) {
+  __shared__ int lds[4];
+  const int64_t n = dev_n(n_dev, n_host);
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+  int cnt = 0;
+#pragma unroll
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool f = (i < n) && owner[slot_of[i]] == (int32_t)i;
+    cnt += __popcll(__ballot(f));
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// owners, in fine-row order, become the coarse rows: coordinates and rank
+__global__ __launch_bounds__(256) void k_chain_emit(const int4 *__restrict__ fine, const int32_t *__restrict__ slot_of,
+                                                   const int32_t *__restrict__ owner, const int64_t *n_dev,
+                                                   int64_t n_host, const int32_t *__restrict__ block_offsets,
+                                                   int4 *__restrict__ coarse, int32_t *__restrict__ rank_at) {
+  __shared__ int lds[4];
+  const int64_t n = dev_n(n_dev, n_host);
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+  int running = block_offsets[blockIdx.x];
+#pragma unroll 1
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool f = (i < n) && owner[slot_of[i]] == (int32_t)i;
+    int total;
+    const int r = sgnn_block_rank256(f, lds, total);
+    if (f) {
+      const int4 c = fine[i];
+      coarse[running + r] = make_int4(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+      rank_at[i] = running + r;
+    }
+    running += total;
+  }
+}
+
+// parent row of every fine site; the coarse hash's values become coarse rows (written by the owners into cvals, a
+// different array than the owner table the other threads are still reading)
+__global__ __launch_bounds__(256) void k_chain_parent(const int64_t *n_dev, int64_t n_host,
+                                                     const int32_t *__restrict__ owner,
+                                                     const int32_t *__restrict__ rank_at,
+                                                     const int32_t *__restrict__ slot_of,
+                                                     int32_t *__restrict__ parent, int32_t *__restrict__ cvals) {
+  const int64_t nf = dev_n(n_dev, n_host);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < nf; i += stride) {
+    const int32_t sl = slot_of[i];
+    const int32_t p = rank_at[owner[sl]];
+    parent[i] = p;
+    if (rank_at[i] >= 0) cvals[sl] = p;
+  }
+}
+
+SGNN_EXPORT int64_t sgnn_down2_chain_ws_bytes(int64_t cap) {
+  const int64_t nblk = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  // slot_of[cap] + rank_at[cap] + owner[ccap] + block sums
+  return (2 * cap + sgnn_hash_capacity(cap)) * (int64_t)sizeof(int32_t) + (nblk + 1) * (int64_t)sizeof(int32_t) + 256;
+}
+
+SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_dev, int64_t cap, int depth,
+                                 void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
+                                 void *const *coarse_coords, int64_t *counts_dev, void *ws, int64_t ws_bytes,
+                                 sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(depth >= 1 && depth <= 8 && cap >= 0 && n0 >= 0 && n0 <= cap && counts_dev && ckeys && cvals && parent &&
+                 coarse_coords);
+  SGNN_CHECK_ARG(ccap >= 2 * cap && ccap >= 2 && (ccap & (ccap - 1)) == 0 && ccap < (1ll << 31));
+  if (cap == 0) {
+    SGNN_HIP_TRY(hipMemsetAsync(counts_dev, 0, depth * sizeof(int64_t), s));
+    for (int l = 0; l < depth; ++l) SGNN_HIP_TRY(hipMemsetAsync(ckeys[l], 0xFF, (size_t)ccap * sizeof(uint64_t), s));
+    return SGNN_OK;
+  }
+  SGNN_CHECK_ARG(fine_coords);
+  if (!ws || ws_bytes < sgnn_down2_chain_ws_bytes(cap)) {
+    sgnn_set_error("sgnn_down2_chain: workspace too small");
+    return SGNN_ENOWS;
+  }
+  const int64_t nblk = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  int32_t *slot_of = (int32_t *)ws;
+  int32_t *rank_at = slot_of + cap;
+  int32_t *owner = rank_at + cap;
+  int32_t *block_sums = owner + ccap;
+  const int4 *fine = (const int4 *)fine_coords;
+  const int64_t *n_dev = n0_dev;
+  int64_t n_host = n0_dev ? cap : n0;
+  const int g = sgnn_grid_for(cap, 256, 8192);
+  for (int l = 0; l < depth; ++l) {
+    SGNN_CHECK_ARG(ckeys[l] && cvals[l] && parent[l] && coarse_coords[l]);
+    hipLaunchKernelGGL(k_chain_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s,
+                       (unsigned long long *)ckeys[l], owner, ccap, rank_at, cap);
+    hipLaunchKernelGGL(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, n_host, (unsigned long long *)ckeys[l],
+                       owner, (uint64_t)(ccap - 1), slot_of);
+    hipLaunchKernelGGL(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of,
+                       (const int32_t *)owner, n_dev, n_host, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l);
+    hipLaunchKernelGGL(k_chain_emit, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of,
+                       (const int32_t *)owner, n_dev, n_host, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
+                       rank_at);
+    hipLaunchKernelGGL(k_chain_parent, dim3(g), dim3(256), 0, s, n_dev, n_host, (const int32_t *)owner,
+                       (const int32_t *)rank_at, (const int32_t *)slot_of, (int32_t *)parent[l], (int32_t *)cvals[l]);
+    fine = (const int4 *)coarse_coords[l];
+    n_dev = counts_dev + l;
+    n_host = cap;
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ fine,
                                                      const int32_t *__restrict__ parent, int64_t nf,
                                                      int32_t *__restrict__ children, int64_t ldc,

@@ -58,7 +58,7 @@ int make_layout(const View &v, Layout &L) {
   return 0;
 }
 
-int64_t ws_need(const View &v) {
+int64_t ws_main(const View &v) {
   int64_t need = 0;
   for (int i = 0; i < v.nops; ++i) {
     const int32_t *o = v.ops + 8 * i;
@@ -68,8 +68,39 @@ int64_t ws_need(const View &v) {
     if (o[0] == OP_BN) w = sgnn_bn_ws_bytes(v.lev_n[o[5]], o[6]);
     if (w > need) need = w;
   }
-  return need;
+  return (need + 255) & ~int64_t(255);
 }
+
+// statistics partials a convolution epilogue hands to the neighbouring BatchNorm: [grid blocks][2][C] doubles,
+// placed behind the main workspace (the BatchNorm kernels use the main part while they read these)
+int64_t ws_stats(const View &v) {
+  int64_t need = 0;
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + 8 * i;
+    if (o[0] != OP_CONV_SUBM && o[0] != OP_CONV_DOWN) continue;
+    const int64_t rows_f = v.lev_n[o[5]], rows_o = o[0] == OP_CONV_DOWN ? v.lev_n[o[5] + 1] : rows_f;
+    const int64_t a = sgnn_conv_grid_blocks(rows_o > 0 ? rows_o : 1) * 2 * o[7] * (int64_t)sizeof(double);  // forward: out rows x cout
+    const int64_t b = sgnn_conv_grid_blocks(rows_f > 0 ? rows_f : 1) * 2 * o[6] * (int64_t)sizeof(double);  // data gradient: in rows x cin
+    if (a > need) need = a;
+    if (b > need) need = b;
+  }
+  return (need + 255) & ~int64_t(255);
+}
+
+int64_t ws_need(const View &v) { return ws_main(v) + ws_stats(v); }
+
+// number of ops that read buffer b
+std::vector<int> count_readers(const View &v) {
+  std::vector<int> r(v.nbuf, 0);
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + 8 * i;
+    if (o[1] >= 0 && o[1] < v.nbuf) ++r[o[1]];
+    if ((o[0] == OP_ADD || o[0] == OP_JOIN) && o[2] >= 0 && o[2] < v.nbuf) ++r[o[2]];
+  }
+  return r;
+}
+
+bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
 
 // weight-gradient lane: sgnn_prog_backward can run every dW (+ its reduce) on a second stream with its own
 // workspace, concurrently with the dX / BatchNorm chain that forms the critical path (both only READ dy)
@@ -106,6 +137,12 @@ SGNN_EXPORT int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int6
   return SGNN_OK;
 }
 
+SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
+  const int prev = g_fuse ? 1 : 0;
+  g_fuse = on != 0;
+  return prev;
+}
+
 #define PROG_TRY(call)           \
   do {                           \
     const int rc_ = (call);      \
@@ -138,7 +175,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
                                   int nlev, void *const *params, int nparams, const float *input, float *arena,
-                                  int64_t arena_floats, int training, void *ws, int64_t ws_bytes,
+                                  int64_t arena_floats, const int32_t *keep, int training, void *ws, int64_t ws_bytes,
                                   sgnn_stream_t stream) {
   SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1);
   View v{ops, opf, nops, bufs, nbuf, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
@@ -156,29 +193,67 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
   // buffer 0 (the program input) may live outside the arena
   auto B = [&](int b) { return (b == 0 && input) ? const_cast<float *>(input) : arena + L.buf_off[b]; };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
+  // Epilogue fusions (same arithmetic, fewer passes and launches):
+  //  * conv -> AddTable: the convolution adds the other AddTable input while it stores (the sum buffer is written
+  //    directly, the convolution's own output buffer stays untouched) when nothing else reads the convolution output;
+  //  * conv [-> AddTable] -> BatchNorm (training): the convolution epilogue reduces the column sums the BatchNorm
+  //    statistics pass would recompute from HBM.
+  std::vector<int> readers = count_readers(v);
+  if (keep)
+    for (int b = 0; b < nbuf; ++b)
+      if (keep[b]) ++readers[b];
+  std::vector<char> skip(nops, 0);
+  std::vector<const double *> pre(nops, nullptr);
+  std::vector<int64_t> pre_nblk(nops, 0);
+  double *stats_ws = (double *)((char *)ws + ws_main(v));
   for (int i = 0; i < nops; ++i) {
     const int32_t *o = ops + 8 * i;
     const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
     SGNN_CHECK_ARG(in0 >= 0 && in0 < nbuf && out >= 0 && out < nbuf && lev >= 0 && lev < nlev);
     const int64_t n = lev_n[lev];
+    if (skip[i]) continue;
     switch (type) {
       case OP_CONV_SUBM:
-        PROG_TRY(sgnn_conv_fwd(B(in0), n, cin, P(par), 27, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out),
-                               0, 0, stream));
+      case OP_CONV_DOWN: {
+        const bool down = type == OP_CONV_DOWN;
+        SGNN_CHECK_ARG(!down || lev + 1 < nlev);
+        const int64_t n_out = down ? lev_n[lev + 1] : n;
+        const int32_t *table = (const int32_t *)(down ? lev_children[lev] : lev_nbr[lev]);
+        const int64_t ld = down ? lev_ld[lev + 1] : lev_ld[lev];
+        ConvEpi epi{};
+        float *dst = B(out);
+        int dst_buf = out;
+        if (g_fuse && sgnn_conv_epi_supported(cin, cout) && n_out > 0) {
+          int j = i + 1;
+          if (j < nops && ops[8 * j] == OP_ADD && readers[out] == 1 && (ops[8 * j + 1] == out || ops[8 * j + 2] == out) &&
+              ops[8 * j + 1] != ops[8 * j + 2]) {
+            const int other = ops[8 * j + 1] == out ? ops[8 * j + 2] : ops[8 * j + 1];
+            epi.addend = B(other);
+            dst_buf = ops[8 * j + 3];
+            dst = B(dst_buf);
+            skip[j] = 1;
+            ++j;
+          }
+          if (training && j < nops && ops[8 * j] == OP_BN && ops[8 * j + 1] == dst_buf) {
+            epi.stats = 1;
+            epi.partial = stats_ws;
+            pre[j] = stats_ws;
+            pre_nblk[j] = sgnn_conv_grid_blocks(n_out);
+          }
+        }
+        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, dst, 0, 0, nullptr,
+                                    nullptr, 1, 1, down ? 8 : 27, &epi, stream));
         break;
-      case OP_CONV_DOWN:
-        SGNN_CHECK_ARG(lev + 1 < nlev);
-        PROG_TRY(sgnn_conv_fwd(B(in0), n, cin, P(par), 8, (const int32_t *)lev_children[lev], lev_ld[lev + 1],
-                               lev_n[lev + 1], cout, B(out), 0, 0, stream));
-        break;
+      }
       case OP_UNPOOL:  // in0 lives on level lev+1, out on level lev
         SGNN_CHECK_ARG(lev + 1 < nlev);
         PROG_TRY(sgnn_gather_rows(B(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), stream));
         break;
       case OP_BN: {
         float *save = arena + L.aux_off[i];
-        PROG_TRY(sgnn_bn_fwd(B(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i], opf[4 * i + 1],
-                             training, opf[4 * i + 2], save, save + cin, B(out), ws, ws_bytes, stream));
+        PROG_TRY(sgnn_bn_fwd_impl(B(in0), cin, n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
+                                  opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), cin, pre[i],
+                                  pre_nblk[i], ws, ws_bytes, stream));
         break;
       }
       case OP_ADD:
@@ -255,7 +330,10 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     return g_side.stream;
   };
   void *dw_ws = side ? g_side.ws : ws;
-  const int64_t dw_ws_bytes = side ? g_side.ws_bytes : ws_bytes;
+  const int64_t dw_ws_bytes = side ? g_side.ws_bytes : ws_main(v);
+  std::vector<const double *> pre(nops, nullptr);
+  std::vector<int64_t> pre_nblk(nops, 0);
+  double *stats_ws = (double *)((char *)ws + ws_main(v));
 
   for (int i = nops - 1; i >= 0; --i) {
     const int32_t *o = ops + 8 * i;
@@ -272,30 +350,50 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     }
     const float *dy = GR(out);
     switch (type) {
-      case OP_CONV_SUBM: {
-        const int32_t *nbr = (const int32_t *)lev_nbr[lev];
-        const hipStream_t lane = dw_lane();
-        if (wants(in0)) {
-          float *t = target(in0, 0);
-          PROG_TRY(sgnn_conv_fwd(dy, n, cout, P(par), 27, nbr, lev_ld[lev], n, cin, t,
-                                 SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K, 0, stream));
-          PROG_TRY(commit(in0, t));
-        }
-        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 27, n, PG(par), 0, dw_ws, dw_ws_bytes,
-                                      (sgnn_stream_t)lane));
-        break;
-      }
+      case OP_CONV_SUBM:
       case OP_CONV_DOWN: {
-        const int64_t nc = lev_n[lev + 1];
+        const bool down = type == OP_CONV_DOWN;
+        const int K = down ? 8 : 27;
+        const int64_t n_dy = down ? lev_n[lev + 1] : n;      // rows of dy (= rows of the forward output)
+        const int32_t *tab_f = (const int32_t *)(down ? lev_children[lev] : lev_nbr[lev]);
+        const int64_t ld_f = down ? lev_ld[lev + 1] : lev_ld[lev];
+        const int32_t *tab_b = (const int32_t *)(down ? lev_ptable[lev] : lev_nbr[lev]);
+        const int flags_b = down ? SGNN_CONV_TRANSPOSE_W : (SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K);
         const hipStream_t lane = dw_lane();
         if (wants(in0)) {
-          float *t = target(in0, 0);
-          PROG_TRY(sgnn_conv_fwd(dy, nc, cout, P(par), 8, (const int32_t *)lev_ptable[lev], lev_ld[lev], n, cin, t,
-                                 SGNN_CONV_TRANSPOSE_W, 0, stream));
-          PROG_TRY(commit(in0, t));
+          if (g_fuse && sgnn_conv_epi_supported(cout, cin) && n > 0) {
+            // the data gradient lands in G(in0) directly: what the buffer (or its alias) already holds is added in the
+            // store (in place), and when in0 is the output of the BatchNormReLU right before this op and this is the
+            // last contribution to its gradient, the epilogue also reduces sum dz / sum dz*xhat for that BatchNorm
+            ConvEpi epi{};
+            if (init[in0] == 1) epi.addend = G(in0);
+            else if (init[in0] == 2) epi.addend = G(alias[in0]);
+            if (i > 0 && ops[8 * (i - 1)] == OP_BN && ops[8 * (i - 1) + 3] == in0 && ops[8 * (i - 1) + 6] == cin) {
+              const int32_t *bo = ops + 8 * (i - 1);
+              const float *save = arena + L.aux_off[i - 1];
+              epi.stats = 2;
+              epi.partial = stats_ws;
+              epi.bn_x = X(bo[1]);
+              epi.mean = save;
+              epi.invstd = save + cin;
+              epi.gamma = P(bo[4]);
+              epi.beta = P(bo[4] + 1);
+              epi.leak = opf[4 * (i - 1) + 2];
+              pre[i - 1] = stats_ws;
+              pre_nblk[i - 1] = sgnn_conv_grid_blocks(n);
+            }
+            PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
+                                        nullptr, 1, 1, K, &epi, stream));
+            init[in0] = 1;
+            alias[in0] = -1;
+          } else {
+            float *t = target(in0, 0);
+            PROG_TRY(sgnn_conv_fwd(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, t, flags_b, 0, stream));
+            PROG_TRY(commit(in0, t));
+          }
         }
-        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, (const int32_t *)lev_children[lev], lev_ld[lev + 1],
-                                      8, nc, PG(par), 0, dw_ws, dw_ws_bytes, (sgnn_stream_t)lane));
+        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, tab_f, ld_f, K, n_dy, PG(par), 0, dw_ws, dw_ws_bytes,
+                                      (sgnn_stream_t)lane));
         break;
       }
       case OP_UNPOOL:
@@ -311,8 +409,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         // the kernel adds what the buffer already holds (in place) or the aliased gradient: no scratch pass, no k_add
         const float *addend = !wants(in0) ? nullptr : (init[in0] == 1 ? G(in0) : (init[in0] == 2 ? G(alias[in0]) : nullptr));
         float *t = wants(in0) ? G(in0) : scratch[0];
-        PROG_TRY(sgnn_bn_bwd_add(X(in0), dy, n, cin, P(par), P(par + 1), save, save + cin, training, opf[4 * i + 2],
-                                 addend, t, PG(par), PG(par + 1), ws, ws_bytes, stream));
+        PROG_TRY(sgnn_bn_bwd_impl(X(in0), cin, dy, cin, n, cin, P(par), P(par + 1), save, save + cin, training,
+                                  opf[4 * i + 2], addend, cin, t, cin, PG(par), PG(par + 1), pre[i], pre_nblk[i], ws, ws_bytes,
+                                  stream));
         if (wants(in0)) {
           init[in0] = 1;
           alias[in0] = -1;

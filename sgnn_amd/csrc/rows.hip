@@ -62,6 +62,33 @@ SGNN_EXPORT int sgnn_gather_rows(const float *src, int c, const int32_t *idx, in
   return SGNN_OK;
 }
 
+// the same with the row count taken from device memory (launched for the host-known bound m_cap): lets a mask
+// compaction's coordinates feed the next level's rulebook builders before the host has read the count
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows_dn(const float *__restrict__ src, int cq,
+                                                       const int32_t *__restrict__ idx, const int64_t *m_dev,
+                                                       float *__restrict__ dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = *m_dev * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    const int32_t i = idx[r];
+    reinterpret_cast<T *>(dst)[g] = (i >= 0) ? reinterpret_cast<const T *>(src)[(int64_t)i * cq + col] : vzero<VEC>();
+  }
+}
+
+SGNN_EXPORT int sgnn_gather_rows_dn(const float *src, int c, const int32_t *idx, const int64_t *m_dev, int64_t m_cap,
+                                    float *dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && m_cap >= 0 && m_dev);
+  if (m_cap == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && idx && dst);
+  const int cq = c / row_vec(c);
+  ROWS_LAUNCH(k_gather_rows_dn, c, m_cap * cq, stream, src, cq, idx, m_dev, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 // dst[idx[r]] = src[r]
 template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter_rows(const float *__restrict__ src, int cq,

@@ -98,6 +98,7 @@ class TSDFEncoder(nn.Module):
         if prog is not None:
             # the three sparse encoder levels (p1, p2, p3 each) as one native program; taps = the p2 outputs
             x0 = self.process_sparse[0].p0(x)
+            x0.metadata.prebuild(x0.key, n_layers)      # all stride-2 levels, one host read-back
             taps = [prog.taps[id(l.p2)][0] for l in self.process_sparse]
             outs, grids, _ = P_.run_program(prog, x0, self.training, taps + [prog.out])
             keys = [x0.key]
@@ -255,6 +256,7 @@ class Refinement(nn.Module):
         self.linear = nn.Linear(nf, 1)
         self.linearsdf = nn.Linear(nf, 1)
         self.fused_expand = True   # False: materialise the 8x replicated features like the reference does
+        self.plan_depth = 2        # stride-2 levels of the NEXT stage's U-Net (FullyConvolutionalNet nPlanes of 3)
 
     def forward(self, x):
         coords = x[0]
@@ -281,8 +283,8 @@ class Refinement(nn.Module):
         out = F_.RowLinear.apply(y, torch.cat([self.linear.weight, self.linearsdf.weight], 0),
                                  torch.cat([self.linear.bias, self.linearsdf.bias], 0))
         n_all = out.shape[0]
-        sel, cnt = F_.compact_sigmoid(out.detach(), 2, n_all)          # stable, == torch boolean indexing order
-        locs = F_.gather_coords(coords_next, sel, cnt)
+        # stable, == torch boolean indexing order; the next stage's U-Net pyramid is built in the same submission
+        sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, n_all, coords_next, self.plan_depth)
         if self.pass_feats and self.pass_occ:
             feats = F_.ConcatRows.apply(y, sel, out, sel, cnt)          # [feats | occ,sdf] (model.py:242)
         elif self.pass_feats:
@@ -347,12 +349,11 @@ class GenModel(nn.Module):
         self.surfacepred = SurfacePrediction(c, nf, 1, self.refine_sizes[-1])
 
     # -- generative glue ---------------------------------------------------------------------------------
-    def dense_coarse_to_sparse(self, feat_rows, occ_rows, geo, truncation=3):
+    def dense_coarse_to_sparse(self, feat_rows, occ_rows, geo, truncation=3, plan_depth=0):
         """model.py:315-336: every coarse voxel is a candidate; keep sigmoid(occ) > 0.5 in raster order.
         feat_rows / occ_rows are the dense volume as rows (what the reference builds with permute+view)."""
         n_all = occ_rows.shape[0]
-        sel, cnt = F_.compact_sigmoid(occ_rows.detach(), 2, n_all)
-        locs = F_.gather_coords(geo.coords, sel, cnt)
+        sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, plan_depth)
         if self.pass_occ and self.pass_feats:
             feats = F_.ConcatRows.apply(occ_rows, sel, feat_rows, sel, cnt)  # [occ,sdf | feats] (model.py:330)
         elif self.pass_occ:
@@ -392,10 +393,15 @@ class GenModel(nn.Module):
         feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
         if self.use_skip_sparse:
             skips = [(t.grid(), t.features) for t in skips]
-        locs, feats, out0 = self.dense_coarse_to_sparse(feat_rows, occ_rows, geo, truncation=3)
+        R = len(self.refinement)
+        # which later stage consumes a compaction's sites (its U-Net needs a 2-level stride-2 pyramid)?
+        runs = [loss_weights[h + 1] > 0 for h in range(R)] + [bool(self.PRED_SURF and loss_weights[-1] > 0)]
+        for h in range(R):
+            self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
+        locs, feats, out0 = self.dense_coarse_to_sparse(feat_rows, occ_rows, geo, truncation=3,
+                                                        plan_depth=2 if runs[0] else 0)
         outputs.append(out0)
         xs = [locs, feats]
-        R = len(self.refinement)
         for h in range(R):
             if loss_weights[h + 1] > 0:
                 if self.use_skip_sparse:

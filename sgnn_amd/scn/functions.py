@@ -448,6 +448,31 @@ def compact_sigmoid(logits, stride, n):
     return sel[:count], count
 
 
+def compact_sigmoid_plan(logits, stride, n, coords_all, depth):
+    """compact_sigmoid + the kept rows' coordinates + the stride-2 pyramid (`depth` levels) below them, with ONE host
+    read-back for all row counts: the coordinate gather and the pyramid kernels read the kept-row count from device
+    memory (sgnn_gather_rows_dn, sgnn_down2_chain).  Returns (sel[:count], count, locs (count,4) int32); when a
+    pyramid was built, `locs` carries it (`_sgnn_plan`) and the next InputLayer adopts it instead of rebuilding."""
+    from . import metadata as MD
+    if not MD.CHAIN or depth < 1 or n == 0:
+        sel, cnt = compact_sigmoid(logits, stride, n)
+        return sel, cnt, gather_coords(coords_all, sel, cnt)
+    rt = runtime(logits.device)
+    sel = torch.empty(n, dtype=torch.int32, device=logits.device)
+    wsb = _lib.query('sgnn_compact_ws_bytes', n)
+    ws = rt.workspace(wsb)
+    _lib.call('sgnn_compact_sigmoid', ptr(logits), stride, n, ptr(sel), ptr(rt.state), ptr(ws), wsb)
+    locs_cap = torch.empty(n, 4, dtype=torch.int32, device=logits.device)
+    _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(rt.state), n, ptr(locs_cap))
+    chain = MD.PendingChain(locs_cap, 0, True, depth)
+    host = rt.read_counts()
+    count = int(host[0])
+    locs = locs_cap[:count]
+    if count:
+        locs._sgnn_plan = chain.finalize(count, host)
+    return sel[:count], count, locs
+
+
 def compact_mask(mask_u8, n):
     rt = runtime(mask_u8.device)
     sel = torch.empty(max(n, 1), dtype=torch.int32, device=mask_u8.device)

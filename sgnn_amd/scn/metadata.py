@@ -5,6 +5,7 @@ Counterpart of upstream's `Metadata_3` object that the reference reaches through
 shares.  All hashing / rulebook arithmetic happens in libsgnn_hip.so; this module only owns the
 torch tensors that back the tables and caches them per (spatial size, filter) like upstream does.
 """
+import numpy as np
 import torch
 
 from .. import _lib
@@ -20,8 +21,11 @@ class _Runtime(object):
     def __init__(self, device):
         self.device = device
         self.ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
-        self.state = torch.zeros(4, dtype=torch.int64, device=device)
+        # [0] count of the last compaction / stride-2 build, [1] status word, [2:] row counts of a pre-issued
+        # stride-2 chain (sgnn_down2_chain): one D2H copy returns all of them
+        self.state = torch.zeros(8, dtype=torch.int64, device=device)
         self.status32 = self.state[1:2].view(torch.int32)  # two int32 words, first one used
+        self.syncs = 0                                     # host read-backs so far (bench / tests)
 
     def workspace(self, nbytes):
         if self.ws.numel() < nbytes:
@@ -49,8 +53,13 @@ class _Runtime(object):
 
     def read_count(self):
         """One D2H copy: returns the count word and raises on pending input errors."""
-        host = self.state.cpu()
-        status = int(host[1].item()) & 0xFFFFFFFF
+        return self.read_counts()[0]
+
+    def read_counts(self):
+        """One D2H copy of the whole state block: [count, status, chain counts...] as Python ints."""
+        self.syncs += 1
+        host = self.state.cpu().tolist()
+        status = int(host[1]) & 0xFFFFFFFF
         if status:
             self.state[1] = 0
             msgs = []
@@ -59,7 +68,7 @@ class _Runtime(object):
             if status & 2:
                 msgs.append('InputLayer(mode=0): duplicate coordinates are a caller error')
             raise _lib.SgnnError('; '.join(msgs))
-        return int(host[0].item())
+        return host
 
 
 _runtimes = {}
@@ -156,6 +165,58 @@ def build_down2(fine):
     return Down2(fine, coarse, parent[:nf], children, ldc, ptable, ldf)
 
 
+CHAIN = True    # False: one stride-2 build + one host read-back per level (the round-1 behaviour)
+MAX_CHAIN = 6   # state words available for chain counts
+
+
+class PendingChain(object):
+    """Stride-2 pyramid below a level, issued before the host knows any row count (sgnn_down2_chain).
+    `finalize(n0, counts)` turns it into Grid / Down2 objects once the single read-back has happened."""
+
+    def __init__(self, coords_cap, n0, n0_on_device, depth):
+        dev = coords_cap.device
+        rt = runtime(dev)
+        cap = int(coords_cap.shape[0])
+        depth = min(depth, MAX_CHAIN)
+        self.coords_cap, self.cap, self.depth = coords_cap, cap, depth
+        self.ccap = _lib.query('sgnn_hash_capacity', cap)
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.ckeys = [mk(self.ccap, torch.int64) for _ in range(depth)]
+        self.cvals = [mk(self.ccap, torch.int32) for _ in range(depth)]
+        self.parent = [mk(max(cap, 1), torch.int32) for _ in range(depth)]
+        self.ccoords = [mk((max(cap, 1), 4), torch.int32) for _ in range(depth)]
+        wsb = _lib.query('sgnn_down2_chain_ws_bytes', cap)
+        ws = rt.workspace(wsb)
+        arr = lambda ts: np.ascontiguousarray(np.array([t.data_ptr() for t in ts], dtype=np.uint64))
+        self._keep = [arr(self.ckeys), arr(self.cvals), arr(self.parent), arr(self.ccoords)]
+        _lib.call('sgnn_down2_chain', ptr(coords_cap), 0 if n0_on_device else int(n0),
+                  rt.state.data_ptr() if n0_on_device else None, cap, depth, self._keep[0].ctypes.data,
+                  self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data, self._keep[3].ctypes.data,
+                  rt.state.data_ptr() + 16, ptr(ws), wsb)
+
+    def finalize(self, n0, host_state):
+        """-> (grid of level 0, [Down2 level l -> l+1])."""
+        counts = [int(v) for v in host_state[2:2 + self.depth]]
+        fine = Grid(self.coords_cap[:n0])
+        grid0, downs = fine, []
+        for l in range(self.depth):
+            nc = counts[l]
+            coarse = Grid(self.ccoords[l][:nc], self.ckeys[l], self.cvals[l], self.ccap)
+            downs.append(_down2_tables(fine, coarse, self.parent[l]))
+            fine = coarse
+        return grid0, downs
+
+
+def _down2_tables(fine, coarse, parent):
+    dev = fine.device
+    nf, nc = fine.n, coarse.n
+    ldc, ldf = coarse.ld, fine.ld
+    children = torch.empty(8 * ldc, dtype=torch.int32, device=dev)
+    ptable = torch.empty(8 * ldf, dtype=torch.int32, device=dev)  # rows >= nf are never read
+    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf)
+    return Down2(fine, coarse, parent[:nf], children, ldc, ptable, ldf)
+
+
 class Metadata(object):
     def __init__(self, dimension=3):
         self.dimension = dimension
@@ -168,6 +229,40 @@ class Metadata(object):
 
     def set_input(self, spatial_size, grid):
         self.grids[self.key(spatial_size)] = grid
+
+    def adopt(self, spatial_size, grid0, downs):
+        """Register a finalized PendingChain: level 0 at `spatial_size`, level l at spatial_size / 2^l."""
+        key = self.key(spatial_size)
+        self.grids[key] = grid0
+        for d in downs:
+            nxt = tuple(v // 2 for v in key)
+            self.down[(key, nxt)] = d
+            self.grids[nxt] = d.coarse
+            key = nxt
+
+    def prebuild(self, spatial_size, depth):
+        """Build the stride-2 pyramid (`depth` levels below `spatial_size`) with ONE host read-back instead of one
+        per level.  The level-0 grid must be registered already; levels already built are kept."""
+        key = self.key(spatial_size)
+        k, todo = key, 0
+        for _ in range(depth):
+            if any(v % 2 for v in k):
+                break
+            nxt = tuple(v // 2 for v in k)
+            if (k, nxt) not in self.down:
+                todo += 1
+            k = nxt
+        g0 = self.grids[key]
+        if not CHAIN or todo < 2 or g0.n == 0 or len(self.down):
+            return
+        chain = PendingChain(g0.coords, g0.n, False, todo)
+        host = runtime(g0.device).read_counts()
+        _, downs = chain.finalize(g0.n, host)
+        fine = g0
+        for d in downs:            # level 0 keeps its Grid object (hash / rulebook caches)
+            d.fine = fine
+            fine = d.coarse
+        self.adopt(key, g0, downs)
 
     def grid(self, spatial_size):
         return self.grids[self.key(spatial_size)]

@@ -115,8 +115,13 @@ class InputLayer(nn.Module):
         coords = coords_from_locs(locs, feats.device)
         md = Metadata(self.dimension)
         key = tuple(int(v) for v in self.spatial_size)
-        g = Grid(coords)
-        md.grids[key] = g
+        plan = getattr(coords, '_sgnn_plan', None)   # stride-2 pyramid pre-built with the compaction that made coords
+        if plan is not None and plan[0].n == coords.shape[0]:
+            g = plan[0]
+            md.adopt(key, g, plan[1])
+        else:
+            g = Grid(coords)
+            md.grids[key] = g
         return SparseConvNetTensor(feats, md, key, g)
 
 

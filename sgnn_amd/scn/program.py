@@ -183,10 +183,12 @@ class _ProgramFn(Function):
         run.total, run.wsb = total, wsb
         arena = torch.empty(total, dtype=torch.float32, device=x.device)
         ws = rt.workspace(wsb)
+        keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away
+        keep[run.out_bufs] = 1
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                   run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, n_lev, run.pptr.ctypes.data, len(params),
-                  x.data_ptr(), arena.data_ptr(), total, int(run.training), ws.data_ptr(), wsb)
+                  x.data_ptr(), arena.data_ptr(), total, keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
         run.offsets = {}
         outs = []
         for b in run.out_bufs:

@@ -47,7 +47,13 @@ def bind_to_device_numa(device=None):
 
 
 class FlatGradAllReduce(object):
-    """Averages gradients across ranks with a single collective on one flat buffer."""
+    """Averages gradients across ranks with a single collective on one flat buffer.
+
+    The buffer carries one extra float per parameter tensor: 1 where this rank produced a gradient.  A parameter no
+    rank reached this step (a generative level whose loss weight is still 0, train.py:203-231) keeps ``grad = None``
+    on every rank, so Adam skips it exactly as the single-process run does (no step-counter advance, no weight
+    decay).  A parameter only SOME ranks reached (rank-local empty level) receives sum / world_size — the mean over
+    all replicas, the missing ones contributing zero — on every rank."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -58,19 +64,34 @@ class FlatGradAllReduce(object):
     def __call__(self):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
-        # a parameter unreached this step (empty generative level) contributes zeros and still receives the mean
-        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
-                 for p in self.params]
-        self.flat = torch.cat(grads)                      # one gather kernel instead of one copy per tensor
+        ps = self.params
+        dev, dt = ps[0].device, ps[0].dtype
+        have_local = [p.grad is not None for p in ps]
+        zeros = None
+        if not all(have_local):
+            zeros = torch.zeros(max(p.numel() for p, h in zip(ps, have_local) if not h), dtype=dt, device=dev)
+        flags = torch.tensor([1.0 if h else 0.0 for h in have_local], dtype=dt).to(dev, non_blocking=True)
+        grads = [p.grad.reshape(-1) if h else zeros[:p.numel()] for p, h in zip(ps, have_local)]
+        self.flat = torch.cat(grads + [flags])           # one gather kernel instead of one copy per tensor
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(dist.get_world_size(self.group))
-        pieces = self.flat.split([p.numel() for p in self.params])
-        have = [(p.grad, v.view_as(p)) for p, v in zip(self.params, pieces) if p.grad is not None]
-        if have:
-            torch._foreach_copy_([a for a, _ in have], [b for _, b in have])
-        for p, v in zip(self.params, pieces):
-            if p.grad is None:
+        world = dist.get_world_size(self.group)
+        if all(have_local):
+            have_any = have_local                          # every rank sees >= 1 contributor: no read-back needed
+        else:
+            have_any = (self.flat[self.numel:] > 0).tolist()   # one small D2H, only on steps with a local gap
+        self.flat[:self.numel].div_(world)
+        pieces = self.flat[:self.numel].split([p.numel() for p in ps])
+        dst, src = [], []
+        for p, v, hl, ha in zip(ps, pieces, have_local, have_any):
+            if not ha:
+                p.grad = None
+            elif hl:
+                dst.append(p.grad)
+                src.append(v.view_as(p))
+            else:
                 p.grad = v.view_as(p).clone()
+        if dst:
+            torch._foreach_copy_(dst, src)
 
 
 class FastAdam(torch.optim.Adam):
@@ -101,15 +122,25 @@ class FastAdam(torch.optim.Adam):
             steps.append(st['step'])
         return ps, avgs, sqs, steps
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._fast = None                 # the cached moment / step tensors were replaced
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._fast = None
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        if any(g['amsgrad'] or g['maximize'] or g.get('capturable') or g.get('differentiable')
+               for g in self.param_groups):
+            return super().step()         # decided before any group was touched: no double step
         for gi, group in enumerate(self.param_groups):
-            if group['amsgrad'] or group['maximize'] or group.get('capturable') or group.get('differentiable'):
-                return super().step()
             n_with_grad = sum(p.grad is not None for p in group['params'])
             cache = self._fast.get(gi) if self._fast else None
-            if cache is None or cache[0] != n_with_grad or any(p.grad is None for p in cache[1][0]):
+            if cache is None or cache[0] != n_with_grad or any(p.grad is None for p in cache[1][0]) or \
+                    any(self.state[p].get('exp_avg') is not a for p, a in zip(cache[1][0][:1], cache[1][1][:1])):
                 cache = (n_with_grad, self._lists(group))      # first step, or a level (dis)appeared
                 self._fast = dict(self._fast or {})
                 self._fast[gi] = cache

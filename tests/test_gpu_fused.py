@@ -1,0 +1,145 @@
+"""Fused convolution epilogues and strided rows (sgnn_conv_fwd_epi, sgnn_bn_fwd_ex / sgnn_bn_bwd_ex) against the
+unfused kernels (themselves held to the oracle in test_gpu_ops.py): residual add in the store, BatchNorm statistics
+out of the accumulator tile, rows that live in a column range of a wider buffer — serves the AddTable / BatchNormReLU /
+JoinTable around every convolution of torch/model.py:33-42 and the FullyConvolutionalNet blocks (:180, :255)."""
+import numpy as np
+import pytest
+import torch
+
+from util import random_sites
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(batch, dim, seed):
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    locs = random_sites(batch, dim, 0.1, seed, surface=True)
+    g = Grid(coords_from_locs(locs, torch.device('cuda')))
+    return g, g.subm_table()
+
+
+def _view(n, c, ld, col0, gen):
+    """(contiguous copy, wide buffer, pointer of the view) of random rows living in columns [col0, col0+c) of ld."""
+    wide = torch.randn(n, ld, device='cuda', generator=gen)
+    return wide[:, col0:col0 + c].contiguous(), wide, wide.data_ptr() + 4 * col0
+
+
+@pytest.mark.parametrize('batch,dim', [(2, 24), (5, 64)])   # 64-row workgroups / 256-row workgroups (>= 41 k rows)
+@pytest.mark.parametrize('cin,cout', [(16, 16), (8, 12), (34, 16)])
+def test_conv_epilogue_add_stats_strided(batch, dim, cin, cout):
+    from sgnn_amd import _lib
+    from sgnn_amd.scn import functions as F_
+    g, tab = _grid(batch, dim, 7)
+    n = g.n
+    gen = torch.Generator(device='cuda').manual_seed(cin * 10 + cout)
+    xc, xw, xp = _view(n, cin, cin + 8, 4, gen)
+    ac, aw, ap = _view(n, cout, cout + 4, 4, gen)
+    w = torch.randn(27, cin, cout, device='cuda', generator=gen) * 0.2
+    ywide = torch.full((n, cout + 24), 7.0, device='cuda')
+    nblk = _lib.query('sgnn_conv_stats_blocks', n)
+    assert nblk == (-(-n // 64) if -(-n // 256) < 160 else -(-n // 256))
+    part = torch.zeros(nblk, 2, cout, dtype=torch.float64, device='cuda')
+    _lib.call('sgnn_conv_fwd_epi', xp, n, cin, cin + 8, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, cout,
+              ywide.data_ptr() + 4 * 8, cout + 24, 0, ap, cout + 4, 1, part.data_ptr(), None, 0, None, None, None, None, 0.0)
+    want = F_.conv_fwd_raw(xc, cin, w, 27, tab, g.ld, n, cout) + ac
+    got = ywide[:, 8:8 + cout]
+    assert torch.equal(got, want)                                  # same accumulation order, same fp32 add
+    assert (ywide[:, :8] == 7).all() and (ywide[:, 8 + cout:] == 7).all()   # neighbours of the column range untouched
+    s = part.sum(0)
+    w64 = want.double()
+    assert torch.allclose(s[0], w64.sum(0), rtol=1e-6, atol=1e-6 * float(w64.abs().sum(0).max()))
+    assert torch.allclose(s[1], (w64 * w64).sum(0), rtol=1e-6)
+    # in-place accumulation: addend == y
+    acc = ac.clone()
+    _lib.call('sgnn_conv_fwd_epi', xp, n, cin, cin + 8, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, cout,
+              acc.data_ptr(), 0, 0, acc.data_ptr(), 0, 0, None, None, 0, None, None, None, None, 0.0)
+    assert torch.equal(acc, want)
+    # BatchNorm on those partials == BatchNorm with its own statistics pass (1e-6: summation order only)
+    from sgnn_amd.scn.metadata import runtime
+    rt = runtime(torch.device('cuda'))
+    wsb = _lib.query('sgnn_bn_ws_bytes', n, cout)
+    ws = rt.workspace(wsb)
+    gamma = torch.rand(cout, device='cuda', generator=gen) + 0.5
+    beta = torch.randn(cout, device='cuda', generator=gen) * 0.1
+    outs = []
+    for pre in (True, False):
+        rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+        save = torch.empty(2, cout, device='cuda')
+        y = torch.empty(n, cout + 2, device='cuda')
+        _lib.call('sgnn_bn_fwd_ex', ywide.data_ptr() + 4 * 8, cout + 24, n, cout, gamma.data_ptr(), beta.data_ptr(),
+                  rm.data_ptr(), rv.data_ptr(), 1e-4, 0.9, 1, 0.0, save[0].data_ptr(), save[1].data_ptr(), y.data_ptr(),
+                  cout + 2, part.data_ptr() if pre else None, nblk if pre else 0, ws.data_ptr(), wsb)
+        outs.append((y[:, :cout].clone(), rm, rv, save))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    # and equals the contiguous entry point
+    rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    save = torch.empty(2, cout, device='cuda')
+    y = torch.empty(n, cout, device='cuda')
+    _lib.call('sgnn_bn_fwd', want.data_ptr(), n, cout, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+              1e-4, 0.9, 1, 0.0, save[0].data_ptr(), save[1].data_ptr(), y.data_ptr(), ws.data_ptr(), wsb)
+    assert torch.allclose(y, outs[1][0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('batch,dim', [(2, 24), (5, 64)])
+@pytest.mark.parametrize('c', [16, 12])
+def test_data_gradient_epilogue_feeds_batchnorm_backward(batch, dim, c):
+    """dX convolution with stats = 2 + sgnn_bn_bwd_ex(pre_partial) == dX convolution, then sgnn_bn_bwd."""
+    from sgnn_amd import _lib
+    from sgnn_amd.scn import functions as F_
+    from sgnn_amd.scn.metadata import runtime
+    g, tab = _grid(batch, dim, 11)
+    n, cout = g.n, 16
+    gen = torch.Generator(device='cuda').manual_seed(c)
+    dy_conv = torch.randn(n, cout, device='cuda', generator=gen)         # gradient of the convolution output
+    w = torch.randn(27, c, cout, device='cuda', generator=gen) * 0.2     # layer weight (K, cin = c, cout)
+    bn_x = torch.randn(n, c, device='cuda', generator=gen) * 2 + 0.3     # BatchNorm input
+    gamma = torch.rand(c, device='cuda', generator=gen) + 0.5
+    beta = torch.randn(c, device='cuda', generator=gen) * 0.3
+    prior = torch.randn(n, c, device='cuda', generator=gen)              # gradient the BN output already carries
+    rt = runtime(torch.device('cuda'))
+    wsb = _lib.query('sgnn_bn_ws_bytes', n, c)
+    ws = rt.workspace(wsb)
+    rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    save = torch.empty(2, c, device='cuda')
+    bn_y = torch.empty(n, c, device='cuda')
+    _lib.call('sgnn_bn_fwd', bn_x.data_ptr(), n, c, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1e-4,
+              0.9, 1, 0.0, save[0].data_ptr(), save[1].data_ptr(), bn_y.data_ptr(), ws.data_ptr(), wsb)
+    flags = F_.CONV_TRANSPOSE_W | F_.CONV_FLIP_K
+    # unfused
+    d_bn_out = F_.conv_fwd_raw(dy_conv, cout, w, 27, tab, g.ld, n, c, flags) + prior
+    dx0, dgb0 = torch.empty(n, c, device='cuda'), torch.empty(2, c, device='cuda')
+    _lib.call('sgnn_bn_bwd', bn_x.data_ptr(), d_bn_out.data_ptr(), n, c, gamma.data_ptr(), beta.data_ptr(),
+              save[0].data_ptr(), save[1].data_ptr(), 1, 0.0, dx0.data_ptr(), dgb0[0].data_ptr(), dgb0[1].data_ptr(),
+              ws.data_ptr(), wsb)
+    # fused: in-place accumulation onto `prior` + statistics in the epilogue
+    nblk = _lib.query('sgnn_conv_stats_blocks', n)
+    part = torch.zeros(nblk, 2, c, dtype=torch.float64, device='cuda')
+    gbuf = prior.clone()
+    _lib.call('sgnn_conv_fwd_epi', dy_conv.data_ptr(), n, cout, 0, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, c,
+              gbuf.data_ptr(), 0, flags, gbuf.data_ptr(), 0, 2, part.data_ptr(), bn_x.data_ptr(), 0, save[0].data_ptr(),
+              save[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0.0)
+    assert torch.equal(gbuf, d_bn_out)
+    dz = torch.where(bn_y > 0, d_bn_out, torch.zeros_like(d_bn_out)).double()
+    xh = ((bn_x - save[0]) * save[1]).double()
+    s = part.sum(0)
+    assert torch.allclose(s[0], dz.sum(0), rtol=1e-5, atol=1e-6 * float(dz.abs().sum(0).max()))
+    assert torch.allclose(s[1], (dz * xh).sum(0), rtol=1e-5, atol=1e-6 * float((dz * xh).abs().sum(0).max()))
+    dx1, dgb1 = torch.empty(n, c, device='cuda'), torch.empty(2, c, device='cuda')
+    _lib.call('sgnn_bn_bwd_ex', bn_x.data_ptr(), 0, gbuf.data_ptr(), 0, n, c, gamma.data_ptr(), beta.data_ptr(),
+              save[0].data_ptr(), save[1].data_ptr(), 1, 0.0, None, 0, dx1.data_ptr(), 0, dgb1[0].data_ptr(),
+              dgb1[1].data_ptr(), part.data_ptr(), nblk, ws.data_ptr(), wsb)
+    scale = max(1.0, float(dx0.abs().max()))
+    assert (dx1 - dx0).abs().max().item() <= 1e-5 * scale
+    assert torch.allclose(dgb1, dgb0, rtol=1e-5, atol=1e-5 * float(dgb0.abs().max()))
+
+
+def test_epilogue_rejects_uncompiled_shapes():
+    from sgnn_amd import _lib
+    g, tab = _grid(1, 16, 3)
+    x = torch.randn(g.n, 5, device='cuda')
+    w = torch.randn(27, 5, 7, device='cuda')
+    y = torch.empty(g.n, 7, device='cuda')
+    with pytest.raises(_lib.SgnnError, match='compiled'):
+        _lib.call('sgnn_conv_fwd_epi', x.data_ptr(), g.n, 5, 0, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, 7,
+                  y.data_ptr(), 0, 0, y.data_ptr(), 0, 0, None, None, 0, None, None, None, None, 0.0)

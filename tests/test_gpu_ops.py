@@ -195,37 +195,3 @@ def test_empty_input_is_legal():
     assert y.features.shape == (0, 16)
     z = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(y)
     assert z.features.shape == (0, 16)
-
-
-@pytest.mark.parametrize('cin,cout', [(16, 16)])
-def test_x_reuse_conv_kernel_equals_plain_kernel_on_a_large_level(cin, cout):
-    """Levels with >= 768 row tiles run k_conv_fwd_dxr (lane rotates instead of repeated gathers along x).  It must
-    agree with the plain kernel (itself checked against the oracle above) for the forward and the flipped /
-    transposed data-gradient walk, on raster-ordered surface sites and on a shuffled site order."""
-    from sgnn_amd import synth, _lib
-    from sgnn_amd.scn import functions as F_
-    from sgnn_amd.scn.metadata import Grid, coords_from_locs
-    lib = _lib.load()
-    data = synth.make_batch(18, (64, 64, 64), cfg=3)
-    locs = data['input'][0]
-    for order in ('raster', 'shuffled'):
-        if order == 'shuffled':
-            locs = locs[torch.randperm(locs.shape[0], generator=torch.Generator().manual_seed(0))]
-        g = Grid(coords_from_locs(locs, torch.device('cuda')))
-        assert g.n >= 768 * 256
-        tab = g.subm_table()
-        torch.manual_seed(1)
-        x = torch.randn(g.n, cin, device='cuda')
-        w = torch.randn(27, cin, cout, device='cuda') * 0.2
-        dy = torch.randn(g.n, cout, device='cuda')
-        outs = []
-        for on in (1, 0):
-            prev = lib.sgnn_conv_set_dxr(on)
-            try:
-                y = F_.conv_fwd_raw(x, cin, w, 27, tab, g.ld, g.n, cout, 0, 0)
-                dx = F_.conv_fwd_raw(dy, cout, w, 27, tab, g.ld, g.n, cin, F_.CONV_TRANSPOSE_W | F_.CONV_FLIP_K, 0)
-            finally:
-                lib.sgnn_conv_set_dxr(prev)
-            outs.append((y, dx))
-        for a, b in zip(outs[0], outs[1]):
-            assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item()), order

@@ -1,6 +1,10 @@
-"""The native program executor (sgnn_prog_forward/backward) must reproduce the per-layer path: same kernels in the
-same order, so logits, site lists and every parameter gradient agree to fp32 round-off (bit-identical except
-for the order of two-term gradient sums)."""
+"""The native program executor (sgnn_prog_forward/backward) must reproduce the per-layer path.  With the epilogue
+fusions off it launches the same kernels in the same order (logits agree to 1e-6, bit-identical except for the
+order of two-term gradient sums); with the fusions on (default) the only arithmetic difference is the summation
+order of the BatchNorm statistics (fp64 over convolution tiles instead of fp32 row pairs flushed into fp64), which
+moves mean / invstd by an ulp in some channels; ~60 stacked conv/BN layers amplify that to ~5e-6 of the logit scale
+(measured, scripts/diag_fuse.py; two fused runs are bit-identical): site lists stay identical, logits are held to
+3e-5 of the logit scale — the oracle comparison in test_gpu_model.py is the accuracy test."""
 import numpy as np
 import pytest
 import torch
@@ -36,10 +40,16 @@ def _run(enabled, train=True):
         P.ENABLED = True
 
 
-@pytest.mark.parametrize('train', [True, False])
-def test_program_path_equals_layer_path(train):
-    ma, sa, oa, la = _run(True, train)
+@pytest.mark.parametrize('train,fused', [(True, True), (True, False), (False, True)])
+def test_program_path_equals_layer_path(train, fused):
+    from sgnn_amd import _lib
+    prev = _lib.load().sgnn_prog_set_fusion(int(fused))
+    try:
+        ma, sa, oa, la = _run(True, train)
+    finally:
+        _lib.load().sgnn_prog_set_fusion(prev)
     mb, sb, ob, lb = _run(False, train)
+    tol = 3e-5 if (fused and train) else 1e-6
     assert ma.encoder._sparse_program() is not None
     if train:
         assert ma.refinement[0]._prog is not None and ma.surfacepred._prog is not None
@@ -48,18 +58,18 @@ def test_program_path_equals_layer_path(train):
             assert len(a[0]) == 0 and len(b[0]) == 0
             return
         assert torch.equal(a[0], b[0])
-        assert (a[1] - b[1]).abs().max().item() <= 1e-6
+        assert (a[1] - b[1]).abs().max().item() <= tol * max(1.0, b[1].abs().max().item())
 
     for h in range(4):
         same(oa[h], ob[h])
     same(sa, sb)
     if train:
-        assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+        assert abs(la - lb) <= tol * max(1.0, abs(lb))
         pb = dict(mb.named_parameters())
         for n, p in ma.named_parameters():
             assert p.grad is not None and pb[n].grad is not None, n
             scale = max(1.0, pb[n].grad.abs().max().item())
-            assert (p.grad - pb[n].grad).abs().max().item() <= 1e-5 * scale, n
+            assert (p.grad - pb[n].grad).abs().max().item() <= 10 * tol * scale, n
         bb = dict(mb.named_buffers())
         for n, b in ma.named_buffers():
             assert torch.allclose(b.float(), bb[n].float(), atol=1e-6), n

@@ -185,6 +185,11 @@ int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy,
                          const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
                          int64_t ws_bytes, sgnn_stream_t stream);
 
+/* pre-summed weights of the generative up-sampling convolution and their gradient: Wc (64, cin, cout) from the layer's
+ * W (27, cin, cout); dW from dWc (see sgnn_conv_fwd_ex) */
+int sgnn_expand_weights(const float *w, int cin, int cout, float *wc, sgnn_stream_t stream);
+int sgnn_expand_weights_bwd(const float *dwc, int cin, int cout, float *dw, sgnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * scn.BatchNormReLU / BatchNormalization (torch/model.py:37,39,42,45,181,187,256)
  * leak: 0 = ReLU, 1 = plain batch norm.  momentum = fraction of OLD running value kept.
@@ -227,6 +232,13 @@ int sgnn_gather_rows(const float *src, int c, const int32_t *idx, int64_t m, flo
  * compaction and the consumers of the compacted coordinates */
 int sgnn_gather_rows_dn(const float *src, int c, const int32_t *idx, const int64_t *m_dev, int64_t m_cap,
                         float *dst, sgnn_stream_t stream);
+/* dst[r] = [ a[ia?ia[r]:r] | b[ib?ib[r]:r] | c[ic?ic[r]:r] ]  (negative index -> zeros, zero-channel sources skipped) and
+ * its gradient (indices unique; destinations reached through an index array are zero-filled first, NULL ones skipped) */
+int sgnn_concat3_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
+                      const float *c, int cc, const int32_t *ic, int64_t m, float *dst, sgnn_stream_t stream);
+int sgnn_concat3_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int cc,
+                          const int32_t *ic, int64_t m, float *da, int64_t na, float *db, int64_t nb, float *dc,
+                          int64_t nc, sgnn_stream_t stream);
 /* dst (n_dst rows, zero-filled here) ; dst[idx[r]] = src[r]   (idx unique) */
 int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
                       int64_t n_dst, sgnn_stream_t stream);
@@ -321,6 +333,13 @@ int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int
  *         (cin / cout = channels of in0 / in1)
  *   opf   float[nops][4] = {eps, momentum, leak, 0}
  *   bufs  int32[nbuf][2] = {level, channels}; buffer 0 is the input
+ *   ops are 12 ints each: type, in0, in1, out, param slot, level, cin, cout, in2, ia, ib, ic.  Types 0..5 are the scn
+ *         containers' leaves (SUBM conv, stride-2 conv, UnPooling, BatchNorm(ReLU), AddTable, JoinTable); 6 =
+ *         CONCAT_IN out = [in0[ia] | in1[ib] | in2[ic]] (the skip join + feature hand-over between generative
+ *         stages, torch/model.py:242, 330, 338-355; ia/ib/ic index the idx[] array of int32 device arrays, -1 = rows
+ *         as they are); 7 = the 8-child up-sampling convolution on the parent rulebook (out has 8x the rows); 8 =
+ *         linear heads (weight row o = slot par+2o, bias par+2o+1).  Buffers [0, n_ext) are caller-owned inputs
+ *         (ext[] pointers; their gradients go to gext[]), the rest live in the arena.
  *   lev_* per level: rows, table ld, nbr table, and for the transition level -> level+1 the children /
  *         ptable tables and the parent array (device pointers, NULL where unused)
  *   params / pgrads: host arrays of device pointers.
@@ -333,23 +352,23 @@ int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int
  * fusions off (A/B measurements, parity tests); it returns the previous setting.
  * ------------------------------------------------------------------------- */
 int sgnn_prog_set_fusion(int on);
-int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                const int64_t *lev_n, int nlev);
 int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
-int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                 const int64_t *lev_n, int nlev, int b);
-int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                      int nlev, void *const *params, int nparams, const float *input, float *arena,
-                      int64_t arena_floats, const int32_t *keep, int training, void *ws, int64_t ws_bytes,
-                      sgnn_stream_t stream);
-int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+                      int nlev, void *const *params, int nparams, void *const *ext, void *const *idx, int nidx,
+                      float *arena, int64_t arena_floats, const int32_t *keep, int training, void *ws,
+                      int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                       int nlev, void *const *params, void *const *pgrads, int nparams,
-                       const float *input, const float *arena, float *garena, int64_t arena_floats,
-                       const int32_t *ginit, int need_input_grad, int training, void *ws, int64_t ws_bytes,
+                       int nlev, void *const *params, void *const *pgrads, int nparams, void *const *ext,
+                       void *const *gext, void *const *idx, int nidx, const float *arena, float *garena,
+                       int64_t arena_floats, void *const *gout, int training, void *ws, int64_t ws_bytes,
                        sgnn_stream_t stream);
 
 /* Optional second lane for sgnn_prog_backward: every weight-gradient launch (dW + its reduce) runs on `stream2`

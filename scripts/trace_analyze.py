@@ -52,3 +52,17 @@ for g, at in sorted(gaps, reverse=True)[:25]:
     before = max((r for r in step if r['e'] <= at), key=lambda r: r['e'])
     after = min((r for r in step if r['s'] >= at + g), key=lambda r: r['s'])
     print('  %7.1f  %-45s -> %s' % (g / 1e3, short(before['Kernel_Name'])[:45], short(after['Kernel_Name'])[:45]))
+
+# --- gaps between consecutive kernels of the main queue, by (prev family -> next family)
+main_q = max(byq.items(), key=lambda kv: len(kv[1]))[0]
+mq = sorted(byq[main_q], key=lambda r: r['s'])
+fam = lambda n: re.sub(r'<.*', '', short(n))[:28]
+pair = collections.defaultdict(list)
+for a, b in zip(mq[:-1], mq[1:]):
+    pair[(fam(a['Kernel_Name']), fam(b['Kernel_Name']))].append((b['s'] - a['e']) / 1e3)
+print('main-queue start-after-end gaps (us): pair n median min')
+import statistics
+for k, v in sorted(pair.items(), key=lambda kv: -sum(kv[1]))[:40]:
+    print('  %-28s -> %-28s n=%3d med %6.1f min %6.1f sum %7.1f' % (k[0], k[1], len(v), statistics.median(v), min(v), sum(v)))
+allg = [ (b['s'] - a['e']) / 1e3 for a, b in zip(mq[:-1], mq[1:])]
+print('main queue: %d kernels, busy %.3f ms, gaps total %.3f ms, median gap %.2f us' % (len(mq), sum(r['e'] - r['s'] for r in mq) / 1e6, sum(allg) / 1e3, statistics.median(allg)))

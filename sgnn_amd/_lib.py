@@ -67,15 +67,20 @@ PROTOTYPES = {
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_loss_level_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32]),
+    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32]),
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
-    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32]),
+    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
-    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                  c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
-    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                   c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                  c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                   c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_concat3_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_concat3_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                      c_i64, c_vp]),
+    'sgnn_expand_weights': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    'sgnn_expand_weights_bwd': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     'sgnn_io_layout': (c_i32, [c_vp, c_i64, c_i32, c_vp]),
     'sgnn_io_flag_entries': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f32, c_i64, c_vp, c_vp]),
     'sgnn_io_emit_entries': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -134,8 +139,16 @@ _fn_cache = {}
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
+_HOST_DELAY = float(os.environ.get('SGNN_HOST_DELAY_US', '0')) * 1e-6   # diagnostics: is a step host- or GPU-bound?
+
+
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on error."""
+    if _HOST_DELAY:
+        import time
+        t = time.perf_counter() + _HOST_DELAY
+        while time.perf_counter() < t:
+            pass
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(load(), name)

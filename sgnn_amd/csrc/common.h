@@ -47,6 +47,13 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
                      const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 bool sgnn_conv_epi_supported(int cin, int cout);
+int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR);
+// linear.hip: heads whose weight rows / biases are separate tensors
+int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,
+                         float *y, sgnn_stream_t stream);
+int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
+                         float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
+                         sgnn_stream_t stream);
 
 #define SGNN_CHECK_ARG(cond)                                                    \
   do {                                                                          \

@@ -477,6 +477,98 @@ SGNN_EXPORT int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t
 }
 
 // ---------------------------------------------------------------------------
+// Generative up-sampling convolution (sgnn_hip.h, sgnn_conv_fwd_ex): constants and weight transforms.
+// Child parity g = 4*jz+2*jy+jx, parent-level offset slot i = 4*iz+2*iy+ix; per axis the parent offset is
+// o = i - 1 + j and the 3x3x3 taps d of a child that fall into that parent are
+//   (j,i) = (0,0): {-1}   (0,1): {0,+1}   (1,0): {-1,0}   (1,1): {+1}.
+// S[g*8+i] = parent-table row of (g,i), ST = 26 - S (mirrored row: data gradient), PAR = g.
+// ---------------------------------------------------------------------------
+struct ExpandMaps {
+  int32_t v[192];
+};
+constexpr ExpandMaps make_expand_maps() {
+  ExpandMaps m{};
+  for (int g = 0; g < 8; ++g)
+    for (int i = 0; i < 8; ++i) {
+      const int o0 = ((i >> 2) & 1) - 1 + ((g >> 2) & 1), o1 = ((i >> 1) & 1) - 1 + ((g >> 1) & 1),
+                o2 = (i & 1) - 1 + (g & 1);
+      const int srow = (o0 + 1) * 9 + (o1 + 1) * 3 + (o2 + 1);
+      m.v[g * 8 + i] = srow;
+      m.v[64 + g * 8 + i] = 26 - srow;
+      m.v[128 + g * 8 + i] = g;
+    }
+  return m;
+}
+__device__ const ExpandMaps g_expand_maps = make_expand_maps();
+
+// device pointers to S, ST, PAR (64 ints each)
+int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR) {
+  static const int32_t *base = nullptr;
+  if (!base) {
+    void *p = nullptr;
+    SGNN_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_expand_maps)));
+    base = (const int32_t *)p;
+  }
+  *S = base;
+  *ST = base + 64;
+  *PAR = base + 128;
+  return SGNN_OK;
+}
+
+__device__ __forceinline__ void axis_taps(int j, int i, int &lo, int &hi) {   // taps d in [lo, hi]
+  if (j == 0) { lo = i ? 0 : -1; hi = i ? 1 : -1; }
+  else        { lo = i ? 1 : -1; hi = i ? 1 : 0; }
+}
+
+// Wc[g*8+i] = sum of the 3x3x3 taps of child parity g that fall into parent offset slot i   (64 x cin*cout)
+__global__ __launch_bounds__(256) void k_expand_weights(const float *__restrict__ w, int cc, float *__restrict__ wc) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 64 * cc) return;
+  const int gi = t / cc, e = t - gi * cc, g = gi >> 3, i = gi & 7;
+  int l0, h0, l1, h1, l2, h2;
+  axis_taps((g >> 2) & 1, (i >> 2) & 1, l0, h0);
+  axis_taps((g >> 1) & 1, (i >> 1) & 1, l1, h1);
+  axis_taps(g & 1, i & 1, l2, h2);
+  float acc = 0.f;
+  for (int dz = l0; dz <= h0; ++dz)
+    for (int dy = l1; dy <= h1; ++dy)
+      for (int dx = l2; dx <= h2; ++dx) acc += w[(size_t)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)) * cc + e];
+  wc[t] = acc;
+}
+
+// dW[tap] = sum over the 8 parities of dWc[g*8 + i(g, tap)]   (27 x cin*cout)
+__global__ __launch_bounds__(256) void k_expand_weights_bwd(const float *__restrict__ dwc, int cc,
+                                                           float *__restrict__ dw) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 27 * cc) return;
+  const int tap = t / cc, e = t - tap * cc;
+  const int d0 = tap / 9 - 1, d1 = (tap / 3) % 3 - 1, d2 = tap % 3 - 1;
+  float acc = 0.f;
+  for (int g = 0; g < 8; ++g) {
+    const int j0 = (g >> 2) & 1, j1 = (g >> 1) & 1, j2 = g & 1;
+    const int i0 = j0 ? (d0 > 0) : (d0 >= 0), i1 = j1 ? (d1 > 0) : (d1 >= 0), i2 = j2 ? (d2 > 0) : (d2 >= 0);
+    acc += dwc[(size_t)(g * 8 + i0 * 4 + i1 * 2 + i2) * cc + e];
+  }
+  dw[t] = acc;
+}
+
+SGNN_EXPORT int sgnn_expand_weights(const float *w, int cin, int cout, float *wc, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(w && wc && cin >= 1 && cout >= 1);
+  const int cc = cin * cout;
+  hipLaunchKernelGGL(k_expand_weights, dim3((64 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cc, wc);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_expand_weights_bwd(const float *dwc, int cin, int cout, float *dw, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(dwc && dw && cin >= 1 && cout >= 1);
+  const int cc = cin * cout;
+  hipLaunchKernelGGL(k_expand_weights_bwd, dim3((27 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwc, cc, dw);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient: dW[k][ci][co] = sum_j x[table[k][j]][ci] * dy[j][co]
 // MFMA with the site index on the contraction axis (4 rows per instruction):
 //   A[i=ci][kslot=q] = x[table[k][R+q]][ci],  B[kslot=q][j=co] = dy[R+q][co]

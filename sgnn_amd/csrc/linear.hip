@@ -24,13 +24,23 @@ __device__ __forceinline__ void load_row(const float *__restrict__ p, float (&v)
   }
 }
 
+// weight row o lives at w[o] (CIN floats), its bias at b[o] (one float, may be NULL): the two heads of a Refinement are
+// separate nn.Linear modules (torch/model.py:190-191) and need not be packed first
+struct LinW {
+  const float *w[LIN_MAX_OUT];
+  const float *b[LIN_MAX_OUT];
+};
+struct LinG {
+  float *dw[LIN_MAX_OUT];
+  float *db[LIN_MAX_OUT];
+};
+
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x, int64_t n,
-                                                   const float *__restrict__ w, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x, int64_t n, LinW p,
                                                    float *__restrict__ y) {
   __shared__ float ws[COUT * CIN + COUT];
-  for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = w[e];
-  if (threadIdx.x < COUT) ws[COUT * CIN + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = p.w[e / CIN][e % CIN];
+  if (threadIdx.x < COUT) ws[COUT * CIN + threadIdx.x] = p.b[threadIdx.x] ? p.b[threadIdx.x][0] : 0.f;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
@@ -49,12 +59,12 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 // dx[r][c] = sum_o dy[r][o] w[o][c]; block partials of dW[o][c] = sum_r dy[r][o] x[r][c], db[o] = sum_r dy[r][o]
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_linear_bwd(const float *__restrict__ x, const float *__restrict__ dy,
-                                                   int64_t n, const float *__restrict__ w, float *__restrict__ dx,
+                                                   int64_t n, LinW p, float *__restrict__ dx,
                                                    double *__restrict__ partial) {
   constexpr int NV = COUT * CIN + COUT;
   __shared__ float ws[COUT * CIN];
   __shared__ float red[4][NV];
-  for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = w[e];
+  for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = p.w[e / CIN][e % CIN];
   __syncthreads();
   float acc[NV];
 #pragma unroll
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float *__restrict__ x,
 }
 
 __global__ __launch_bounds__(256) void k_linear_finalize(const double *__restrict__ partial, int nblk, int nv,
-                                                        int ncw, float *__restrict__ dw, float *__restrict__ db) {
+                                                        int ncw, int cin, LinG g) {
   __shared__ double sh[256];
   const int e = blockIdx.x;
   double a = 0.0;
@@ -118,9 +128,9 @@ __global__ __launch_bounds__(256) void k_linear_finalize(const double *__restric
   }
   if (threadIdx.x == 0) {
     if (e < ncw) {
-      if (dw) dw[e] = (float)sh[0];
-    } else if (db) {
-      db[e - ncw] = (float)sh[0];
+      if (g.dw[e / cin]) g.dw[e / cin][e % cin] = (float)sh[0];
+    } else if (g.db[e - ncw]) {
+      g.db[e - ncw][0] = (float)sh[0];
     }
   }
 }
@@ -139,17 +149,23 @@ SGNN_EXPORT int64_t sgnn_linear_ws_bytes(int64_t n, int cin, int cout) {
 
 #define LIN_CASES(X) X(16, 1) X(16, 2) X(48, 1) X(48, 2) X(8, 1) X(8, 2) X(32, 1) X(32, 2) X(12, 2) X(4, 1)
 
-SGNN_EXPORT int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float *w, const float *bias, int cout,
-                                float *y, sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1);
+int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,
+                         float *y, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1 && cout <= LIN_MAX_OUT);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && y);
+  LinW p{};
+  for (int o = 0; o < cout; ++o) {
+    SGNN_CHECK_ARG(w[o]);
+    p.w[o] = w[o];
+    p.b[o] = b ? b[o] : nullptr;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int grid = sgnn_grid_for(n, 256, 2048);
   bool done = false;
 #define X(CI, CO)                                                                                   \
   if (!done && cin == CI && cout == CO) {                                                           \
-    hipLaunchKernelGGL((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, w, bias, y);      \
+    hipLaunchKernelGGL((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, p, y);            \
     done = true;                                                                                    \
   }
   LIN_CASES(X)
@@ -162,27 +178,48 @@ SGNN_EXPORT int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float 
   return SGNN_OK;
 }
 
-SGNN_EXPORT int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int cin, const float *w, int cout,
-                                float *dx, float *dw, float *dbias, void *ws, int64_t ws_bytes,
-                                sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float *w, const float *bias, int cout,
+                                float *y, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(cout >= 1 && cout <= LIN_MAX_OUT && cin >= 1);
+  const float *wr[LIN_MAX_OUT] = {}, *br[LIN_MAX_OUT] = {};
+  for (int o = 0; o < cout; ++o) {
+    wr[o] = w ? w + (size_t)o * cin : nullptr;
+    br[o] = bias ? bias + o : nullptr;
+  }
+  return sgnn_linear_fwd_rows(x, n, cin, wr, br, cout, y, stream);
+}
+
+int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
+                         float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
+                         sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1);
+  SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1 && cout <= LIN_MAX_OUT && w);
   if (n == 0) {
-    if (dw) SGNN_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)cin * cout * sizeof(float), s));
-    if (dbias) SGNN_HIP_TRY(hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), s));
+    for (int o = 0; o < cout; ++o) {
+      if (dw && dw[o]) SGNN_HIP_TRY(hipMemsetAsync(dw[o], 0, (size_t)cin * sizeof(float), s));
+      if (db && db[o]) SGNN_HIP_TRY(hipMemsetAsync(db[o], 0, sizeof(float), s));
+    }
     return SGNN_OK;
   }
-  SGNN_CHECK_ARG(x && dy && w);
+  SGNN_CHECK_ARG(x && dy);
   if (!ws || ws_bytes < sgnn_linear_ws_bytes(n, cin, cout)) {
     sgnn_set_error("sgnn_linear_bwd: workspace too small");
     return SGNN_ENOWS;
+  }
+  LinW p{};
+  LinG g{};
+  for (int o = 0; o < cout; ++o) {
+    SGNN_CHECK_ARG(w[o]);
+    p.w[o] = w[o];
+    g.dw[o] = dw ? dw[o] : nullptr;
+    g.db[o] = db ? db[o] : nullptr;
   }
   const int nblk = lin_blocks(n);
   const int nv = cin * cout + cout;
   bool done = false;
 #define X(CI, CO)                                                                                          \
   if (!done && cin == CI && cout == CO) {                                                                  \
-    hipLaunchKernelGGL((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, w, dx, (double *)ws); \
+    hipLaunchKernelGGL((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws); \
     done = true;                                                                                           \
   }
   LIN_CASES(X)
@@ -191,8 +228,21 @@ SGNN_EXPORT int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int 
     sgnn_set_error("sgnn_linear_bwd: unsupported head shape %d -> %d", cin, cout);
     return SGNN_EINVAL;
   }
-  hipLaunchKernelGGL(k_linear_finalize, dim3(nv), dim3(256), 0, s, (const double *)ws, nblk, nv, cin * cout, dw,
-                     dbias);
+  hipLaunchKernelGGL(k_linear_finalize, dim3(nv), dim3(256), 0, s, (const double *)ws, nblk, nv, cin * cout, cin, g);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_linear_bwd(const float *x, const float *dy, int64_t n, int cin, const float *w, int cout,
+                                float *dx, float *dw, float *dbias, void *ws, int64_t ws_bytes,
+                                sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(cout >= 1 && cout <= LIN_MAX_OUT && cin >= 1 && w);
+  const float *wr[LIN_MAX_OUT] = {};
+  float *dwr[LIN_MAX_OUT] = {}, *dbr[LIN_MAX_OUT] = {};
+  for (int o = 0; o < cout; ++o) {
+    wr[o] = w + (size_t)o * cin;
+    dwr[o] = dw ? dw + (size_t)o * cin : nullptr;
+    dbr[o] = dbias ? dbias + o : nullptr;
+  }
+  return sgnn_linear_bwd_rows(x, dy, n, cin, wr, cout, dx, dwr, dbr, ws, ws_bytes, stream);
 }

@@ -1,24 +1,38 @@
-// Sparse-network program executor: runs a whole static sub-network (an encoder level stack, a
-// FullyConvolutionalNet U, ...) forward or backward from ONE call, launching the same kernels in the
-// same order as the per-layer path (bit-identical results) without a host round trip per layer.
+// Sparse-network program executor: runs a whole static sub-network — an encoder level stack, or a complete
+// generative stage (skip join -> SubmanifoldConvolution -> FullyConvolutionalNet U -> BatchNormReLU -> 8-child
+// up-sampling convolution -> BatchNormReLU -> the two linear heads) — forward or backward from ONE call.
 //
-// Counterpart of what upstream does with Python nn.Module containers (scn.Sequential / ConcatTable /
-// AddTable / JoinTable composing <Op>_updateOutput calls): the reference's model.py builds
-// those containers at torch/model.py:31-47, 178-188, 253-257; here the container tree is compiled once into
-// a flat op list (sgnn_amd/scn/program.py) and interpreted natively.  Host-side code only: no kernels here.
+// Counterpart of what upstream does with Python nn.Module containers (scn.Sequential / ConcatTable / AddTable /
+// JoinTable composing <Op>_updateOutput calls): the reference's model.py builds those containers at
+// torch/model.py:31-47, 178-191, 253-258 and glues them with tensor ops at :209-247, 259-272, 338-355; here the tree
+// is compiled once into a flat op list (sgnn_amd/scn/program.py) and interpreted natively.  A training step is
+// host-bound (every microsecond of host time shows up in the step time, profiles/r02_host_bound.txt): one native call
+// per stage and direction replaces ~12 Python autograd nodes and their tensor allocations.
+// Host-side code only: no kernels here.
 #include <vector>
 #include "common.h"
 
-enum { OP_CONV_SUBM = 0, OP_CONV_DOWN = 1, OP_UNPOOL = 2, OP_BN = 3, OP_ADD = 4, OP_JOIN = 5 };
+enum {
+  OP_CONV_SUBM = 0, OP_CONV_DOWN = 1, OP_UNPOOL = 2, OP_BN = 3, OP_ADD = 4, OP_JOIN = 5,
+  OP_CONCAT_IN = 6,   // out = [in0[ia] | in1[ib] | in2[ic]]  (index arrays optional; inputs may be externals)
+  OP_EXPAND = 7,      // SubmanifoldConvolution over the 8-child expansion, on the parent rulebook (sgnn_conv_fwd_ex)
+  OP_LINEAR = 8       // cout (1 or 2) per-site heads; weight row o = param slot par + 2*o, its bias par + 2*o + 1
+};
+#define OPW 12   // ints per op: type, in0, in1, out, par, lev, cin, cout, in2, ia, ib, ic
+#define EXPAND_DX_SPLIT 4
+
+// conv.hip entry points without a prototype in the public header
+extern "C" int sgnn_expand_weights(const float *w, int cin, int cout, float *wc, sgnn_stream_t stream);
+extern "C" int sgnn_expand_weights_bwd(const float *dwc, int cin, int cout, float *dw, sgnn_stream_t stream);
 
 namespace {
 
 struct View {
-  const int32_t *ops;   // nops x 8: type, in0, in1, out, param, level, cin, cout
+  const int32_t *ops;   // nops x OPW
   const float *opf;     // nops x 4: eps, momentum, leak, unused
   int nops;
-  const int32_t *bufs;  // nbuf x 2: level, channels
-  int nbuf;
+  const int32_t *bufs;  // nbuf x 2: rows class ("level"), channels
+  int nbuf, n_ext;      // buffers [0, n_ext) are caller-owned inputs outside the arena
   const int64_t *lev_n, *lev_ld;
   void *const *lev_nbr, *const *lev_children, *const *lev_ptable, *const *lev_parent;
   int nlev;
@@ -26,14 +40,15 @@ struct View {
 
 inline int64_t round64(int64_t v) { return (v + 63) & ~int64_t(63); }
 
-// arena layout: [buffers..., BN save areas (2*C floats per BN op)..., 2 scratch buffers (backward only)]
+// arena layout: [buffers..., per-op areas (BatchNorm: mean/invstd; up-sampling conv: its 64 pre-summed weight
+// slices)..., backward scratch: 2 x largest buffer, up-sampling weight gradient + its split data-gradient rows]
 struct Layout {
   std::vector<int64_t> buf_off, buf_floats, aux_off;
-  int64_t max_buf = 0, total = 0, scratch0 = 0, scratch1 = 0;
+  int64_t max_buf = 0, total = 0, scratch0 = 0, scratch1 = 0, bextra = 0;
 };
 
 int make_layout(const View &v, Layout &L) {
-  L.buf_off.resize(v.nbuf);
+  L.buf_off.assign(v.nbuf, -1);
   L.buf_floats.resize(v.nbuf);
   L.aux_off.assign(v.nops, -1);
   int64_t off = 0;
@@ -41,19 +56,30 @@ int make_layout(const View &v, Layout &L) {
     const int lev = v.bufs[2 * b], ch = v.bufs[2 * b + 1];
     if (lev < 0 || lev >= v.nlev || ch < 1) return -1;
     L.buf_floats[b] = v.lev_n[lev] * ch;
+    if (L.buf_floats[b] > L.max_buf) L.max_buf = L.buf_floats[b];
+    if (b < v.n_ext) continue;
     L.buf_off[b] = off;
     off += round64(L.buf_floats[b]);
-    if (L.buf_floats[b] > L.max_buf) L.max_buf = L.buf_floats[b];
   }
-  for (int i = 0; i < v.nops; ++i)
-    if (v.ops[8 * i] == OP_BN) {
+  int64_t bextra = 0;
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i;
+    if (o[0] == OP_BN) {
       L.aux_off[i] = off;
-      off += round64(2 * (int64_t)v.ops[8 * i + 6]);
+      off += round64(2 * (int64_t)o[6]);
+    } else if (o[0] == OP_EXPAND) {
+      L.aux_off[i] = off;
+      off += round64(64 * (int64_t)o[6] * o[7]);
+      const int64_t need = round64(64 * (int64_t)o[6] * o[7]) + round64(v.lev_n[o[5]] * EXPAND_DX_SPLIT * (int64_t)o[6]);
+      if (need > bextra) bextra = need;
     }
+  }
   L.scratch0 = off;
   off += round64(L.max_buf);
   L.scratch1 = off;
   off += round64(L.max_buf);
+  L.bextra = off;
+  off += bextra;
   L.total = off;
   return 0;
 }
@@ -61,11 +87,13 @@ int make_layout(const View &v, Layout &L) {
 int64_t ws_main(const View &v) {
   int64_t need = 0;
   for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + 8 * i;
+    const int32_t *o = v.ops + OPW * i;
     int64_t w = 0;
     if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
     if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
+    if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
     if (o[0] == OP_BN) w = sgnn_bn_ws_bytes(v.lev_n[o[5]], o[6]);
+    if (o[0] == OP_LINEAR) w = sgnn_linear_ws_bytes(v.lev_n[o[5]], o[6], o[7]);
     if (w > need) need = w;
   }
   return (need + 255) & ~int64_t(255);
@@ -76,7 +104,7 @@ int64_t ws_main(const View &v) {
 int64_t ws_stats(const View &v) {
   int64_t need = 0;
   for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + 8 * i;
+    const int32_t *o = v.ops + OPW * i;
     if (o[0] != OP_CONV_SUBM && o[0] != OP_CONV_DOWN) continue;
     const int64_t rows_f = v.lev_n[o[5]], rows_o = o[0] == OP_CONV_DOWN ? v.lev_n[o[5] + 1] : rows_f;
     const int64_t a = sgnn_conv_grid_blocks(rows_o > 0 ? rows_o : 1) * 2 * o[7] * (int64_t)sizeof(double);  // forward: out rows x cout
@@ -92,10 +120,14 @@ int64_t ws_need(const View &v) { return ws_main(v) + ws_stats(v); }
 // number of ops that read buffer b
 std::vector<int> count_readers(const View &v) {
   std::vector<int> r(v.nbuf, 0);
+  auto hit = [&](int b) {
+    if (b >= 0 && b < v.nbuf) ++r[b];
+  };
   for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + 8 * i;
-    if (o[1] >= 0 && o[1] < v.nbuf) ++r[o[1]];
-    if ((o[0] == OP_ADD || o[0] == OP_JOIN) && o[2] >= 0 && o[2] < v.nbuf) ++r[o[2]];
+    const int32_t *o = v.ops + OPW * i;
+    hit(o[1]);
+    if (o[0] == OP_ADD || o[0] == OP_JOIN || o[0] == OP_CONCAT_IN) hit(o[2]);
+    if (o[0] == OP_CONCAT_IN) hit(o[8]);
   }
   return r;
 }
@@ -114,10 +146,11 @@ struct SideLane {
 int64_t dw_ws_need(const View &v) {
   int64_t need = 0;
   for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + 8 * i;
+    const int32_t *o = v.ops + OPW * i;
     int64_t w = 0;
     if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
     if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
+    if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
     if (w > need) need = w;
   }
   return need;
@@ -149,36 +182,37 @@ SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
     if (rc_ != SGNN_OK) return rc_; \
   } while (0)
 
-SGNN_EXPORT int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+SGNN_EXPORT int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                            const int64_t *lev_n, int nlev) {
-  View v{ops, nullptr, nops, bufs, nbuf, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
   Layout L;
   if (make_layout(v, L) != 0) return -1;
   return L.total;
 }
 
 SGNN_EXPORT int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev) {
-  View v{ops, nullptr, nops, nullptr, 0, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  View v{ops, nullptr, nops, nullptr, 0, 0, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
   return ws_need(v);
 }
 
-// byte offset of buffer `b` inside an arena (so the host layer can hand out views)
-SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf,
+// float offset of buffer `b` inside an arena (so the host layer can hand out views); -1 for externals
+SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                             const int64_t *lev_n, int nlev, int b) {
-  View v{ops, nullptr, nops, bufs, nbuf, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
   Layout L;
   if (make_layout(v, L) != 0 || b < 0 || b >= nbuf) return -1;
   return L.buf_off[b];
 }
 
-SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                  int nlev, void *const *params, int nparams, const float *input, float *arena,
-                                  int64_t arena_floats, const int32_t *keep, int training, void *ws, int64_t ws_bytes,
-                                  sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1);
-  View v{ops, opf, nops, bufs, nbuf, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+                                  int nlev, void *const *params, int nparams, void *const *ext, void *const *idx,
+                                  int nidx, float *arena, int64_t arena_floats, const int32_t *keep, int training,
+                                  void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1 &&
+                 n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || ext));
+  View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Layout L;
   SGNN_CHECK_ARG(make_layout(v, L) == 0);
   if (arena_floats < L.total) {
@@ -190,9 +224,11 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
     sgnn_set_error("sgnn_prog_forward: workspace too small");
     return SGNN_ENOWS;
   }
-  // buffer 0 (the program input) may live outside the arena
-  auto B = [&](int b) { return (b == 0 && input) ? const_cast<float *>(input) : arena + L.buf_off[b]; };
+  auto B = [&](int b) -> float * { return b < 0 ? nullptr : (b < n_ext ? (float *)ext[b] : arena + L.buf_off[b]); };
+  auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
+  auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
+  auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
   // Epilogue fusions (same arithmetic, fewer passes and launches):
   //  * conv -> AddTable: the convolution adds the other AddTable input while it stores (the sum buffer is written
   //    directly, the convolution's own output buffer stays untouched) when nothing else reads the convolution output;
@@ -207,9 +243,10 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
   std::vector<int64_t> pre_nblk(nops, 0);
   double *stats_ws = (double *)((char *)ws + ws_main(v));
   for (int i = 0; i < nops; ++i) {
-    const int32_t *o = ops + 8 * i;
+    const int32_t *o = ops + OPW * i;
     const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
-    SGNN_CHECK_ARG(in0 >= 0 && in0 < nbuf && out >= 0 && out < nbuf && lev >= 0 && lev < nlev);
+    SGNN_CHECK_ARG(out >= n_ext && out < nbuf && lev >= 0 && lev < nlev && in0 < nbuf && in1 < nbuf);
+    SGNN_CHECK_ARG(type == OP_CONCAT_IN || in0 >= 0);
     const int64_t n = lev_n[lev];
     if (skip[i]) continue;
     switch (type) {
@@ -225,16 +262,16 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         int dst_buf = out;
         if (g_fuse && sgnn_conv_epi_supported(cin, cout) && n_out > 0) {
           int j = i + 1;
-          if (j < nops && ops[8 * j] == OP_ADD && readers[out] == 1 && (ops[8 * j + 1] == out || ops[8 * j + 2] == out) &&
-              ops[8 * j + 1] != ops[8 * j + 2]) {
-            const int other = ops[8 * j + 1] == out ? ops[8 * j + 2] : ops[8 * j + 1];
+          if (j < nops && ops[OPW * j] == OP_ADD && readers[out] == 1 &&
+              (ops[OPW * j + 1] == out || ops[OPW * j + 2] == out) && ops[OPW * j + 1] != ops[OPW * j + 2]) {
+            const int other = ops[OPW * j + 1] == out ? ops[OPW * j + 2] : ops[OPW * j + 1];
             epi.addend = B(other);
-            dst_buf = ops[8 * j + 3];
+            dst_buf = ops[OPW * j + 3];
             dst = B(dst_buf);
             skip[j] = 1;
             ++j;
           }
-          if (training && j < nops && ops[8 * j] == OP_BN && ops[8 * j + 1] == dst_buf) {
+          if (training && j < nops && ops[OPW * j] == OP_BN && ops[OPW * j + 1] == dst_buf) {
             epi.stats = 1;
             epi.partial = stats_ws;
             pre[j] = stats_ws;
@@ -257,13 +294,40 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       }
       case OP_ADD:
-        SGNN_CHECK_ARG(in1 >= 0 && in1 < nbuf);
+        SGNN_CHECK_ARG(in1 >= 0);
         PROG_TRY(sgnn_add(B(in0), B(in1), n * cin, B(out), stream));
         break;
       case OP_JOIN:  // cin = channels of in0, cout = channels of in1
-        SGNN_CHECK_ARG(in1 >= 0 && in1 < nbuf);
+        SGNN_CHECK_ARG(in1 >= 0);
         PROG_TRY(sgnn_concat_rows(B(in0), cin, nullptr, B(in1), cout, nullptr, n, B(out), stream));
         break;
+      case OP_CONCAT_IN: {
+        const int in2 = o[8];
+        SGNN_CHECK_ARG(in2 < nbuf && CH(in0) + CH(in1) + CH(in2) == CH(out));
+        PROG_TRY(sgnn_concat3_rows(B(in0), CH(in0), I(o[9]), B(in1), CH(in1), I(o[10]), B(in2), CH(in2), I(o[11]), n,
+                                   B(out), stream));
+        break;
+      }
+      case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
+        SGNN_CHECK_ARG(ROWS(out) == 8 * n);
+        const int32_t *S, *ST, *PAR;
+        PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
+        float *wc = arena + L.aux_off[i];
+        PROG_TRY(sgnn_expand_weights(P(par), cin, cout, wc, stream));
+        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
+                                    0, S, nullptr, 1, 8, 27, nullptr, stream));
+        break;
+      }
+      case OP_LINEAR: {
+        SGNN_CHECK_ARG(cout >= 1 && cout <= 4);
+        const float *w[4] = {}, *b[4] = {};
+        for (int q = 0; q < cout; ++q) {
+          w[q] = P(par + 2 * q);
+          b[q] = P(par + 2 * q + 1);
+        }
+        PROG_TRY(sgnn_linear_fwd_rows(B(in0), n, cin, w, b, cout, B(out), stream));
+        break;
+      }
       default:
         sgnn_set_error("sgnn_prog_forward: unknown op %d", type);
         return SGNN_EINVAL;
@@ -272,18 +336,19 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
   return SGNN_OK;
 }
 
-// garena has the same layout as arena; ginit[b] != 0 marks gradient buffers the caller already filled
-// (the program outputs).  need_input_grad: whether buffer 0's gradient is wanted.
-SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf,
+// garena has the same layout as arena.  gout[b] != NULL: the caller's gradient of buffer b (a program output); it
+// is copied into the arena first (the executor accumulates into its own memory only).  gext[e] != NULL: where the
+// gradient of external input e is wanted (fully overwritten).
+SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                    const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                    void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
                                    int nlev, void *const *params, void *const *pgrads, int nparams,
-                                   const float *input, const float *arena, float *garena, int64_t arena_floats,
-                                   const int32_t *ginit,
-                                   int need_input_grad, int training, void *ws, int64_t ws_bytes,
-                                   sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && pgrads && arena && garena && ginit);
-  View v{ops, opf, nops, bufs, nbuf, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+                                   void *const *ext, void *const *gext, void *const *idx, int nidx,
+                                   const float *arena, float *garena, int64_t arena_floats, void *const *gout,
+                                   int training, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && pgrads && arena && garena && gout &&
+                 n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || (ext && gext)));
+  View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Layout L;
   SGNN_CHECK_ARG(make_layout(v, L) == 0);
   if (arena_floats < L.total || ws_bytes < ws_need(v)) {
@@ -294,14 +359,22 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   // gradient state of a buffer: 0 nothing yet, 1 G(b) holds it, 2 it EQUALS the gradient of buffer alias[b]
   // (an AddTable input whose only contribution so far is the sum's gradient: nothing is copied until something
   // has to be added to it, and a reader just follows the alias)
-  std::vector<char> init(nbuf);
+  std::vector<char> init(nbuf, 0);
   std::vector<int> alias(nbuf, -1);
-  for (int b = 0; b < nbuf; ++b) init[b] = ginit[b] != 0;
-  auto X = [&](int b) { return (b == 0 && input) ? input : arena + L.buf_off[b]; };
-  auto G = [&](int b) { return garena + L.buf_off[b]; };
+  auto X = [&](int b) -> const float * { return b < 0 ? nullptr : (b < n_ext ? (const float *)ext[b] : arena + L.buf_off[b]); };
+  auto G = [&](int b) -> float * { return b < n_ext ? (float *)gext[b] : garena + L.buf_off[b]; };
   auto GR = [&](int b) -> const float * { return init[b] == 2 ? G(alias[b]) : G(b); };   // where b's gradient is read
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto PG = [&](int p) { return (p >= 0 && p < nparams) ? (float *)pgrads[p] : nullptr; };
+  auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
+  auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
+  auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
+  for (int b = n_ext; b < nbuf; ++b)
+    if (gout[b]) {
+      if (L.buf_floats[b] > 0)
+        SGNN_HIP_TRY(hipMemcpyAsync(G(b), gout[b], (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+      init[b] = 1;
+    }
   float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
   // where a kernel should write the gradient of buffer b: the buffer itself unless it already holds data
   auto target = [&](int b, int which) { return init[b] == 1 ? scratch[which] : G(b); };
@@ -318,7 +391,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     }
     return sgnn_add(G(b), wrote, L.buf_floats[b], G(b), stream);
   };
-  auto wants = [&](int b) { return b != 0 || need_input_grad; };
+  auto wants = [&](int b) { return b >= n_ext || gext[b] != nullptr; };
   // dW launches go to the side lane when one is configured and its workspace is big enough
   const bool side = g_side.stream && g_side.stream != hs && g_side.ws && g_side.ws_bytes >= dw_ws_need(v);
   bool forked = false;
@@ -336,16 +409,21 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   double *stats_ws = (double *)((char *)ws + ws_main(v));
 
   for (int i = nops - 1; i >= 0; --i) {
-    const int32_t *o = ops + 8 * i;
+    const int32_t *o = ops + OPW * i;
     const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
     const int64_t n = lev_n[lev];
     if (!init[out]) {  // no gradient reached this output: its producers contribute nothing
-      if (type == OP_CONV_SUBM || type == OP_CONV_DOWN)
-        SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, (size_t)(type == OP_CONV_SUBM ? 27 : 8) * cin * cout * sizeof(float), hs));
+      if (type == OP_CONV_SUBM || type == OP_CONV_DOWN || type == OP_EXPAND)
+        SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, (size_t)(type == OP_CONV_DOWN ? 8 : 27) * cin * cout * sizeof(float), hs));
       if (type == OP_BN) {
         if (PG(par)) SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, cin * sizeof(float), hs));
         if (PG(par + 1)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 1), 0, cin * sizeof(float), hs));
       }
+      if (type == OP_LINEAR)
+        for (int q = 0; q < cout; ++q) {
+          if (PG(par + 2 * q)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 2 * q), 0, cin * sizeof(float), hs));
+          if (PG(par + 2 * q + 1)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 2 * q + 1), 0, sizeof(float), hs));
+        }
       continue;
     }
     const float *dy = GR(out);
@@ -368,8 +446,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             ConvEpi epi{};
             if (init[in0] == 1) epi.addend = G(in0);
             else if (init[in0] == 2) epi.addend = G(alias[in0]);
-            if (i > 0 && ops[8 * (i - 1)] == OP_BN && ops[8 * (i - 1) + 3] == in0 && ops[8 * (i - 1) + 6] == cin) {
-              const int32_t *bo = ops + 8 * (i - 1);
+            if (i > 0 && ops[OPW * (i - 1)] == OP_BN && ops[OPW * (i - 1) + 3] == in0 && ops[OPW * (i - 1) + 6] == cin) {
+              const int32_t *bo = ops + OPW * (i - 1);
               const float *save = arena + L.aux_off[i - 1];
               epi.stats = 2;
               epi.partial = stats_ws;
@@ -420,8 +498,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       }
       case OP_ADD: {
         const int src = init[out] == 2 ? alias[out] : out;      // the buffer that physically holds dy
-        for (int side = 0; side < 2; ++side) {
-          const int b = side ? in1 : in0;
+        for (int side_ = 0; side_ < 2; ++side_) {
+          const int b = side_ ? in1 : in0;
           if (!wants(b)) continue;
           if (init[b] == 1) {
             PROG_TRY(sgnn_add(G(b), dy, L.buf_floats[b], G(b), stream));
@@ -444,13 +522,70 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         if (tb) PROG_TRY(commit(in1, tb));
         break;
       }
+      case OP_CONCAT_IN: {
+        const int src[3] = {in0, in1, o[8]};
+        float *d[3] = {nullptr, nullptr, nullptr};
+        for (int q = 0; q < 3; ++q)
+          if (src[q] >= 0 && wants(src[q])) {
+            if (init[src[q]]) {
+              sgnn_set_error("sgnn_prog_backward: a CONCAT_IN source already carries a gradient (unsupported)");
+              return SGNN_EINVAL;
+            }
+            d[q] = G(src[q]);
+            init[src[q]] = 1;
+          }
+        PROG_TRY(sgnn_concat3_rows_bwd(dy, CH(in0), I(o[9]), CH(in1), I(o[10]), CH(o[8]), I(o[11]), n, d[0],
+                                       in0 >= 0 ? ROWS(in0) : 0, d[1], in1 >= 0 ? ROWS(in1) : 0, d[2],
+                                       o[8] >= 0 ? ROWS(o[8]) : 0, stream));
+        break;
+      }
+      case OP_EXPAND: {
+        const int32_t *S, *ST, *PAR;
+        PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
+        const float *wc = arena + L.aux_off[i];
+        const int32_t *nbr = (const int32_t *)lev_nbr[lev];
+        float *dwc = garena + L.bextra;
+        float *part = dwc + round64(64 * (int64_t)cin * cout);
+        const hipStream_t lane = dw_lane();
+        if (wants(in0) && n > 0) {
+          // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
+          const int Gs = EXPAND_DX_SPLIT;
+          PROG_TRY(sgnn_conv_fwd_impl(dy, 8 * n, cout, wc, 64 / Gs, nbr, lev_ld[lev], n, cin, part, SGNN_CONV_TRANSPOSE_W,
+                                      0, ST, PAR, 8, Gs, 27, nullptr, stream));
+          float *t = target(in0, 0);
+          PROG_TRY(sgnn_sum_groups(part, cin, n, Gs, t, stream));
+          PROG_TRY(commit(in0, t));
+        }
+        PROG_TRY(sgnn_conv_bwd_weight_ex(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1, 8, 27,
+                                         dw_ws, dw_ws_bytes, (sgnn_stream_t)lane));
+        PROG_TRY(sgnn_expand_weights_bwd(dwc, cin, cout, PG(par), (sgnn_stream_t)lane));
+        break;
+      }
+      case OP_LINEAR: {
+        const float *w[4] = {};
+        float *dw[4] = {}, *db[4] = {};
+        for (int q = 0; q < cout; ++q) {
+          w[q] = P(par + 2 * q);
+          dw[q] = PG(par + 2 * q);
+          db[q] = PG(par + 2 * q + 1);
+        }
+        float *t = wants(in0) ? target(in0, 0) : nullptr;
+        PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, t, dw, db, ws, ws_bytes, stream));
+        if (t) PROG_TRY(commit(in0, t));
+        break;
+      }
       default:
         sgnn_set_error("sgnn_prog_backward: unknown op %d", type);
         return SGNN_EINVAL;
     }
   }
-  if (need_input_grad && init[0] == 2)                // the caller reads G(0): an alias has to become a copy
-    SGNN_HIP_TRY(hipMemcpyAsync(G(0), G(alias[0]), (size_t)L.buf_floats[0] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+  for (int b = 0; b < n_ext; ++b) {                   // the caller reads gext[b]: an alias has to become a copy,
+    if (!gext[b] || L.buf_floats[b] == 0) continue;   // an input nothing reached gets zeros
+    if (init[b] == 2)
+      SGNN_HIP_TRY(hipMemcpyAsync(G(b), G(alias[b]), (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    else if (init[b] == 0)
+      SGNN_HIP_TRY(hipMemsetAsync(G(b), 0, (size_t)L.buf_floats[b] * sizeof(float), hs));
+  }
   if (forked) {                                       // parameter gradients are complete once the lane has drained
     SGNN_HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
     SGNN_HIP_TRY(hipStreamWaitEvent(hs, g_side.join, 0));

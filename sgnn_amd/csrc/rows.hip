@@ -268,6 +268,79 @@ SGNN_EXPORT int sgnn_concat_rows_bwd(const float *ddst, int ca, const int32_t *i
   return SGNN_OK;
 }
 
+// dst[r] = [ a[ia?ia[r]:r] | b[ib?ib[r]:r] | c[ic?ic[r]:r] ]  (negative index -> zeros; a source with 0 channels is
+// skipped).  One launch builds the input rows of a generative stage: kept features of the previous level, their
+// occupancy/sdf logits, and the encoder's skip features at the same sites (torch/model.py:242, 330, 338-355).
+struct Cat3 {
+  const float *src[3];
+  const int32_t *idx[3];
+  int c[3];
+};
+struct Cat3Out {
+  float *dst[3];
+  const int32_t *idx[3];
+  int c[3];
+};
+
+__global__ __launch_bounds__(256) void k_concat3(Cat3 s, int64_t m, float *__restrict__ dst) {
+  const int c01 = s.c[0] + s.c[1], c = c01 + s.c[2];
+  const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / c;
+    const int col = (int)(g - r * c);
+    const int which = col < s.c[0] ? 0 : (col < c01 ? 1 : 2);
+    const int lc = col - (which == 0 ? 0 : (which == 1 ? s.c[0] : c01));
+    const int64_t i = s.idx[which] ? (int64_t)s.idx[which][r] : r;
+    dst[g] = i >= 0 ? s.src[which][i * s.c[which] + lc] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_concat3_bwd(const float *__restrict__ ddst, int64_t m, Cat3Out o) {
+  const int c01 = o.c[0] + o.c[1], c = c01 + o.c[2];
+  const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / c;
+    const int col = (int)(g - r * c);
+    const int which = col < o.c[0] ? 0 : (col < c01 ? 1 : 2);
+    if (!o.dst[which]) continue;
+    const int lc = col - (which == 0 ? 0 : (which == 1 ? o.c[0] : c01));
+    const int64_t i = o.idx[which] ? (int64_t)o.idx[which][r] : r;
+    if (i >= 0) o.dst[which][i * o.c[which] + lc] = ddst[g];
+  }
+}
+
+SGNN_EXPORT int sgnn_concat3_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
+                                  const float *c, int cc, const int32_t *ic, int64_t m, float *dst,
+                                  sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && cc >= 0 && ca + cb + cc >= 1 && m >= 0);
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b) && (cc == 0 || c));
+  const Cat3 s{{a, b, c}, {ia, ib, ic}, {ca, cb, cc}};
+  hipLaunchKernelGGL(k_concat3, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     s, m, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// gradient of sgnn_concat3_rows: d{a,b,c}[idx[r]] = the matching columns of ddst[r] (indices unique).  A destination
+// reached through an index array is zero-filled first (n{a,b,c} rows); NULL destinations are skipped.
+SGNN_EXPORT int sgnn_concat3_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int cc,
+                                      const int32_t *ic, int64_t m, float *da, int64_t na, float *db, int64_t nb,
+                                      float *dc, int64_t nc, sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && cc >= 0 && ca + cb + cc >= 1 && m >= 0 && na >= 0 && nb >= 0 && nc >= 0);
+  if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
+  if (db && ib && nb > 0 && cb > 0) SGNN_HIP_TRY(hipMemsetAsync(db, 0, (size_t)nb * cb * sizeof(float), s));
+  if (dc && ic && nc > 0 && cc > 0) SGNN_HIP_TRY(hipMemsetAsync(dc, 0, (size_t)nc * cc * sizeof(float), s));
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(ddst);
+  SGNN_CHECK_ARG((ia || !da || na >= m) && (ib || !db || nb >= m) && (ic || !dc || nc >= m));
+  const Cat3Out o{{da, db, dc}, {ia, ib, ic}, {ca, cb, cc}};
+  hipLaunchKernelGGL(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 __global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const float *__restrict__ b,
                                             int64_t count, float *__restrict__ y) {
   const int64_t n4 = count / 4, stride = (int64_t)gridDim.x * 256;

@@ -27,6 +27,9 @@ from .scn import program as P_
 from .scn.metadata import coords_from_locs
 
 
+STAGES = True   # each generative stage (skip join .. heads) as one native program; False: per-module glue
+
+
 def _dense_block(cin, cout, k, stride, pad, transposed=False):
     conv = (nn.ConvTranspose3d if transposed else nn.Conv3d)(cin, cout, kernel_size=k, stride=stride, padding=pad,
                                                               bias=False)
@@ -297,6 +300,48 @@ class Refinement(nn.Module):
     def p0_coords(x):
         return coords_from_locs(x[0], x[1].device)
 
+    def stage(self, prev, skip):
+        """The whole level as ONE native program (sgnn_amd/scn/program.py): skip join + p1 + p2 + p3 + up-sampling
+        convolution n1 + n2 + both heads.  prev = (a, b, sel, locs, cnt): this level's input rows are
+        [a[sel] | b[sel]] (what forward() receives as x[1], before concat_skip) at the sites `locs`; skip = (Grid,
+        features) of the encoder level or None.  Returns (y (8cnt,nf), out (8cnt,2) [occ, sdf], child coords), or None
+        when the configuration is not compilable (the caller then uses forward())."""
+        prog, ext, idx, extra = _stage_program(self, prev, skip, [self.p1, self.p2, self.p3], self.nf_in,
+                                               [('expand', self.n1), ('bn', self.n2),
+                                                ('linear', [self.linear, self.linearsdf])])
+        if prog is None:
+            return None
+        locs = prev[3]
+        x0 = self.p0([locs, ext[0]])
+        outs, _, _ = P_.run_program(prog, x0, self.training, [prog.taps[id(self.n2)][0], prog.taps[id(self.linear)][0]],
+                                    ext=ext, idx=idx, extra_rows=extra)
+        return outs[0], outs[1], F_.expand8_coords(locs)
+
+
+def _stage_program(owner, prev, skip, chain, nf_in, tail):
+    """Program + run-time inputs of a generative stage (see Refinement.stage)."""
+    a, b, sel, locs, cnt = prev
+    srcs, ext = [None, None, None], []
+    for k, t in enumerate((a, b)):
+        if t is not None:
+            srcs[k] = ('prev', int(t.shape[1]), 0)
+            ext.append(t)
+    idx = [sel]
+    extra = {'prev': int(ext[0].shape[0])}
+    if skip is not None:
+        grid_from, feats_from = skip
+        if grid_from.n == 0:
+            return None, None, None, None
+        srcs[2] = ('skip', int(feats_from.shape[1]), 1)
+        ext.append(feats_from)
+        idx.append(grid_from.lookup(locs))
+        extra['skip'] = grid_from.n
+    cache = owner.__dict__.setdefault('_stage_progs', {})
+    key = tuple(srcs)
+    if key not in cache:
+        cache[key] = P_.compile_or_none(chain, nf_in, sources=srcs, tail=tail)
+    return cache[key], ext, idx, extra
+
 
 class SurfacePrediction(nn.Module):
     def __init__(self, nf_in, nf, nf_out, max_data_size):
@@ -318,6 +363,17 @@ class SurfacePrediction(nn.Module):
         else:
             f = self.p4(self.p3(self.p2(self.p1(self.p0(x)))))
         return F_.RowLinear.apply(f, self.linear.weight, self.linear.bias)
+
+    def stage(self, prev, skip):
+        """As Refinement.stage: skip join + p1 + p2 + p3 + linear in one native program; returns sdf (cnt, 1) or None."""
+        prog, ext, idx, extra = _stage_program(self, prev, skip, [self.p1, self.p2, self.p3], self.p1.nIn,
+                                               [('linear', [self.linear])])
+        if prog is None:
+            return None
+        x0 = self.p0([prev[3], ext[0]])
+        outs, _, _ = P_.run_program(prog, x0, self.training, [prog.taps[id(self.linear)][0]], ext=ext, idx=idx,
+                                    extra_rows=extra)
+        return outs[0]
 
 
 class GenModel(nn.Module):
@@ -388,7 +444,6 @@ class GenModel(nn.Module):
 
     # -- forward -----------------------------------------------------------------------------------------
     def forward(self, x, loss_weights, batch_size=None):
-        outputs = []
         x = [coords_from_locs(x[0], x[1].device), x[1]]
         feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
         if self.use_skip_sparse:
@@ -398,6 +453,11 @@ class GenModel(nn.Module):
         runs = [loss_weights[h + 1] > 0 for h in range(R)] + [bool(self.PRED_SURF and loss_weights[-1] > 0)]
         for h in range(R):
             self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
+        if P_.ENABLED and STAGES:
+            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs)
+            if res is not None:
+                return res
+        outputs = []
         locs, feats, out0 = self.dense_coarse_to_sparse(feat_rows, occ_rows, geo, truncation=3,
                                                         plan_depth=2 if runs[0] else 0)
         outputs.append(out0)
@@ -418,3 +478,47 @@ class GenModel(nn.Module):
             locs_out = F_.coords_to_i64(locs) if len(locs) else locs
             return [locs_out, sdf], outputs
         return [[], []], outputs
+
+    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs):
+        """forward() with every generative stage as one native program (Refinement.stage / SurfacePrediction.stage):
+        the kept rows of a level are never gathered into their own tensor — the next stage's CONCAT_IN reads them
+        through the compaction's index list.  Same results as the per-module path (tests/test_gpu_program.py)."""
+        if not (self.pass_occ or self.pass_feats):
+            return None
+        R = len(self.refinement)
+        if getattr(geo, 'coords_i64', None) is None:
+            geo.coords_i64 = F_.coords_to_i64(geo.coords)      # depends on the volume shape only (cached with geo)
+        outputs = [[geo.coords_i64, occ_rows]]
+        n_all = occ_rows.shape[0]
+        sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0)
+        # channel order of model.py:330: [occ, sdf | features]
+        prev = (occ_rows if self.pass_occ else None, feat_rows if self.pass_feats else None, sel, locs, cnt)
+        for h in range(R):
+            if not runs[h]:
+                outputs.append([[], []])
+                continue
+            if cnt == 0:                         # nothing predicted occupied: the hierarchy ends here (model.py:211)
+                outputs.append([[], []])
+                continue
+            ref = self.refinement[h]
+            got = ref.stage(prev, skips[R - h] if self.use_skip_sparse else None)
+            if got is None:
+                return None if h == 0 else self._stage_fallback()
+            y, out, coords_next = got
+            outputs.append([F_.coords_to_i64(coords_next), out])
+            sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth)
+            # channel order of model.py:242: [features | occ, sdf]
+            prev = (y if ref.pass_feats else None, out if ref.pass_occ else None, sel, locs, cnt)
+        if not runs[R]:
+            return [[], []], outputs
+        if cnt == 0:
+            return [[], []], outputs
+        sdf = self.surfacepred.stage(prev, skips[0] if self.use_skip_sparse else None)
+        if sdf is None:
+            return self._stage_fallback()
+        return [F_.coords_to_i64(prev[3]), sdf], outputs
+
+    @staticmethod
+    def _stage_fallback():
+        raise RuntimeError('sgnn_amd: a generative stage could not be compiled into a native program after an earlier '
+                           'one was; set sgnn_amd.model.STAGES = False to run the per-module path')

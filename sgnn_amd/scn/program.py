@@ -1,15 +1,18 @@
-"""Compile a tree of scn containers into a flat op list and run it through the native executor
-(sgnn_prog_forward / sgnn_prog_backward, sgnn_amd/csrc/prog.hip).
+"""Compile a tree of scn containers — optionally with the tensor glue around it — into a flat op list and run it
+through the native executor (sgnn_prog_forward / sgnn_prog_backward, sgnn_amd/csrc/prog.hip).
 
 The reference composes its sparse sub-networks from scn.Sequential / ConcatTable / AddTable / JoinTable
-(torch/model.py:31-47 encoder layer, :178-188 Refinement, :253-257 SurfacePrediction, and upstream's
-FullyConvolutionalNet).  Executing those containers layer by layer costs one Python autograd node per layer
-(~110 per step); a Program runs the same kernels in the same order from one call per direction.  The
-modules stay the parameter holders, so state-dict layout and results are unchanged (bit-identical to the
-per-layer path, tests/test_gpu_program.py).
-"""
-import ctypes
+(torch/model.py:31-47 encoder layer, :178-191 Refinement, :253-258 SurfacePrediction, and upstream's
+FullyConvolutionalNet) and glues the generative stages together with tensor ops (:209-247 Refinement.forward,
+:259-272 SurfacePrediction.forward, :338-355 concat_skip).  Executing that layer by layer costs one Python autograd
+node per layer (~110 per step) plus a dozen more per stage for the glue, and the training step is host-bound
+(profiles/r02_host_bound.txt); a Program runs the same kernels from ONE call per direction:
 
+    [CONCAT_IN: kept rows of the previous stage | their occ/sdf logits | encoder skip features at those sites]
+      -> chain of scn modules (p1, p2, p3) -> [8-child up-sampling convolution n1 -> BatchNormReLU n2 -> linear heads]
+
+The modules stay the parameter holders, so state-dict layout and results are unchanged (tests/test_gpu_program.py).
+"""
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -18,7 +21,8 @@ from .. import _lib
 from . import modules as M
 from .metadata import runtime
 
-OP_SUBM, OP_DOWN, OP_UNPOOL, OP_BN, OP_ADD, OP_JOIN = range(6)
+OP_SUBM, OP_DOWN, OP_UNPOOL, OP_BN, OP_ADD, OP_JOIN, OP_CONCAT_IN, OP_EXPAND, OP_LINEAR = range(9)
+OPW = 12
 ENABLED = True   # False: run the containers layer by layer (one autograd node per layer)
 
 
@@ -26,26 +30,77 @@ class Unsupported(Exception):
     pass
 
 
-class Program(object):
-    """ops over buffers; buffer 0 = input (level 0).  `taps` maps a module to the buffer holding its output."""
+def _op(t, in0=-1, in1=-1, out=-1, par=-1, lev=0, cin=0, cout=0, in2=-1, ia=-1, ib=-1, ic=-1):
+    return [t, in0, in1, out, par, lev, cin, cout, in2, ia, ib, ic]
 
-    def __init__(self, chain, in_channels, tap_modules=()):
-        self.ops, self.opf, self.bufs = [], [], [[0, in_channels]]
-        self.slots = []            # tensors in parameter-slot order (conv weight | gamma, beta, rmean, rvar)
+
+class Program(object):
+    """ops over buffers.  Without `sources`, buffer 0 is the one external input (level 0, in_channels).  With
+    `sources` = up to three (rows class name, channels, index slot or None) entries (None entries allowed), the
+    externals are those tensors and a CONCAT_IN op builds the chain's input rows from them.  `tail` continues after
+    the chain: ('expand', SubmanifoldConvolution) | ('bn', BatchNormalization) | ('linear', [nn.Linear, ...]).
+    Rows classes: 0..nlev-1 = the stride-2 pyramid below the chain's input level; further named classes ('child' =
+    8 x level 0, and the classes of the sources) get the ids nlev.. in `class_ids`; their row counts are given per run.
+    `taps` maps a module (or a tail entry's module / first linear) to the buffer holding its output."""
+
+    def __init__(self, chain, in_channels, tap_modules=(), sources=None, tail=()):
+        self.ops, self.opf, self.bufs = [], [], []
+        self.slots = []            # (module, attribute) in parameter-slot order
         self.grad_slot = []        # True where the slot is a trainable parameter
         self.taps = {}
         self._tap_modules = set(id(m) for m in tap_modules)
-        cur = (0, 0, in_channels)
+        self._classes = []         # named rows classes, in id order after the pyramid levels
+        if sources is None:
+            self.n_ext = 1
+            self.bufs.append([0, in_channels])
+            cur = (0, 0, in_channels)
+        else:
+            if len(sources) != 3 or all(s is None for s in sources):
+                raise Unsupported('CONCAT_IN takes three (possibly None) sources')
+            ins, idxs, total = [], [], 0
+            for s in sources:
+                if s is None:
+                    ins.append(-1)
+                    idxs.append(-1)
+                    continue
+                cls, ch, slot = s
+                ins.append(self._new_buf(self._class(cls), ch))
+                idxs.append(-1 if slot is None else int(slot))
+                total += ch
+            self.n_ext = len(self.bufs)
+            if total != in_channels:
+                raise Unsupported('sources carry %d channels, the chain expects %d' % (total, in_channels))
+            b = self._new_buf(0, total)
+            self.ops.append(_op(OP_CONCAT_IN, ins[0], ins[1], b, -1, 0, 0, 0, ins[2], idxs[0], idxs[1], idxs[2]))
+            self.opf.append([0, 0, 0, 0])
+            cur = (b, 0, total)
         for m in chain:
             cur = self._emit(m, cur)
         if isinstance(cur, list):
             raise Unsupported('chain ends in a ConcatTable')
         self.out = cur[0]
-        self.nlev = 1 + max(b[0] for b in self.bufs)
-        self.ops_np = np.ascontiguousarray(np.array(self.ops, dtype=np.int32).reshape(-1, 8))
+        for kind, m in tail:
+            cur = self._emit_tail(kind, m, cur)
+        self.tail_out = cur[0]
+        self.nlev = 1 + max([b[0] for b in self.bufs if b[0] >= 0] + [0])
+        for b in self.bufs:                      # named classes were negative placeholders until nlev was known
+            if b[0] < 0:
+                b[0] = self.nlev + (-1 - b[0])
+        for o in self.ops:
+            if o[5] < 0:
+                o[5] = self.nlev + (-1 - o[5])
+        self.class_ids = dict((name, self.nlev + k) for k, name in enumerate(self._classes))
+        self.n_classes = self.nlev + len(self._classes)
+        self.ops_np = np.ascontiguousarray(np.array(self.ops, dtype=np.int32).reshape(-1, OPW))
         self.opf_np = np.ascontiguousarray(np.array(self.opf, dtype=np.float32).reshape(-1, 4))
         self.bufs_np = np.ascontiguousarray(np.array(self.bufs, dtype=np.int32).reshape(-1, 2))
-        self.subm_levels = sorted(set(o[5] for o in self.ops if o[0] == OP_SUBM))
+        self.subm_levels = sorted(set(o[5] for o in self.ops if o[0] in (OP_SUBM, OP_EXPAND)))
+        self.n_idx = 1 + max([max(o[9:12]) for o in self.ops] + [-1])
+
+    def _class(self, name):
+        if name not in self._classes:
+            self._classes.append(name)
+        return -1 - self._classes.index(name)
 
     def _new_buf(self, level, ch):
         self.bufs.append([level, ch])
@@ -65,6 +120,41 @@ class Program(object):
         out = self._emit_inner(m, cur)
         if id(m) in self._tap_modules and not isinstance(out, list):
             self.taps[id(m)] = out
+        return out
+
+    def _emit_tail(self, kind, m, cur):
+        buf, lev, ch = cur
+        if kind == 'expand':
+            if lev != 0 or not isinstance(m, M.SubmanifoldConvolution) or m.bias is not None or m.nIn != ch:
+                raise Unsupported('up-sampling convolution: level-0 input, no bias')
+            cls = self._class('child')
+            b = self._new_buf(cls, m.nOut)
+            self.ops.append(_op(OP_EXPAND, buf, -1, b, self._slot(m, ['weight'], [True]), 0, m.nIn, m.nOut))
+            self.opf.append([0, 0, 0, 0])
+            out = (b, cls, m.nOut)
+        elif kind == 'bn':
+            if not isinstance(m, M.BatchNormalization) or m.weight is None or m.nPlanes != ch:
+                raise Unsupported('non-affine BatchNormalization / channel mismatch')
+            b = self._new_buf(lev, ch)
+            s = self._slot(m, ['weight', 'bias', 'running_mean', 'running_var'], [True, True, False, False])
+            self.ops.append(_op(OP_BN, buf, -1, b, s, lev, ch, ch))
+            self.opf.append([m.eps, m.momentum, m.leakiness, 0])
+            out = (b, lev, ch)
+        elif kind == 'linear':
+            lins = list(m)
+            if not 1 <= len(lins) <= 2 or any(l.in_features != ch or l.out_features != 1 for l in lins):
+                raise Unsupported('linear heads: one or two nn.Linear(ch, 1)')
+            first = len(self.slots)
+            for l in lins:
+                self._slot(l, ['weight', 'bias'], [True, l.bias is not None])
+            b = self._new_buf(lev, len(lins))
+            self.ops.append(_op(OP_LINEAR, buf, -1, b, first, lev, ch, len(lins)))
+            self.opf.append([0, 0, 0, 0])
+            out = (b, lev, len(lins))
+            m = lins[0]
+        else:
+            raise Unsupported('tail entry %r' % (kind,))
+        self.taps[id(m)] = out
         return out
 
     def _emit_inner(self, m, cur):
@@ -87,11 +177,11 @@ class Program(object):
                     if acc[2] != nxt[2]:
                         raise Unsupported('AddTable channel mismatch')
                     b = self._new_buf(acc[1], acc[2])
-                    self.ops.append([OP_ADD, acc[0], nxt[0], b, -1, acc[1], acc[2], acc[2]])
+                    self.ops.append(_op(OP_ADD, acc[0], nxt[0], b, -1, acc[1], acc[2], acc[2]))
                     acc = (b, acc[1], acc[2])
                 else:
                     b = self._new_buf(acc[1], acc[2] + nxt[2])
-                    self.ops.append([OP_JOIN, acc[0], nxt[0], b, -1, acc[1], acc[2], nxt[2]])
+                    self.ops.append(_op(OP_JOIN, acc[0], nxt[0], b, -1, acc[1], acc[2], nxt[2]))
                     acc = (b, acc[1], acc[2] + nxt[2])
                 self.opf.append([0, 0, 0, 0])
             return acc
@@ -104,21 +194,21 @@ class Program(object):
             if m.bias is not None or m.nIn != ch:
                 raise Unsupported('SubmanifoldConvolution with bias / channel mismatch')
             b = self._new_buf(lev, m.nOut)
-            self.ops.append([OP_SUBM, buf, -1, b, self._slot(m, ['weight'], [True]), lev, m.nIn, m.nOut])
+            self.ops.append(_op(OP_SUBM, buf, -1, b, self._slot(m, ['weight'], [True]), lev, m.nIn, m.nOut))
             self.opf.append([0, 0, 0, 0])
             return (b, lev, m.nOut)
         if isinstance(m, M.Convolution):
             if m.bias is not None or m.nIn != ch:
                 raise Unsupported('Convolution with bias / channel mismatch')
             b = self._new_buf(lev + 1, m.nOut)
-            self.ops.append([OP_DOWN, buf, -1, b, self._slot(m, ['weight'], [True]), lev, m.nIn, m.nOut])
+            self.ops.append(_op(OP_DOWN, buf, -1, b, self._slot(m, ['weight'], [True]), lev, m.nIn, m.nOut))
             self.opf.append([0, 0, 0, 0])
             return (b, lev + 1, m.nOut)
         if isinstance(m, M.UnPooling):
             if lev < 1:
                 raise Unsupported('UnPooling above the input level')
             b = self._new_buf(lev - 1, ch)
-            self.ops.append([OP_UNPOOL, buf, -1, b, -1, lev - 1, ch, ch])
+            self.ops.append(_op(OP_UNPOOL, buf, -1, b, -1, lev - 1, ch, ch))
             self.opf.append([0, 0, 0, 0])
             return (b, lev - 1, ch)
         if isinstance(m, M.BatchNormalization):
@@ -126,7 +216,7 @@ class Program(object):
                 raise Unsupported('non-affine BatchNormalization / channel mismatch')
             b = self._new_buf(lev, ch)
             s = self._slot(m, ['weight', 'bias', 'running_mean', 'running_var'], [True, True, False, False])
-            self.ops.append([OP_BN, buf, -1, b, s, lev, ch, ch])
+            self.ops.append(_op(OP_BN, buf, -1, b, s, lev, ch, ch))
             self.opf.append([m.eps, m.momentum, m.leakiness, 0])
             return (b, lev, ch)
         raise Unsupported('module %s' % type(m).__name__)
@@ -141,11 +231,10 @@ class _Run(object):
     pass
 
 
-def _levels(prog, x):
-    """Grids / stride-2 rulebooks of the program's levels, built through the tensor's Metadata (host syncs for
-    the coarse row counts, exactly as the per-layer path does)."""
-    md, key = x.metadata, x.key
-    grids, downs = [x.grid()], []
+def _levels(prog, md, key, grid0):
+    """Grids / stride-2 rulebooks of the program's pyramid, through the Metadata (pre-built by Metadata.prebuild or a
+    compaction's PendingChain: no host sync here then)."""
+    grids, downs = [grid0], []
     for _ in range(prog.nlev - 1):
         if any(v % 2 for v in key):
             raise ValueError('Convolution(2,2): spatial size %s is not even' % list(key))
@@ -159,68 +248,85 @@ def _levels(prog, x):
 
 class _ProgramFn(Function):
     @staticmethod
-    def forward(ctx, x, run, *params):
+    def forward(ctx, run, *tensors):
         prog = run.prog
-        x = x.contiguous()
-        rt = runtime(x.device)
-        n_lev = prog.nlev
-        lev_n = np.array([g.n for g in run.grids], dtype=np.int64)
-        lev_ld = np.array([g.ld for g in run.grids], dtype=np.int64)
-        nbr = [0] * n_lev
+        n_ext = prog.n_ext
+        ext = [t.contiguous() for t in tensors[:n_ext]]
+        params = tensors[n_ext:]
+        dev = ext[0].device
+        rt = runtime(dev)
+        lev_n = np.zeros(prog.n_classes, dtype=np.int64)
+        lev_ld = np.zeros(prog.n_classes, dtype=np.int64)
+        for l, g in enumerate(run.grids):
+            lev_n[l], lev_ld[l] = g.n, g.ld
+        for name, cid in prog.class_ids.items():
+            lev_n[cid] = run.extra_rows[name]
+        nbr = [0] * prog.n_classes
         for l in prog.subm_levels:
             nbr[l] = run.grids[l].subm_table().data_ptr()
-        children = [d.children.data_ptr() for d in run.downs] + [0]
-        ptable = [d.ptable.data_ptr() for d in run.downs] + [0]
-        parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + [0]
+        pad = [0] * (prog.n_classes - len(run.downs))
+        children = [d.children.data_ptr() for d in run.downs] + pad
+        ptable = [d.ptable.data_ptr() for d in run.downs] + pad
+        parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + pad
         run.lev_n, run.lev_ld = lev_n, lev_ld
         run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent)]
-        run.pptr = _ptr_array([p.data_ptr() for p in params])
+        run.pptr = _ptr_array([0 if p is None else p.data_ptr() for p in params])
+        run.eptr = _ptr_array([t.data_ptr() for t in ext])
+        run.iptr = _ptr_array([t.data_ptr() for t in run.idx] + [0])
         ops, opf, bufs = prog.ops_np, prog.opf_np, prog.bufs_np
-        nops, nbuf = ops.shape[0], bufs.shape[0]
-        total = _lib.query('sgnn_prog_arena_floats', ops.ctypes.data, nops, bufs.ctypes.data, nbuf,
-                           lev_n.ctypes.data, n_lev)
-        wsb = _lib.query('sgnn_prog_ws_bytes', ops.ctypes.data, nops, lev_n.ctypes.data, n_lev)
+        nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
+        total = _lib.query('sgnn_prog_arena_floats', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
+                           lev_n.ctypes.data, ncls)
+        wsb = _lib.query('sgnn_prog_ws_bytes', ops.ctypes.data, nops, lev_n.ctypes.data, ncls)
         run.total, run.wsb = total, wsb
-        arena = torch.empty(total, dtype=torch.float32, device=x.device)
+        arena = torch.empty(total, dtype=torch.float32, device=dev)
         ws = rt.workspace(wsb)
         keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away
         keep[run.out_bufs] = 1
-        _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf,
+        _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, n_lev, run.pptr.ctypes.data, len(params),
-                  x.data_ptr(), arena.data_ptr(), total, keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, ncls, run.pptr.ctypes.data, len(params),
+                  run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), total,
+                  keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
         run.offsets = {}
         outs = []
         for b in run.out_bufs:
-            off = _lib.query('sgnn_prog_buffer_offset', ops.ctypes.data, nops, bufs.ctypes.data, nbuf,
-                             lev_n.ctypes.data, n_lev, b)
+            off = _lib.query('sgnn_prog_buffer_offset', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
+                             lev_n.ctypes.data, ncls, b)
             rows, ch = int(lev_n[bufs[b, 0]]), int(bufs[b, 1])
             run.offsets[b] = (off, rows, ch)
             outs.append(arena[off:off + rows * ch].view(rows, ch))
         ctx.run = run
-        ctx.save_for_backward(x, arena, *params)
+        ctx.save_for_backward(arena, *ext, *[p for p in params if p is not None])
+        ctx.param_none = [p is None for p in params]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         run = ctx.run
         prog = run.prog
-        x, arena = ctx.saved_tensors[0], ctx.saved_tensors[1]
-        params = ctx.saved_tensors[2:]
-        rt = runtime(x.device)
+        n_ext = prog.n_ext
+        saved = ctx.saved_tensors
+        arena, ext = saved[0], saved[1:1 + n_ext]
+        it = iter(saved[1 + n_ext:])
+        params = [None if none else next(it) for none in ctx.param_none]
+        dev = arena.device
+        rt = runtime(dev)
         ops, opf, bufs = prog.ops_np, prog.opf_np, prog.bufs_np
-        nops, nbuf = ops.shape[0], bufs.shape[0]
-        garena = torch.empty(run.total, dtype=torch.float32, device=x.device)
-        ginit = np.zeros(nbuf, dtype=np.int32)
+        nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
+        garena = torch.empty(run.total, dtype=torch.float32, device=dev)
+        gout = [0] * nbuf
+        held = []
         for b, g in zip(run.out_bufs, gouts):
             if g is None:
                 continue
-            off, rows, ch = run.offsets[b]
-            garena[off:off + rows * ch].view(rows, ch).copy_(g)
-            ginit[b] = 1
+            g = g.contiguous()
+            held.append(g)
+            gout[b] = g.data_ptr()
+        gout = _ptr_array(gout)
         # one flat gradient tensor for all trainable slots
-        sizes = [p.numel() if t else 0 for p, t in zip(params, prog.grad_slot)]
-        flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=x.device)
+        sizes = [p.numel() if (t and p is not None) else 0 for p, t in zip(params, prog.grad_slot)]
+        flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=dev)
         gptr, views, o = [], [], 0
         for p, s in zip(params, sizes):
             if s:
@@ -232,34 +338,37 @@ class _ProgramFn(Function):
                 gptr.append(0)
                 views.append(None)
         gp = _ptr_array(gptr)
-        need_dx = bool(ctx.needs_input_grad[0])
+        gext = [torch.empty_like(t) if ctx.needs_input_grad[1 + i] else None for i, t in enumerate(ext)]
+        geptr = _ptr_array([0 if t is None else t.data_ptr() for t in gext])
         ws = rt.workspace(run.wsb)
         rt.side_lane(run.wsb)
-        _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf,
+        _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, prog.nlev, run.pptr.ctypes.data, gp.ctypes.data,
-                  len(params), x.data_ptr(), arena.data_ptr(), garena.data_ptr(), run.total, ginit.ctypes.data,
-                  int(need_dx), int(run.training), ws.data_ptr(), run.wsb)
-        dx = None
-        if need_dx:
-            off0 = _lib.query('sgnn_prog_buffer_offset', ops.ctypes.data, nops, bufs.ctypes.data, nbuf,
-                              run.lev_n.ctypes.data, prog.nlev, 0)
-            dx = garena[off0:off0 + x.numel()].view_as(x)
-        return (dx, None) + tuple(views)
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, ncls, run.pptr.ctypes.data, gp.ctypes.data,
+                  len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
+                  arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, int(run.training), ws.data_ptr(),
+                  run.wsb)
+        return (None,) + tuple(gext) + tuple(views)
 
 
-def compile_or_none(chain, in_channels, tap_modules=()):
+def compile_or_none(chain, in_channels, tap_modules=(), sources=None, tail=()):
     try:
-        return Program(chain, in_channels, tap_modules)
+        return Program(chain, in_channels, tap_modules, sources, tail)
     except Unsupported:
         return None
 
 
-def run_program(prog, x, training, out_bufs=None):
-    """x: SparseConvNetTensor at the program's level 0.  Returns (list of output feature tensors, grids, downs)."""
+def run_program(prog, x, training, out_bufs=None, ext=None, idx=(), extra_rows=None):
+    """x: SparseConvNetTensor at the program's level 0 (its features are the external input unless `ext` lists the
+    program's source tensors).  Returns (list of output feature tensors, grids, downs)."""
     run = _Run()
     run.prog, run.training = prog, training
-    run.grids, run.downs = _levels(prog, x)
+    run.grids, run.downs = _levels(prog, x.metadata, x.key, x.grid())
     run.out_bufs = list(out_bufs) if out_bufs is not None else [prog.out]
-    outs = _ProgramFn.apply(x.features, run, *prog.tensors())
+    run.idx = list(idx)
+    run.extra_rows = dict(extra_rows or {})
+    if 'child' in prog.class_ids and 'child' not in run.extra_rows:
+        run.extra_rows['child'] = 8 * run.grids[0].n
+    tensors = [x.features] if ext is None else list(ext)
+    outs = _ProgramFn.apply(run, *tensors, *prog.tensors())
     return list(outs), run.grids, run.downs

@@ -322,6 +322,23 @@ int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int
                         int mask_mode, const double *sums, const float *gout2, float *dvals,
                         sgnn_stream_t stream);
 
+/* Targets of the hierarchical loss in three launches — compute_targets + compute_weights_missing_geo
+ * (torch/loss.py:15-32, 35-48): tsdf = clamp(sdf, +-trunc); hier_last = tsdf; occ_last = |tsdf| < trunc with UNK_ID (-1)
+ * where known >= 2 (masking); w_last = weight_missing_geo off the input sites, 1 on them; and for the ncoarse (<= 3)
+ * coarser levels, listed from the second finest downwards in the host pointer arrays hier_in / occ / w / hier:
+ * occ = 2x2x2 max-pool of the level above, w = that level's w[::2,::2,::2], hier = clamp(hier_in).  w_last NULL: no
+ * weights.  input_locs = the (n_locs, 4) int64 [z,y,x,b] input sites.  Dimensions must be divisible by 2^ncoarse. */
+int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *input_locs, int64_t n_locs, int batch,
+                      int d0, int d1, int d2, float trunc, int masking, float weight_missing_geo, int ncoarse,
+                      void *const *hier_in, float *tsdf, float *hier_last, float *occ_last, float *w_last,
+                      void *const *occ, void *const *w, void *const *hier, sgnn_stream_t stream);
+/* total = sum_i coef[i] * out2s[i] over the (bce, l1) pairs sgnn_loss_level_fwd produced for all levels (n <= 10
+ * floats; coef is a HOST array, entries of unused slots 0), cur[l] = out2s[2l] + out2s[2l+1] restricted to used slots;
+ * and the gradient fan-out g2[i] = g[0] * coef[i] that sgnn_loss_level_bwd consumes (torch/loss.py:160-199). */
+int sgnn_loss_combine(const float *out2s, const float *coef_host, int n, float *total, float *cur,
+                      sgnn_stream_t stream);
+int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *g2, sgnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Sparse-network programs: a static sub-network (what the reference composes from scn.Sequential /
  * ConcatTable / AddTable / JoinTable containers, torch/model.py:31-47, 178-188, 253-257) compiled into a

@@ -4,14 +4,17 @@
 TAG=$1; PYT=$2; STEPS=${3:-30}
 mkdir -p gpurun_out
 if [ -n "$PYT" ]; then
-  timeout 1500 python -m pytest $PYT -x -q > gpurun_out/${TAG}_tests.log 2>&1
+  timeout -k 10 ${TEST_TIMEOUT:-600} python -m pytest $PYT -x -q > gpurun_out/${TAG}_tests.log 2>&1
+  RC=$?
   tail -5 gpurun_out/${TAG}_tests.log
+  if [ $RC -ne 0 ]; then echo "tests failed (rc $RC): skipping bench/profile"; grep -n "Error\|error\|Abort" gpurun_out/${TAG}_tests.log | head -10; exit 1; fi
 fi
-timeout 600 python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout -k 10 200 python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+[ -s gpurun_out/${TAG}_bench.json ] || { echo "bench failed"; tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
 cat gpurun_out/${TAG}_bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value'], d['unit'], d['ms_per_step'], 'ms/step', 'frac', d['roofline']['frac'], d['config']['generated_sites_per_level'])"
 export TMPDIR=/tmp; D=/tmp/prof_$TAG; rm -rf $D
 ROOT=$(pwd)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)
+(cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)
 tail -3 $ROOT/gpurun_out/${TAG}_prof.err
 F=$(find $D -name '*kernel_stats.csv' | head -1)
 if [ -n "$F" ]; then

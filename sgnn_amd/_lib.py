@@ -67,6 +67,10 @@ PROTOTYPES = {
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_loss_level_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_loss_targets': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_loss_combine': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'sgnn_loss_combine_bwd': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32]),
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32]),

@@ -483,28 +483,23 @@ SGNN_EXPORT int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t
 //   (j,i) = (0,0): {-1}   (0,1): {0,+1}   (1,0): {-1,0}   (1,1): {+1}.
 // S[g*8+i] = parent-table row of (g,i), ST = 26 - S (mirrored row: data gradient), PAR = g.
 // ---------------------------------------------------------------------------
-struct ExpandMaps {
-  int32_t v[192];
-};
-constexpr ExpandMaps make_expand_maps() {
-  ExpandMaps m{};
-  for (int g = 0; g < 8; ++g)
-    for (int i = 0; i < 8; ++i) {
-      const int o0 = ((i >> 2) & 1) - 1 + ((g >> 2) & 1), o1 = ((i >> 1) & 1) - 1 + ((g >> 1) & 1),
-                o2 = (i & 1) - 1 + (g & 1);
-      const int srow = (o0 + 1) * 9 + (o1 + 1) * 3 + (o2 + 1);
-      m.v[g * 8 + i] = srow;
-      m.v[64 + g * 8 + i] = 26 - srow;
-      m.v[128 + g * 8 + i] = g;
-    }
-  return m;
-}
-__device__ const ExpandMaps g_expand_maps = make_expand_maps();
+__device__ int32_t g_expand_maps[192];
 
-// device pointers to S, ST, PAR (64 ints each)
+// device pointers to S, ST, PAR (64 ints each); the table is uploaded on first use
 int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR) {
   static const int32_t *base = nullptr;
   if (!base) {
+    int32_t host[192];
+    for (int g = 0; g < 8; ++g)
+      for (int i = 0; i < 8; ++i) {
+        const int o0 = ((i >> 2) & 1) - 1 + ((g >> 2) & 1), o1 = ((i >> 1) & 1) - 1 + ((g >> 1) & 1),
+                  o2 = (i & 1) - 1 + (g & 1);
+        const int srow = (o0 + 1) * 9 + (o1 + 1) * 3 + (o2 + 1);
+        host[g * 8 + i] = srow;
+        host[64 + g * 8 + i] = 26 - srow;
+        host[128 + g * 8 + i] = g;
+      }
+    SGNN_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_expand_maps), host, sizeof(host)));
     void *p = nullptr;
     SGNN_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_expand_maps)));
     base = (const int32_t *)p;

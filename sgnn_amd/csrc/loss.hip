@@ -182,3 +182,189 @@ SGNN_EXPORT int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int 
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Targets of the hierarchical loss — compute_targets + compute_weights_missing_geo (torch/loss.py:15-32, :35-48) in
+// three launches instead of ~35 tensor ops and an int32 volume:
+//   fine   : tsdf = clamp(sdf); hier[L-1] = tsdf; occ[L-1] = |tsdf| < trunc (UNK_ID where known >= 2);
+//            w[L-1] = (|occ| <= trunc) ? weight_missing_geo : 1           (every voxel treated as "not an input site")
+//   sites  : w[L-1] = 1 at the input sites   (loss.py:42-45: 1 + 1 + 3 = 5 != 4)
+//   coarse : occ[h] = 2x2x2 max of occ[h+1]; w[h] = w[h+1][::2,::2,::2]; hier[h] = clamp(hierarchy[h]) for the (up to
+//            three) coarser levels, one wave per 8^3 fine voxels (4x4x4 voxels of level L-2), maxima by lane shuffles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_targets_fine(const float *__restrict__ sdf, const uint8_t *__restrict__ known,
+                                                     int64_t total, float trunc, int masking, float wmg,
+                                                     float *__restrict__ tsdf, float *__restrict__ hier_last,
+                                                     float *__restrict__ occ, float *__restrict__ w) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const float t = fminf(fmaxf(sdf[i], -trunc), trunc);          // clamp keeps -inf -> -trunc, like torch.clamp_
+    tsdf[i] = t;
+    hier_last[i] = t;
+    float o = fabsf(t) < trunc ? 1.f : 0.f;
+    if (masking && known[i] >= UNK_THRESH_U8) o = UNK_ID_F;
+    occ[i] = o;
+    if (w) w[i] = (fabsf(o) <= trunc) ? wmg : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_targets_sites(const int64_t *__restrict__ locs, int64_t n, int batch, int d0,
+                                                      int d1, int d2, float *__restrict__ w) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+    const longlong2 p0 = reinterpret_cast<const longlong2 *>(locs)[2 * r];
+    const longlong2 p1 = reinterpret_cast<const longlong2 *>(locs)[2 * r + 1];
+    if (p0.x < 0 || p0.x >= d0 || p0.y < 0 || p0.y >= d1 || p1.x < 0 || p1.x >= d2 || p1.y < 0 || p1.y >= batch) continue;
+    w[((p1.y * d0 + p0.x) * d1 + p0.y) * d2 + p1.x] = 1.f;
+  }
+}
+
+struct CoarseArgs {
+  const float *occ_f, *w_f;          // finest level (B, d0, d1, d2)
+  const float *hier_in[3];           // hierarchy inputs of levels L-2, L-3, L-4 (NULL: level absent)
+  float *occ[3], *w[3], *hier[3];    // outputs of those levels (w[k] NULL when weights are off)
+  int batch, d0, d1, d2;             // FINE dims; level L-2-k has dims d >> (k+1)
+  float trunc;
+  int nlev;                          // coarse levels to produce (1..3)
+};
+
+__global__ __launch_bounds__(256) void k_targets_coarse(CoarseArgs a) {
+  // one wave = one 4x4x4 brick of level L-2 voxels; lane = (lz*4 + ly)*4 + lx
+  const int lane = threadIdx.x & 63;
+  const int lz = lane >> 4, ly = (lane >> 2) & 3, lx = lane & 3;
+  const int c0 = a.d0 >> 1, c1 = a.d1 >> 1, c2 = a.d2 >> 1;                       // level L-2 dims
+  const int b0 = (c0 + 3) >> 2, b1 = (c1 + 3) >> 2, b2 = (c2 + 3) >> 2;           // bricks per axis
+  const int64_t bricks = (int64_t)a.batch * b0 * b1 * b2;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t br = wave0; br < bricks; br += nwaves) {
+    int64_t t = br;
+    const int bx = (int)(t % b2); t /= b2;
+    const int by = (int)(t % b1); t /= b1;
+    const int bz = (int)(t % b0);
+    const int b = (int)(t / b0);
+    const int z = bz * 4 + lz, y = by * 4 + ly, x = bx * 4 + lx;
+    const bool in = z < c0 && y < c1 && x < c2;
+    float m = -INFINITY;
+    if (in) {
+      const float *p = a.occ_f + (((int64_t)b * a.d0 + 2 * z) * a.d1 + 2 * y) * a.d2 + 2 * x;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const float2 v = *reinterpret_cast<const float2 *>(p + ((int64_t)dz * a.d1 + dy) * a.d2);
+          m = fmaxf(m, fmaxf(v.x, v.y));
+        }
+      const int64_t o = (((int64_t)b * c0 + z) * c1 + y) * c2 + x;
+      a.occ[0][o] = m;
+      if (a.w[0]) a.w[0][o] = a.w_f[(((int64_t)b * a.d0 + 2 * z) * a.d1 + 2 * y) * a.d2 + 2 * x];
+      a.hier[0][o] = fminf(fmaxf(a.hier_in[0][o], -a.trunc), a.trunc);
+    }
+    if (a.nlev >= 2) {   // level L-3: max over the 2x2x2 lanes that differ in the low bit of lz, ly, lx
+      m = fmaxf(m, __shfl_xor(m, 1));
+      m = fmaxf(m, __shfl_xor(m, 4));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      const int e0 = c0 >> 1, e1 = c1 >> 1, e2 = c2 >> 1;
+      const int zz = z >> 1, yy = y >> 1, xx = x >> 1;
+      if (((lz | ly | lx) & 1) == 0 && zz < e0 && yy < e1 && xx < e2) {
+        const int64_t o = (((int64_t)b * e0 + zz) * e1 + yy) * e2 + xx;
+        a.occ[1][o] = m;
+        if (a.w[1]) a.w[1][o] = a.w_f[(((int64_t)b * a.d0 + 4 * zz) * a.d1 + 4 * yy) * a.d2 + 4 * xx];
+        a.hier[1][o] = fminf(fmaxf(a.hier_in[1][o], -a.trunc), a.trunc);
+      }
+      if (a.nlev >= 3) {   // level L-4: the whole brick
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fmaxf(m, __shfl_xor(m, 8));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const int f0 = e0 >> 1, f1 = e1 >> 1, f2 = e2 >> 1;
+        if (lane == 0 && bz < f0 && by < f1 && bx < f2) {
+          const int64_t o = (((int64_t)b * f0 + bz) * f1 + by) * f2 + bx;
+          a.occ[2][o] = m;
+          if (a.w[2]) a.w[2][o] = a.w_f[(((int64_t)b * a.d0 + 8 * bz) * a.d1 + 8 * by) * a.d2 + 8 * bx];
+          a.hier[2][o] = fminf(fmaxf(a.hier_in[2][o], -a.trunc), a.trunc);
+        }
+      }
+    }
+  }
+}
+
+// all outputs are caller-allocated; hier_in / occ / w / hier list the coarser levels from L-2 downwards (host arrays of
+// device pointers, ncoarse = L - 1 <= 3); w_last NULL (and w entries NULL) switches the weights off.  Every dimension
+// must be divisible by 2^ncoarse (MaxPool3d(2) floors otherwise; the caller falls back to tensor ops then).
+SGNN_EXPORT int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *input_locs, int64_t n_locs,
+                                  int batch, int d0, int d1, int d2, float trunc, int masking, float weight_missing_geo,
+                                  int ncoarse, void *const *hier_in, float *tsdf, float *hier_last, float *occ_last,
+                                  float *w_last, void *const *occ, void *const *w, void *const *hier,
+                                  sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(batch >= 0 && d0 >= 1 && d1 >= 1 && d2 >= 1 && ncoarse >= 0 && ncoarse <= 3 && n_locs >= 0);
+  SGNN_CHECK_ARG((d0 % (1 << ncoarse)) == 0 && (d1 % (1 << ncoarse)) == 0 && (d2 % (1 << ncoarse)) == 0);
+  const int64_t total = (int64_t)batch * d0 * d1 * d2;
+  if (total == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(sdf && tsdf && hier_last && occ_last && (!masking || known) && (!w_last || n_locs == 0 || input_locs));
+  SGNN_CHECK_ARG(ncoarse == 0 || (hier_in && occ && hier && (!w_last || w)));
+  hipLaunchKernelGGL(k_targets_fine, dim3(sgnn_grid_for(total, 256, 4096)), dim3(256), 0, s, sdf, known, total, trunc,
+                     masking, weight_missing_geo, tsdf, hier_last, occ_last, w_last);
+  if (w_last && n_locs > 0)
+    hipLaunchKernelGGL(k_targets_sites, dim3(sgnn_grid_for(n_locs, 256, 4096)), dim3(256), 0, s, input_locs, n_locs,
+                       batch, d0, d1, d2, w_last);
+  if (ncoarse > 0) {
+    CoarseArgs a{};
+    a.occ_f = occ_last;
+    a.w_f = w_last;
+    for (int k = 0; k < ncoarse; ++k) {
+      SGNN_CHECK_ARG(hier_in[k] && occ[k] && hier[k] && (!w_last || w[k]));
+      a.hier_in[k] = (const float *)hier_in[k];
+      a.occ[k] = (float *)occ[k];
+      a.w[k] = w_last ? (float *)w[k] : nullptr;
+      a.hier[k] = (float *)hier[k];
+    }
+    a.batch = batch; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.trunc = trunc; a.nlev = ncoarse;
+    const int64_t bricks = (int64_t)batch * ((d0 / 2 + 3) / 4) * ((d1 / 2 + 3) / 4) * ((d2 / 2 + 3) / 4);
+    hipLaunchKernelGGL(k_targets_coarse, dim3(sgnn_grid_for(bricks, 4, 8192)), dim3(256), 0, s, a);
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// loss = sum_i coef[i] * out2s[i]  over the (bce, l1) pairs of all levels (torch/loss.py:160-199), per-level values
+// cur[l] = out2s[2l] + out2s[2l+1] for logging, and the matching gradient fan-out g2[i] = g * coef[i].
+// ---------------------------------------------------------------------------
+struct Coef10 {
+  float c[10];
+};
+
+__global__ void k_loss_combine(const float *__restrict__ out2s, Coef10 coef, int n, float *__restrict__ total,
+                               float *__restrict__ cur) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (coef.c[i] != 0.f) t += coef.c[i] * out2s[i];
+    *total = t;
+    for (int l = 0; 2 * l < n; ++l)
+      cur[l] = (coef.c[2 * l] != 0.f ? out2s[2 * l] : 0.f) + (coef.c[2 * l + 1] != 0.f ? out2s[2 * l + 1] : 0.f);
+  }
+}
+
+__global__ void k_loss_combine_bwd(const float *__restrict__ g, Coef10 coef, int n, float *__restrict__ g2) {
+  if (threadIdx.x < n && blockIdx.x == 0) g2[threadIdx.x] = g[0] * coef.c[threadIdx.x];
+}
+
+SGNN_EXPORT int sgnn_loss_combine(const float *out2s, const float *coef_host, int n, float *total, float *cur,
+                                  sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(out2s && coef_host && total && cur && n >= 1 && n <= 10);
+  Coef10 c{};
+  for (int i = 0; i < n; ++i) c.c[i] = coef_host[i];
+  hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, out2s, c, n, total, cur);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *g2, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(g && coef_host && g2 && n >= 1 && n <= 10);
+  Coef10 c{};
+  for (int i = 0; i < n; ++i) c.c[i] = coef_host[i];
+  hipLaunchKernelGGL(k_loss_combine_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g, c, n, g2);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}

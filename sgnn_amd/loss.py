@@ -31,6 +31,66 @@ def compute_targets(target, hierarchy, num_hierarchy_levels, truncation, use_los
     return target_for_sdf, target_for_occs, target_for_hier
 
 
+def _targets_fusable(target, hierarchy, L, known, use_loss_masking, input_locs=None):
+    if not (FUSED and target.is_cuda and target.dtype == torch.float32 and target.dim() == 5 and 1 <= L <= 4):
+        return False
+    if any(int(d) % (1 << (L - 1)) for d in target.shape[2:]) or target.shape[1] != 1:
+        return False
+    if use_loss_masking and (known is None or known.dtype != torch.uint8 or not known.is_cuda):
+        return False
+    if input_locs is not None and (input_locs.dtype != torch.int64 or input_locs.device != target.device):
+        return False
+    return all(h.is_cuda and h.dtype == torch.float32 for h in hierarchy[:L - 1])
+
+
+def compute_targets_and_weights(target, hierarchy, num_hierarchy_levels, truncation, use_loss_masking, known,
+                                weight_missing_geo=1.0, input_locs=None):
+    """compute_targets + compute_weights_missing_geo (loss.py:15-48) -> ((tsdf, occs, hiers), weights or None).
+    On the device this is sgnn_loss_targets: three launches, inputs left untouched (no clones needed)."""
+    L = num_hierarchy_levels
+    want_w = weight_missing_geo > 1
+    if not _targets_fusable(target, hierarchy, L, known, use_loss_masking, input_locs if want_w else None):
+        t = compute_targets(target.clone(), [h.clone() for h in hierarchy], L, truncation, use_loss_masking, known)
+        w = compute_weights_missing_geo(weight_missing_geo, input_locs, t[1], truncation) if want_w else None
+        return t, w
+    from . import _lib
+    import numpy as np
+    target = target.contiguous()
+    B, _, d0, d1, d2 = (int(v) for v in target.shape)
+    dev = target.device
+    new = lambda k: torch.empty(B, 1, d0 >> k, d1 >> k, d2 >> k, dtype=torch.float32, device=dev)
+    tsdf, occs, hiers = new(0), [None] * L, [None] * L
+    weights = [None] * L if want_w else None
+    occs[-1], hiers[-1] = new(0), new(0)
+    if want_w:
+        weights[-1] = new(0)
+    arr = {'hin': [], 'occ': [], 'w': [], 'hier': []}
+    held = []
+    for k in range(1, L):
+        h = L - 1 - k
+        occs[h], hiers[h] = new(k), new(k)
+        hin = hierarchy[h].contiguous()
+        assert tuple(hin.shape) == tuple(occs[h].shape), 'hierarchy level %d has shape %s' % (h, tuple(hin.shape))
+        held.append(hin)
+        arr['hin'].append(hin.data_ptr())
+        arr['occ'].append(occs[h].data_ptr())
+        arr['hier'].append(hiers[h].data_ptr())
+        if want_w:
+            weights[h] = new(k)
+            arr['w'].append(weights[h].data_ptr())
+        else:
+            arr['w'].append(0)
+    ptrs = dict((k, np.ascontiguousarray(np.array(v + [0], dtype=np.uint64))) for k, v in arr.items())
+    locs = input_locs.contiguous() if want_w else None
+    kn = known.contiguous() if use_loss_masking else None
+    _lib.call('sgnn_loss_targets', _lib.ptr(target), _lib.ptr(kn), _lib.ptr(locs), 0 if locs is None else int(locs.shape[0]),
+              B, d0, d1, d2, float(truncation), int(bool(use_loss_masking)), float(weight_missing_geo), L - 1,
+              ptrs['hin'].ctypes.data, _lib.ptr(tsdf), _lib.ptr(hiers[-1]), _lib.ptr(occs[-1]),
+              _lib.ptr(weights[-1]) if want_w else None, ptrs['occ'].ctypes.data, ptrs['w'].ctypes.data,
+              ptrs['hier'].ctypes.data)
+    return (tsdf, occs, hiers), weights
+
+
 def _flat(locs, dims):
     return ((locs[:, 3] * dims[0] + locs[:, 0]) * dims[1] + locs[:, 1]) * dims[2] + locs[:, 2]
 
@@ -124,9 +184,100 @@ class _LevelLoss(torch.autograd.Function):
         return (dvals,) + (None,) * 9
 
 
+class _TotalLoss(torch.autograd.Function):
+    """The whole hierarchical loss (loss.py:160-199) as one autograd node: per level sgnn_loss_level_fwd, then
+    sgnn_loss_combine for  sum_l weight_l * (bce_l + l1_l);  backward fans the incoming gradient out to the levels
+    (sgnn_loss_combine_bwd) and runs sgnn_loss_level_bwd per level.  `levels` = list of dicts (locs, tgt_occ, tgt_sdf,
+    weights, known, occ_col, sdf_col, mask_mode, coef (bce, l1)); vals_l are the differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, levels, use_log, *vals):
+        from . import _lib
+        from .scn.metadata import runtime
+        import numpy as np
+        dev = vals[0].device
+        rt = runtime(dev)
+        n = len(levels)
+        out2s = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+        sums = torch.empty(n, 3, dtype=torch.float64, device=dev)
+        wsb = _lib.query('sgnn_loss_ws_bytes')
+        ws = rt.workspace(wsb)
+        args_all, coef, held = [], [], []
+        for l, (lv, v) in enumerate(zip(levels, vals)):
+            v = v.contiguous()
+            locs = lv['locs'].contiguous()
+            dims = lv['tgt_sdf'].shape[2:]
+            m, vstride = v.shape
+            args = (_lib.ptr(locs), _lib.ptr(v), vstride, lv['occ_col'], lv['sdf_col'], _lib.ptr(lv['tgt_occ']),
+                    _lib.ptr(lv['tgt_sdf']), _lib.ptr(lv['weights']), _lib.ptr(lv['known']), int(dims[0]), int(dims[1]),
+                    int(dims[2]), m, int(use_log), lv['mask_mode'])
+            _lib.call('sgnn_loss_level_fwd', *args, sums[l].data_ptr(), out2s.data_ptr() + 8 * l, _lib.ptr(ws), wsb)
+            args_all.append(args)
+            held.append((locs, v))
+            coef += [float(lv['coef'][0]), float(lv['coef'][1])]
+        coef_np = np.ascontiguousarray(np.array(coef, dtype=np.float32))
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        cur = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.call('sgnn_loss_combine', out2s.data_ptr(), coef_np.ctypes.data, 2 * n, total.data_ptr(), cur.data_ptr())
+        ctx.keep = (levels, held, args_all, sums, coef_np)
+        ctx.mark_non_differentiable(cur)
+        return total, cur
+
+    @staticmethod
+    def backward(ctx, g, _g_cur):
+        from . import _lib
+        levels, held, args_all, sums, coef_np = ctx.keep
+        n = len(levels)
+        g = g.contiguous().view(1)
+        g2 = torch.empty(2 * n, dtype=torch.float32, device=g.device)
+        _lib.call('sgnn_loss_combine_bwd', g.data_ptr(), coef_np.ctypes.data, 2 * n, g2.data_ptr())
+        grads = []
+        for l in range(n):
+            dv = torch.empty_like(held[l][1])
+            _lib.call('sgnn_loss_level_bwd', *args_all[l], sums[l].data_ptr(), g2.data_ptr() + 8 * l, dv.data_ptr())
+            grads.append(dv)
+        return (None, None) + tuple(grads)
+
+
 def _fusable(vals, *dense):
     return (FUSED and torch.is_tensor(vals) and vals.is_cuda and vals.dtype == torch.float32 and
             all(d is None or (d.is_cuda and d.is_contiguous()) for d in dense))
+
+
+def _compute_loss_fused(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights,
+                        use_log_transform, use_loss_masking, known, weights):
+    """compute_loss through _TotalLoss when every active level is fusable; None otherwise."""
+    levels, vals, slot = [], [], []
+    for h in range(len(output_occs)):
+        if len(output_occs[h][0]) == 0 or loss_weights[h] == 0:
+            slot.append(None)
+            continue
+        locs, v = output_occs[h]
+        if not (_fusable(v, target_for_occs[h], target_for_hier[h], weights[h]) and
+                target_for_occs[h].dtype == torch.float32):
+            return None
+        lw = float(loss_weights[h])
+        levels.append(dict(locs=locs, tgt_occ=target_for_occs[h], tgt_sdf=target_for_hier[h], weights=weights[h],
+                           known=None, occ_col=0, sdf_col=1, mask_mode=1 if use_loss_masking else 0, coef=(lw, lw)))
+        vals.append(v)
+        slot.append(len(levels) - 1)
+    if len(output_sdf[0]) > 0 and loss_weights[-1] > 0:
+        v = output_sdf[1]
+        if not (_fusable(v, target_for_sdf, weights[-1], known if use_loss_masking else None) and
+                (not use_loss_masking or known.dtype == torch.uint8)):
+            return None
+        levels.append(dict(locs=output_sdf[0], tgt_occ=None, tgt_sdf=target_for_sdf, weights=weights[-1],
+                           known=known if use_loss_masking else None, occ_col=-1, sdf_col=0,
+                           mask_mode=2 if use_loss_masking else 0, coef=(0.0, float(loss_weights[-1]))))
+        vals.append(v)
+        slot.append(len(levels) - 1)
+    else:
+        slot.append(None)
+    if not levels or len(levels) > 5:
+        return None
+    total, cur = _TotalLoss.apply(levels, bool(use_log_transform), *vals)
+    losses = [-1 if k is None else cur[k] for k in slot]
+    return total, losses
 
 
 def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier, loss_weights, truncation,
@@ -138,6 +289,13 @@ def compute_loss(output_sdf, output_occs, target_for_sdf, target_for_occs, targe
     and weights on a second stream while the encoder runs)."""
     assert len(output_occs) == len(target_for_occs)
     loss, losses = 0.0, []
+    if weights is None and weight_missing_geo <= 1:
+        weights = [None] * len(target_for_occs)
+    if weights is not None:
+        fused = _compute_loss_fused(output_sdf, output_occs, target_for_sdf, target_for_occs, target_for_hier,
+                                    loss_weights, use_log_transform, use_loss_masking, known, weights)
+        if fused is not None:
+            return fused
     if weights is None:
         weights = [None] * len(target_for_occs)
         if weight_missing_geo > 1:

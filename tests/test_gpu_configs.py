@@ -1,0 +1,242 @@
+"""Parity at the sizes BASELINE.json names: the HIP path against the oracle on
+  configs[1]  32 x 64^3 surface blocks (~366 k input sites): level-0 rulebook, <16,16> and <48,16> convolutions (forward,
+              data and weight gradients), BatchNormReLU on the full level; GenModel forward at 64^3, batch 4
+  configs[4]  one 128^3 block at 20 % i.i.d. occupancy (~419 k sites): rulebook, stride-2 site set / parents / children,
+              <16,16> convolution fwd/dX/dW, GenModel forward (site lists exact at every level)
+  configs[3]  a (64,256,256) scene through update_sizes: size-independent properties of every generated level
+and the raw-buffer guard (a slab > 4 GiB must be refused, not wrapped).
+Site lists / rulebooks bit-identical; features within 1e-4 (north_star) of the values' scale.  The UNSCALED maximum
+absolute errors are printed and appended to gpurun_out/parity_report.txt (copied into BASELINE.md §4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scn_oracle as oscn
+import model_oracle as mo
+from util import random_sites, param_fill, copy_params
+from sgnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4
+
+
+def report(line):
+    print(line)
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_report.txt'), 'a') as f:
+            f.write(line + '\n')
+
+
+def _fast_oracle():
+    """The oracle's C/OpenMP mode for its two hot loops (held to the torch-op mode by tests/test_oracle_fast.py)."""
+    from scn_oracle import _fast
+    oscn.FAST = bool(_fast.available)
+
+
+def _close(tag, got, want, tol=TOL):
+    got, want = got.detach().cpu().double(), want.detach().double()
+    err = (got - want).abs().max().item()
+    scale = max(1.0, want.abs().max().item())
+    report('%-58s max|err| %.3e   max|ref| %.3e   rows %d' % (tag, err, want.abs().max().item(), want.shape[0]))
+    assert err <= tol * scale, '%s: %g > %g' % (tag, err, tol * scale)
+
+
+def _level_ops(tag, locs, size, shapes):
+    import sgnn_amd.scn as scn
+    _fast_oracle()
+    try:
+        n = locs.shape[0]
+        xo = oscn.InputLayer(3, size, mode=0)([locs, torch.zeros(n, 1)])
+        xh = scn.InputLayer(3, size, mode=0)([locs.cuda(), torch.zeros(n, 1).cuda()])
+        g = xh.grid()
+        nbr = xo.metadata.grid(xo.spatial_size).subm_rules(3)
+        got = g.subm_table().view(27, g.ld)[:, :n].cpu().numpy()
+        assert np.array_equal(got, nbr.astype(np.int32)), tag + ': 3x3x3 rulebook differs'
+        assert (g.subm_table().view(27, g.ld)[:, n:] == -1).all()
+        report('%-58s rulebook identical: %d sites, %d rules (R/N %.1f)' % (tag, n, int((nbr >= 0).sum()),
+                                                                              (nbr >= 0).sum() / float(n)))
+        for cin, cout in shapes:
+            torch.manual_seed(cin * 100 + cout)
+            feats = torch.randn(n, cin)
+            fo, fh = feats.clone().requires_grad_(True), feats.clone().cuda().requires_grad_(True)
+            co, ch = oscn.SubmanifoldConvolution(3, cin, cout, 3, False), scn.SubmanifoldConvolution(3, cin, cout, 3, False).cuda()
+            copy_params(co, ch)
+            bo, bh = oscn.BatchNormReLU(cout), scn.BatchNormReLU(cout).cuda()
+            yo = co(oscn.InputLayer(3, size, mode=0)([locs, fo]))
+            yh = ch(scn.InputLayer(3, size, mode=0)([locs.cuda(), fh]))
+            _close('%s conv<%d,%d> forward' % (tag, cin, cout), yh.features, yo.features)
+            zo, zh = bo(yo).features, bh(yh).features
+            _close('%s BatchNormReLU(%d) forward' % (tag, cout), zh, zo)
+            _close('%s BatchNormReLU(%d) running_var' % (tag, cout), bh.running_var, bo.running_var)
+            go = torch.randn(n, cout)
+            zo.backward(go)
+            zh.backward(go.cuda())
+            _close('%s conv<%d,%d> data gradient (through BN)' % (tag, cin, cout), fh.grad, fo.grad)
+            _close('%s conv<%d,%d> weight gradient' % (tag, cin, cout), ch.weight.grad, co.weight.grad,
+                   tol=1e-4 * max(1.0, np.sqrt(n) / 100))      # sums of n terms: fp32 summation-order noise ~ sqrt(n) ulp
+    finally:
+        oscn.FAST = False
+
+
+def test_config1_full_level_ops():
+    data = synth.make_batch(32, (64, 64, 64), cfg=2)
+    locs = data['input'][0]
+    assert locs.shape[0] > 300000
+    _level_ops('configs[1] 32x64^3 surface', locs, [64, 64, 64], [(16, 16), (48, 16)])
+
+
+def _keys(sites):
+    s = np.asarray(sites, dtype=np.int64)
+    return ((s[:, 3] << 48) | (s[:, 0] << 32) | (s[:, 1] << 16) | s[:, 2])
+
+
+def _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, tol):
+    """Site lists must be identical, except that an occupancy decision may differ where the reference logit lies within
+    the fp32 tolerance of the threshold (sigmoid(x) > 0.5 <=> x > 0 cannot be decided for |x| below the logit error):
+    at these sizes ~1e6 decisions are taken per level and a handful land there.  A differing decision changes the next
+    level's candidate list by that site's 8 children; logits are compared on the sites both sides have."""
+    border_prev = np.zeros(0, np.int64)          # keys of the previous level whose decision was undecidable
+    for h in range(5):
+        if h < 4:
+            hs, hv = hocc[h][0].cpu().numpy(), hocc[h][1].detach().cpu().double().numpy()
+            os_, ov = oocc[h][0].numpy(), oocc[h][1].detach().double().numpy()
+            name = 'level %d logits' % h
+        else:
+            hs, hv = hsdf[0].cpu().numpy(), hsdf[1].detach().cpu().double().numpy()
+            os_, ov = osdf[0].numpy(), osdf[1].detach().double().numpy()
+            name = 'final sdf'
+        scale = max(1.0, float(np.abs(ov).max()))
+        if np.array_equal(hs, os_):
+            ih = io = np.arange(hs.shape[0])
+            n_diff = 0
+        else:
+            kh, ko = _keys(hs), _keys(os_)
+            _, ih, io = np.intersect1d(kh, ko, assume_unique=True, return_indices=True)
+            only = np.concatenate([np.delete(hs, ih, 0), np.delete(os_, io, 0)])
+            n_diff = only.shape[0]
+            # every site only one side has descends (h < 4) from / is (h == 4) an undecidable site of the level above
+            par = only.copy()
+            if h < 4:
+                par[:, :3] //= 2
+            assert np.isin(_keys(par), border_prev).all(), '%s: %s site lists differ beyond undecidable decisions' % (tag, name)
+            assert n_diff <= 1e-4 * max(hs.shape[0], 1) + 16
+            # a site missing on one side changes its neighbours' convolution inputs: values within the U-Net's
+            # receptive field (3 levels: < 24 voxels) of such a site legitimately differ and are not compared
+            far = np.ones(len(io), bool)
+            for q in only:
+                c = os_[io]
+                far &= ~((c[:, 3] == q[3]) & (np.abs(c[:, :3] - q[:3]).max(1) <= 24))
+            ih, io = ih[far], io[far]
+        err = float(np.abs(hv[ih] - ov[io]).max()) if len(ih) else 0.0
+        report('%-58s max|err| %.3e   max|ref| %.3e   sites %d, %d on one side only, %d compared' %
+               ('%s GenModel %s' % (tag, name), err, float(np.abs(ov).max()), os_.shape[0], n_diff, len(ih)))
+        assert err <= tol * scale, '%s %s: %g > %g' % (tag, name, err, tol * scale)
+        if h < 4:
+            border_prev = _keys(os_[np.abs(ov[:, 0]) <= tol * scale])
+
+
+def _model_forward(tag, dims, batch, cfg, dist, occupancy, train=True):
+    from sgnn_amd.model import GenModel
+    _fast_oracle()
+    try:
+        data = synth.make_batch(batch, dims, cfg=cfg, occupancy=occupancy, dist=dist)
+        locs, feats = data['input']
+        lw = np.ones(5, dtype=np.float32)
+        om = param_fill(mo.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train)
+        hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train).cuda()
+        with torch.no_grad():
+            osdf, oocc = om([locs, feats], lw)
+            hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw, batch_size=batch)
+        _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, 2e-4)
+    finally:
+        oscn.FAST = False
+
+
+def test_config1_model_forward_bs4():
+    _model_forward('configs[1] 64^3 bs4', (64, 64, 64), 4, 2, 'surface', 0.05)
+
+
+def test_config4_level_ops_and_stride2():
+    import sgnn_amd.scn as scn
+    locs = random_sites(1, 128, 0.2, 44)
+    n = locs.shape[0]
+    assert 380000 < n < 460000
+    _level_ops('configs[4] 128^3 @20% iid', locs, [128, 128, 128], [(16, 16)])
+    # stride-2: coarse site set == unique(floor(p/2)) in first-touch order, parents, children table
+    xo = oscn.InputLayer(3, [128] * 3, mode=0)([locs, torch.zeros(n, 1)])
+    xh = scn.InputLayer(3, [128] * 3, mode=0)([locs.cuda(), torch.zeros(n, 1).cuda()])
+    d = xh.metadata.down2(xh.spatial_size, xh.spatial_size // 2)
+    parent_o, off_o = xo.metadata.down2(xo.spatial_size, xo.spatial_size // 2)
+    coarse_o = xo.metadata.grid(xo.spatial_size // 2).coords
+    assert d.coarse.n == coarse_o.shape[0]
+    assert np.array_equal(d.coarse.coords.cpu().numpy().astype(np.int64), coarse_o)
+    assert np.array_equal(d.parent.cpu().numpy().astype(np.int64), parent_o)
+    uniq = np.unique(locs.numpy()[:, [3, 0, 1, 2]] // np.array([1, 2, 2, 2]), axis=0)
+    assert uniq.shape[0] == d.coarse.n                     # the set is unique(floor(p/2)) (83 % of the 64^3 grid)
+    ch = d.children.view(8, d.ldc)[:, :d.coarse.n].cpu().numpy()
+    want = np.full_like(ch, -1)
+    want[off_o, parent_o] = np.arange(n)
+    assert np.array_equal(ch, want)
+    report('configs[4] stride-2: %d -> %d sites (%.0f %% of the 64^3 grid), parents / children identical'
+           % (n, d.coarse.n, 100.0 * d.coarse.n / 64 ** 3))
+
+
+def test_config4_model_forward_one_block():
+    _model_forward('configs[4] 128^3 @20% iid bs1', (128, 128, 128), 1, 5, 'iid', 0.2)
+
+
+def test_config3_scene_properties():
+    """A (64,256,256) scene (~215 k input sites) through update_sizes, eval-style call as test_scene.py:72-95: every
+    generated level must (i) hold no duplicate site, (ii) be a subset of the 8-child expansion of the level above
+    restricted to what that level predicted occupied, (iii) stay inside the volume."""
+    from sgnn_amd.model import GenModel
+    dims = (64, 256, 256)
+    locs, feats = synth.make_scene(dims, cfg=4)
+    assert locs.shape[0] > 150000
+    torch.manual_seed(0)
+    m = GenModel(8, (64, 64, 64), 1, 16, 16, 4, True, True, 1, 1).cuda()
+    m.update_sizes(np.array(dims), np.array(dims) // 8)
+    lw = np.ones(5, dtype=np.float32)
+    with torch.no_grad():
+        m.train()
+        sdf, occ = m([locs.cuda(), feats.cuda()], lw)
+    prev_kept = None
+    for h in range(4):
+        sites, vals = occ[h][0].cpu().numpy(), occ[h][1].cpu().numpy()
+        f = 8 >> h
+        lim = np.array([dims[0] // f, dims[1] // f, dims[2] // f])
+        assert sites.shape[0] > 0 and (sites[:, :3] >= 0).all() and (sites[:, :3] < lim).all() and (sites[:, 3] == 0).all()
+        keys = (sites[:, 0] * lim[1] + sites[:, 1]) * lim[2] + sites[:, 2]
+        assert np.unique(keys).shape[0] == keys.shape[0], 'level %d holds duplicate sites' % h
+        if prev_kept is not None:                              # children of exactly the kept parents, 8 per parent, in order
+            par = sites[:, :3] // 2
+            assert sites.shape[0] == 8 * prev_kept.shape[0]
+            assert np.array_equal(par[::8], prev_kept[:, :3]) and np.array_equal(par, np.repeat(prev_kept[:, :3], 8, 0))
+            assert np.array_equal(sites[:8, :3] - 2 * par[:8], np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)]))
+        v32 = vals[:, 0].astype(np.float32)
+        prev_kept = sites[(np.float32(1) / (np.float32(1) + np.exp(-v32))) > np.float32(0.5)]   # the reference's predicate, in fp32
+        report('configs[3] (64,256,256) scene level %d: %d candidate sites, %d kept' % (h, sites.shape[0], prev_kept.shape[0]))
+    assert np.array_equal(sdf[0].cpu().numpy()[:, :3], prev_kept[:, :3])       # final sdf sites == last kept set, same order
+    assert torch.isfinite(sdf[1]).all()
+
+
+def test_four_gib_slab_is_refused():
+    """conv.hip addresses slabs through 32-bit raw-buffer offsets: a feature slab or table >= 4 GiB must come back as
+    SGNN_EOVERFLOW before anything is launched (nothing here is dereferenced: the check precedes the launch)."""
+    from sgnn_amd import _lib
+    small = torch.zeros(1024, device='cuda')
+    n = (1 << 26) + 256                      # n * 16 channels * 4 B = 4 GiB + 16 KiB
+    with pytest.raises(_lib.SgnnError, match='4 GiB'):
+        _lib.call('sgnn_conv_fwd', small.data_ptr(), n, 16, small.data_ptr(), 27, small.data_ptr(), n, n, 16, small.data_ptr(),
+                  0, 0)
+    with pytest.raises(_lib.SgnnError, match='4 GiB'):
+        _lib.call('sgnn_conv_bwd_weight', small.data_ptr(), n, 16, small.data_ptr(), 16, small.data_ptr(), n, 27, n,
+                  small.data_ptr(), 0, small.data_ptr(), 1 << 40)
+    n_ok = 1 << 22                           # the table alone: 64 offsets x ld x 4 B > 4 GiB
+    with pytest.raises(_lib.SgnnError, match='4 GiB'):
+        _lib.call('sgnn_conv_fwd', small.data_ptr(), n_ok, 16, small.data_ptr(), 64, small.data_ptr(), 1 << 25, n_ok, 16,
+                  small.data_ptr(), 0, 0)

@@ -39,9 +39,15 @@ def parse():
     ap.add_argument('--occupancy', type=float, default=0.05)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: run the CPU leg alone, print its JSON')
-    ap.add_argument('--cpu-fast', action='store_true',
-                    help='CPU leg: also try the oracle\'s C/OpenMP kernels (oracle/csrc/scn_cpu.c) and time the faster mode')
+    ap.add_argument('--cpu-torch-only', action='store_true',
+                    help='CPU leg: torch-op oracle only (default: its C/OpenMP kernels for convolutions + rulebooks when built)')
     ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='internal: thread count of a CPU-baseline child process')
+    ap.add_argument('--free-running', action='store_true',
+                    help='generative masks from the predicted occupancy (the reference\'s behaviour; per-level row counts '
+                         'then depend on the random weights).  Default: teacher-forced masks from the target hierarchy')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes behind roofline.traffic')
+    ap.add_argument('--traffic-probe', action='store_true', help='internal: launch the dominant kernel a few times (run under rocprofv3 --pmc)')
     return ap.parse_args()
 
 
@@ -53,7 +59,10 @@ def conv_alg_bytes(kind, n_out, cin, cout, K):
     return 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
 
 
-def collect_prof(lib):
+def collect_prof(lib, valid_ratio=None):
+    """valid_ratio: {(n_out, K): fraction of the K x n_out table entries that are rules} measured on the run's own
+    rulebooks; `flops` counts the rules only (F = 2 R Cin Cout), `flops_exec` every table entry."""
+    valid_ratio = valid_ratio or {}
     n = lib.sgnn_prof_count()
     kind, cin, cout, K, flags = (ctypes.c_int() for _ in range(5))
     n_out = ctypes.c_int64()
@@ -66,11 +75,13 @@ def collect_prof(lib):
             continue
         key = (kind.value, cin.value, cout.value, K.value)
         a = agg.setdefault(key, {'launches': 0, 'ms': 0.0, 'bytes': 0.0, 'flops': 0.0, 'by_size': {}})
-        fl = 2.0 * n_out.value * K.value * cin.value * cout.value
+        fl_exec = 2.0 * n_out.value * K.value * cin.value * cout.value
+        fl = fl_exec * valid_ratio.get((n_out.value, K.value), 1.0)
         a['launches'] += 1
         a['ms'] += ms.value
         a['bytes'] += conv_alg_bytes(kind.value, n_out.value, cin.value, cout.value, K.value)
         a['flops'] += fl
+        a['flops_exec'] = a.get('flops_exec', 0.0) + fl_exec
         # the same kernel serves levels of very different size: keep the launches apart by output rows (powers of 4)
         bucket = 0 if n_out.value <= 0 else int(np.floor(np.log(max(n_out.value, 1)) / np.log(4.0)))
         b = a['by_size'].setdefault(bucket, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'rows': 0})
@@ -81,24 +92,47 @@ def collect_prof(lib):
     return agg
 
 
+def cpu_info():
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1))
+
+
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference algorithm: per-offset gather -> mm -> index_add, torch CPU)
-    timed on this host on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference algorithm: explicit rulebook, per-offset gather -> small GEMM ->
+    scatter-add) timed on this host on a bounded sample of the same workload: one child process per thread count (all
+    physical cores, and 1), median of 5 steps after 2 warm-up steps."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    nthreads = args.cpu_threads or torch.get_num_threads()
+    torch.set_num_threads(nthreads)
     import model_oracle as mo
     import scn_oracle
     from scn_oracle import _fast
     from sgnn_amd import synth
     torch.manual_seed(0)
-    nthreads = torch.get_num_threads()
-    # the oracle's convolutions and 3x3x3 rulebooks through its C/OpenMP kernels when they are built (same algorithm:
-    # explicit rulebook, per-offset gather -> small GEMM -> scatter-add; oracle/csrc/scn_cpu.c) — torch's single-threaded
-    # index_select/index_add otherwise take half of the step
     nb = args.cpu_blocks
     m = mo.GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     data = synth.make_batch(nb, (args.dim,) * 3, cfg=2, occupancy=args.occupancy)
     lw = np.ones(5, dtype=np.float32)
+    # convolutions and 3x3x3 rulebooks through the oracle's C/OpenMP kernels when they are built (same algorithm as
+    # the torch-op mode and held to it by tests/test_oracle_fast.py; ~80 % of the oracle's step is inside them)
+    scn_oracle.FAST = bool(_fast.available and not args.cpu_torch_only)
 
     def step():
         t0 = time.time()
@@ -110,39 +144,137 @@ def cpu_baseline(args):
         opt.step()
         return time.time() - t0
 
-    # default: the torch-op oracle (the mode every round-1 number was taken with).  --cpu-fast: one untimed step per
-    # mode decides which one this host runs faster — the C/OpenMP kernels win by 3x on the 8-core authoring container;
-    # on the 256-thread GPU host the two OpenMP pools (torch's and the C kernels') have not been tuned yet
-    scn_oracle.FAST = False
-    t_torch = step()
-    t_c = None
-    if args.cpu_fast and _fast.available:
-        scn_oracle.FAST = True
-        t_c = step()
-        scn_oracle.FAST = t_c < t_torch
-    if scn_oracle.FAST:
-        how = 'convolutions + rulebooks in C/OpenMP (%d threads), the rest torch-CPU (%d threads)' % (_fast.threads(), nthreads)
-        nthreads = max(nthreads, _fast.threads())
-    else:
-        how = 'torch-CPU ops only (%d threads%s)' % (nthreads, '' if t_c is None else '; the C/OpenMP mode was slower here: %.1f vs %.1f s' % (t_c, t_torch))
-    times = [step() for _ in range(2)]
-    best = min(times)
-    return {'value': nb / best, 'unit': 'blocks/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel fwd+bwd+Adam on the CPU oracle [%s], '
-                      'best of 2 timed steps after the warm-up steps (%.2f s/step)' % (nb, args.dim, how, best)}
+    for _ in range(2):
+        step()
+    times = sorted(step() for _ in range(5))
+    med = times[2]
+    how = ('convolutions + 3x3x3 rulebooks in C/OpenMP (oracle/csrc/scn_cpu.c, %d threads), BatchNorm / stride-2 rulebooks / '
+           'glue / loss torch-CPU (%d threads)' % (_fast.threads(), nthreads)) if scn_oracle.FAST else \
+        'torch-CPU ops only (%d threads)' % nthreads
+    return {'value': nb / med, 'unit': 'blocks/s', 'cores': nthreads, 'kind': 'port', 's_per_step': round(med, 3),
+            'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel targets+fwd+loss+bwd+Adam on the CPU oracle [%s], '
+                      'median of 5 timed steps after 2 warm-up steps' % (nb, args.dim, how)}
 
 
 def cpu_baseline_subprocess(args):
-    """The CPU leg in its own process: the GPU process is pinned to its GPU's NUMA node (train.bind_to_device_numa), and
-    threads created after that inherit the mask — the host baseline must see every host core."""
+    """The CPU leg in its own processes (the GPU process is pinned to its GPU's NUMA node and OpenMP pools are sized
+    at start-up): once on all physical cores — the reported baseline — and once on 1 thread."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--dim', str(args.dim), '--occupancy',
-           str(args.occupancy), '--cpu-blocks', str(args.cpu_blocks)] + (['--cpu-fast'] if args.cpu_fast else [])
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
-    for line in reversed(out.stdout.strip().splitlines()):
-        if line.startswith('{'):
-            return json.loads(line)
-    raise RuntimeError('cpu baseline leg failed: %s' % out.stderr[-400:])
+    model, phys = cpu_info()
+    res = {}
+    runs = [('all_cores', phys), ('one_thread', 1)] + ([('16_threads', 16)] if phys > 16 else [])
+    for tag, nt in runs:
+        env = dict(os.environ)
+        env['OMP_NUM_THREADS'] = str(nt)
+        env['MKL_NUM_THREADS'] = str(nt)
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--dim', str(args.dim), '--occupancy',
+               str(args.occupancy), '--cpu-blocks', str(args.cpu_blocks), '--cpu-threads', str(nt)] + \
+              (['--cpu-torch-only'] if args.cpu_torch_only else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        got = None
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                got = json.loads(line)
+                break
+        if got is None:
+            raise RuntimeError('cpu baseline leg failed: %s' % out.stderr[-400:])
+        res[tag] = got
+    # headline = the fastest of the measured thread counts (fork/join over 128 cores costs more than it buys on loops
+    # this short: all-cores is reported next to it, as is the single thread)
+    best = max(res, key=lambda k: res[k]['value'])
+    cpu = dict(res[best])
+    cpu.update({'cpu_model': model, 'physical_cores': phys, 'threads_of_headline': res[best]['cores'],
+                'by_threads': dict((k, {'threads': v['cores'], 'value': round(v['value'], 4), 's_per_step': v['s_per_step']})
+                                   for k, v in res.items())})
+    return cpu
+
+
+def measure_valid_ratios(step, i):
+    """One extra (untimed) step with a hook on the rulebook builder: fraction of real rules per table, keyed by
+    (rows, K).  A stride-2 table holds exactly one rule per fine site."""
+    from sgnn_amd.scn import metadata as MD
+    ratios, real = {}, MD.Grid.subm_table
+
+    def hooked(self):
+        fresh = self._nbr is None
+        tab = real(self)
+        if fresh and self.n:
+            ratios[(self.n, 27)] = float((tab.view(27, self.ld)[:, :self.n] >= 0).sum().item()) / (27.0 * self.n)
+        return tab
+    MD.Grid.subm_table = hooked
+    try:
+        step(i)
+        torch.cuda.synchronize()
+    finally:
+        MD.Grid.subm_table = real
+    return ratios
+
+
+def traffic_probe(args):
+    """Internal (--traffic-probe, run under rocprofv3 --pmc): the dominant conv shape on this batch's input level."""
+    from sgnn_amd import synth
+    from sgnn_amd.scn import functions as F_
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    dev = torch.device('cuda', 0)
+    cin, cout = (int(v) for v in os.environ.get('SGNN_PROBE_SHAPE', '16,16').split(','))
+    data = synth.make_batch(args.batch, (args.dim,) * 3, cfg=2, occupancy=args.occupancy)
+    g = Grid(coords_from_locs(data['input'][0], dev))
+    tab = g.subm_table()
+    x = torch.randn(g.n, cin, device=dev)
+    w = torch.randn(27, cin, cout, device=dev) * 0.1
+    for _ in range(6):
+        F_.conv_fwd_raw(x, cin, w, 27, tab, g.ld, g.n, cout, 0, 0)
+    torch.cuda.synchronize()
+    print(json.dumps({'rows': g.n, 'rules': int((tab.view(27, g.ld)[:, :g.n] >= 0).sum().item())}))
+
+
+def measure_traffic(args, dom_key):
+    """HBM bytes per launch of the dominant conv class from PMC counters: two rocprofv3 passes (FETCH_SIZE / WRITE_SIZE,
+    KiB) over the probe; gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide reads (MI355X_MICROARCH.md, HBM),
+    so traffic = 2 * FETCH + WRITE.  Returns None when rocprofv3 is not usable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None or dom_key is None:
+        return None
+    cin, cout = dom_key[1], dom_key[2]
+    vals, rows, rules = {}, None, None
+    env = dict(os.environ)
+    env.update({'SGNN_PROBE_SHAPE': '%d,%d' % (cin, cout), 'TMPDIR': '/tmp', 'SGNN_NO_BIND': '1'})
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='sgnn_pmc_', dir='/tmp')
+        try:
+            cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--batch', str(args.batch), '--dim',
+                   str(args.dim), '--occupancy', str(args.occupancy)]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd='/tmp')
+            for line in out.stdout.splitlines():
+                if line.startswith('{'):
+                    info = json.loads(line)
+                    rows, rules = info['rows'], info['rules']
+            got = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') == counter and 'k_conv_fwd' in r.get('Kernel_Name', ''):
+                        got.append(float(r['Counter_Value']))
+            if not got:
+                return None
+            vals[counter] = sum(got) / len(got)
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if rows is None:
+        return None
+    byts = (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+    alg = 4.0 * rows * (cin + cout) + 4.0 * 27 * rows + 4.0 * 27 * cin * cout
+    return {'bytes_per_launch': round(byts), 'algorithmic_bytes': round(alg), 'ratio': round(byts / alg, 3),
+            'kernel': 'conv_fwd<%d,%d>K27' % (cin, cout), 'rows': rows, 'rules': rules,
+            'FETCH_SIZE_KiB': round(vals['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vals['WRITE_SIZE'], 1),
+            'method': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, kernel trace only), mean per launch of the '
+                      'kernel on the batch\'s input level; traffic = 2*FETCH + WRITE (gfx950 FETCH_SIZE correction)'}
 
 
 def spawn_ranks(args):
@@ -166,6 +298,9 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    if args.traffic_probe:
+        traffic_probe(args)
+        return
     if args.cpu_baseline_only:
         if hasattr(os, 'sched_setaffinity'):
             try:
@@ -214,8 +349,10 @@ def main():
                for j in range(2)]
     n_sites = [int(b['input'][0].shape[0]) for b in batches]
 
+    teacher = not args.free_running
+
     def step(i):
-        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync)
+        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher)
 
     n_prof_steps = 0
     for i in range(args.warmup):
@@ -247,8 +384,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    valid = measure_valid_ratios(step, args.warmup + args.steps)    # one more (untimed) step, on every rank: it all-reduces
     if rank == 0:
-        agg = collect_prof(lib)
+        agg = collect_prof(lib, valid)
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
         roof = None
         kernels = []
@@ -269,10 +407,15 @@ def main():
             else:
                 roof = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(gbs / HBM_PEAK_GBS, 4)}
-            # traffic: the PMC passes need their own rocprofv3 runs (profiles/r01i_conv_pmc.txt: 87.5 MB moved vs 86.1 MB
-            # algorithmic for conv_fwd<16,16> at N = 366 085, 478 vs 476 MB on a generated level of 2.0 M sites); the bench
-            # mixes level sizes and K = 27 / K = 8 launches under one kernel name, so there is no single per-launch figure
-            roof.update({'traffic': None, 'kernel': kernels[0]['kernel'],
+            # traffic: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; their own runs, kernel trace only) over a probe
+            # that launches the dominant kernel shape on this batch's input level; per launch, gfx950 correction applied
+            traffic = None
+            if world == 1 and not args.no_traffic:
+                traffic = measure_traffic(args, dom_key)
+            roof.update({'traffic': (traffic or {}).get('bytes_per_launch'), 'traffic_detail': traffic,
+                         'flops_counted': 'rules only (2 R Cin Cout); executed incl. empty table entries: %.2f TFLOP/s'
+                                          % (dom.get('flops_exec', dom['flops']) / (dom['ms'] * 1e-3) / 1e12),
+                         'kernel': kernels[0]['kernel'],
                          'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2), 'launches': dom['launches'],
                          'alg_GBps': round(gbs, 1), 'alg_frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4),
                          'TFLOPs': round(tfs, 2), 'frac_of_fp32_mfma_peak': round(tfs / FP32_MFMA_PEAK_TF, 4),
@@ -301,8 +444,10 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: full SG-NN 4-level GenModel (643735 params, random init), %d synthetic '
-                                   '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam'
-                                   % (args.batch, args.dim, 100 * args.occupancy),
+                                   '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam; %s'
+                                   % (args.batch, args.dim, 100 * args.occupancy,
+                                      'generative masks teacher-forced from the target hierarchy (row counts independent of '
+                                      'the random weights)' if teacher else 'generative masks from the predicted occupancy'),
                        'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
                        'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world,
                        'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},

@@ -172,6 +172,9 @@ int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *
  * partial holds sgnn_conv_stats_blocks(n_out) * 2 * cout doubles; sgnn_bn_fwd_ex / sgnn_bn_bwd_ex accept it as
  * pre_partial.  Only for the compiled (cin, cout) shapes; SGNN_EINVAL otherwise. */
 int64_t sgnn_conv_stats_blocks(int64_t n_out);
+/* levels below ~40 k rows run a latency-oriented kernel (16 rows per workgroup, the four waves split the offsets);
+ * 0 switches back to the 64-row variant of the big kernel (A/B measurements).  Returns the previous setting. */
+int sgnn_conv_set_small(int on);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,
@@ -277,6 +280,9 @@ int64_t sgnn_compact_ws_bytes(int64_t n);
 int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_t n, int32_t *sel,
                          int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 /* same for an explicit uint8 mask */
+/* teacher forcing: keep site i iff the dense (B,1,d0,d1,d2) float volume is > 0.5 at coords[i] = {z,y,x,b} */
+int sgnn_compact_dense(const int32_t *coords, int64_t n, const float *vol, int batch, int d0, int d1, int d2,
+                       int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, int64_t *count, void *ws,
                       int64_t ws_bytes, sgnn_stream_t stream);
 

@@ -324,6 +324,158 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// Small levels (< ~40 k rows: every coarse U-Net level, ~60 % of all convolution launches of a step).  The kernel
+// above walks the offsets serially with a short prefetch distance: on a level that cannot fill the chip its time is
+// K dependent gather round trips (~0.4 us each, 11 us per launch at K = 27), not bandwidth and not MFMA.  Here a
+// workgroup owns only 16 output rows and its four waves split the K offsets: every wave issues the rule loads, then
+// ALL its gathers and weight fragments at once (one memory round trip each), runs its ~7 x V MFMAs on two independent
+// accumulators, and the four partial tiles are summed through LDS.  Same arithmetic per (row, offset); the summation
+// order over offsets differs from the big kernel (fp32 round-off only).  Plain rulebook walk only.
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x, int64_t n_in,
+                                                   const float *__restrict__ w, const int32_t *__restrict__ table,
+                                                   int64_t ld, int K, int64_t n_out, float *y, int flags, int in_shift,
+                                                   ConvEpi epi) {
+  using C = ConvCfg<CIN, COUT>;
+  constexpr int V = C::V, CINP = C::CINP, NT = C::NT;
+  constexpr int KW = 7;                       // offsets per wave (K <= 28)
+  __shared__ float red[4][NT * 256];          // the four waves' partial 16 x (NT*16) tiles
+  __shared__ double sred[4][2][NT * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
+  const int per = (K + 3) >> 2;               // offsets of this wave: [k0, k0 + nk)
+  const int k0 = wave * per;
+  const int nk = (K - k0) < per ? ((K - k0) > 0 ? (K - k0) : 0) : per;
+
+  const uint32_t ldx4 = (uint32_t)epi.ldx * 4u, ldy4 = (uint32_t)epi.ldy * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(((n_out - 1) * epi.ldy + COUT) * 4));
+  const uint32_t lane_off = (uint32_t)(row0 + r) * 4u;
+  const uint32_t ld4 = (uint32_t)ld * 4u;
+
+  // one round trip: the rule entries of all offsets of this wave (offsets past nk are clamped and ignored)
+  int32_t id[KW];
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    const int k = k0 + (kk < nk ? kk : (nk > 0 ? nk - 1 : 0));
+    id[kk] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, (k < K ? k : K - 1) * ld4, 0) >> in_shift;
+  }
+  // second round trip: every gathered row quarter + (independent of the rules) the weight fragments of these offsets
+  float a[KW][V];
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    buf_load_floats<V>(rs_x, (uint32_t)id[kk] * ldx4 + (uint32_t)(q * V * 4), a[kk]);
+    if constexpr (CINP != CIN) {
+#pragma unroll
+      for (int s = 0; s < V; ++s)
+        if (3 * V + s >= CIN) a[kk][s] = (q == 3) ? 0.f : a[kk][s];
+    }
+  }
+  float b[KW][NT][V];
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    const int k = k0 + kk;
+    const int ks = flip ? (K - 1 - k) : k;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + r;
+#pragma unroll
+      for (int s = 0; s < V; ++s) {
+        const int c = q * V + s;
+        float v = 0.f;
+        if (kk < nk && c < CIN && n < COUT)
+          v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
+        b[kk][nt][s] = v;
+      }
+    }
+  }
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    if (kk < nk) {   // wave-uniform
+#pragma unroll
+      for (int s = 0; s < V; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[kk & 1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][s], b[kk][nt][s], acc[kk & 1][nt], 0, 0, 0);
+    }
+  }
+  // C/D layout: col = lane&15, row = (lane>>4)*4 + reg  ->  red[wave][nt][row][col]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][nt * 256 + (q * 4 + i) * 16 + r] = acc[0][nt][i] + acc[1][nt][i];
+  __syncthreads();
+
+  // one output element per thread and column tile: row = tid / 16, col = nt*16 + tid % 16
+  const bool has_add = epi.addend != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(has_add ? epi.addend : x, has_add ? (uint32_t)(((n_out - 1) * epi.ld_add + COUT) * 4) : 0u);
+  const uint32_t lda4 = (uint32_t)epi.ld_add * 4u;
+  const int stats = epi.stats;
+  const __amdgpu_buffer_rsrc_t rs_b =
+      make_rsrc(stats == 2 ? epi.bn_x : x, stats == 2 ? (uint32_t)(((n_out - 1) * epi.ld_bnx + COUT) * 4) : 0u);
+  const uint32_t ldb4 = (uint32_t)epi.ld_bnx * 4u;
+  const int orow_l = tid >> 4, ocol_l = tid & 15;
+  const int64_t row = row0 + orow_l;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 16 + ocol_l;
+    const bool ok = col < COUT && row < n_out;
+    const int e = nt * 256 + orow_l * 16 + ocol_l;
+    float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const uint32_t orow = (uint32_t)row;
+    if (has_add) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, ok ? orow * lda4 + col * 4u : 0xFFFFFFFFu, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_y, ok ? orow * ldy4 + col * 4u : 0xFFFFFFFFu, 0, 0);
+    if (stats) {
+      double f1 = 0.0, f2 = 0.0;
+      if (stats == 1) {
+        f1 = ok ? (double)v : 0.0;
+        f2 = f1 * f1;
+      } else {
+        float cm = 0.f, ci = 0.f, cg = 1.f, cb = 0.f;
+        if (col < COUT) {
+          cm = epi.mean[col];
+          ci = epi.invstd[col];
+          cg = epi.gamma ? epi.gamma[col] : 1.f;
+          cb = epi.beta ? epi.beta[col] : 0.f;
+        }
+        const float xb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, ok ? orow * ldb4 + col * 4u : 0xFFFFFFFFu, 0, 0));
+        const float xh = (xb - cm) * ci;
+        const float t = fmaf(xh, cg, cb);
+        const float dz = ok ? (t > 0.f ? v : v * epi.leak) : 0.f;
+        f1 = (double)dz;
+        f2 = (double)dz * (double)xh;
+      }
+      // a wave holds rows 4*wave .. 4*wave+3 x 16 columns: fold the 4 rows (lanes c, c+16, c+32, c+48), then the waves
+      f1 += __shfl_xor(f1, 16); f2 += __shfl_xor(f2, 16);
+      f1 += __shfl_xor(f1, 32); f2 += __shfl_xor(f2, 32);
+      if (lane < 16) {
+        sred[wave][0][nt * 16 + lane] = f1;
+        sred[wave][1][nt * 16 + lane] = f2;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int o = tid; o < 2 * NT * 16; o += 256) {
+      const int which = o / (NT * 16), col = o % (NT * 16);
+      if (col < COUT)
+        epi.partial[((size_t)blockIdx.x * 2 + which) * COUT + col] =
+            (sred[0][which][col] + sred[1][which][col]) + (sred[2][which][col] + sred[3][which][col]);
+    }
+  }
+}
+
 // any (cin, cout): one thread per output element, plain FMA.  Correctness fallback for layer
 // widths outside the SG-NN set; not a performance path.
 __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restrict__ x, int cin,
@@ -367,7 +519,14 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 // number of workgroups (= statistics partial blocks) a plain launch over n_out rows uses
 int64_t sgnn_conv_grid_blocks(int64_t n_out) {
   const int64_t grid4 = (n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK;
-  return grid4 < CONV_SMALL_GRID ? (n_out + 63) / 64 : grid4;
+  return grid4 < CONV_SMALL_GRID ? (n_out + 15) / 16 : grid4;    // k_conv_small: 16 rows per workgroup
+}
+
+static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_small(int on) {
+  const int prev = g_small_kernel;
+  g_small_kernel = on ? 1 : 0;
+  return prev;
 }
 
 bool sgnn_conv_epi_supported(int cin, int cout) {
@@ -401,6 +560,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                  epi.ld_add <= 1024 && epi.ld_bnx >= cout && epi.ld_bnx <= 1024);
   SGNN_CHECK_ARG(epi.stats >= 0 && epi.stats <= 2 && (!epi.stats || (plain && epi.partial)));
   SGNN_CHECK_ARG(epi.stats != 2 || (epi.bn_x && epi.mean && epi.invstd));
+  SGNN_CHECK_ARG(!epi.stats || K <= 28);   // the statistics partial count assumes the small-level kernel below ~40 k rows
   const int64_t lmax = epi.ldy > epi.ld_add ? (epi.ldy > epi.ld_bnx ? epi.ldy : epi.ld_bnx)
                                             : (epi.ld_add > epi.ld_bnx ? epi.ld_add : epi.ld_bnx);
   if (n_in * epi.ldx * 4 > 0xFFFFF000ll || n_out * groups * lmax * 4 > 0xFFFFF000ll ||
@@ -418,7 +578,10 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
 #define LAUNCH_FWD(CI, CO, EXV)                                                                         \
   do {                                                                                                  \
-    if (small)                                                                                          \
+    if (small && !EXV && K <= 28 && (g_small_kernel || epi.stats))                                      \
+      hipLaunchKernelGGL((k_conv_small<CI, CO>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,  \
+                         x, n_in, w, table, ld, K, n_out, y, flags, in_shift, epi);                     \
+    else if (small)                                                                                     \
       hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
                          ld, K, n_out, y, flags, in_shift, ex, epi);                                    \
     else                                                                                                \

@@ -237,6 +237,18 @@ struct FlagMask {
   const uint8_t *mask;
   __device__ __forceinline__ bool operator()(int64_t i) const { return mask[i] != 0; }
 };
+struct FlagDense {  // site i is kept iff a dense (B,1,d0,d1,d2) volume is > 0.5 at its coordinates (teacher forcing)
+  const int4 *coords;
+  const float *vol;
+  int batch, d0, d1, d2;
+  __device__ __forceinline__ bool operator()(int64_t i) const {
+    const int4 c = coords[i];
+    if ((unsigned)c.x >= (unsigned)d0 || (unsigned)c.y >= (unsigned)d1 || (unsigned)c.z >= (unsigned)d2 ||
+        (unsigned)c.w >= (unsigned)batch)
+      return false;
+    return vol[(((int64_t)c.w * d0 + c.x) * d1 + c.y) * d2 + c.z] > 0.5f;
+  }
+};
 struct FlagOwner {  // fine site i owns its parent iff it is the smallest row that touched it
   const int32_t *slot_of;
   const int32_t *cvals;
@@ -354,6 +366,17 @@ SGNN_EXPORT int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_
   SGNN_CHECK_ARG(n >= 0 && count && stride >= 1 && n < (1ll << 31));
   SGNN_CHECK_ARG(n == 0 || (logits && sel));
   return compact_impl(FlagSigmoid{logits, stride}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// keep site i iff vol[b, z, y, x] > 0.5 at coords[i] = {z, y, x, b}: the generative masks taken from the TARGET
+// occupancy pyramid instead of the predicted one (teacher forcing; bench.py uses it so that per-level row counts do
+// not depend on the random initial weights)
+SGNN_EXPORT int sgnn_compact_dense(const int32_t *coords, int64_t n, const float *vol, int batch, int d0, int d1, int d2,
+                                   int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count && n < (1ll << 31) && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
+  SGNN_CHECK_ARG(n == 0 || (coords && vol && sel));
+  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, n, sel, count, ws, ws_bytes,
+                      (hipStream_t)stream);
 }
 
 SGNN_EXPORT int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, int64_t *count, void *ws,

@@ -443,7 +443,10 @@ class GenModel(nn.Module):
         self.surfacepred.p0.spatial_size[:] = torch.from_numpy(ref * 2 ** len(self.refinement))
 
     # -- forward -----------------------------------------------------------------------------------------
-    def forward(self, x, loss_weights, batch_size=None):
+    def forward(self, x, loss_weights, batch_size=None, teacher=None):
+        """teacher (optional, not in the reference): list of the L dense target occupancy volumes (loss.compute_targets'
+        target_for_occs); when given, every generative mask is `target occupancy == 1` at the candidate site instead of
+        sigmoid(predicted occupancy) > 0.5, so the per-level site counts do not depend on the weights (bench.py)."""
         x = [coords_from_locs(x[0], x[1].device), x[1]]
         feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
         if self.use_skip_sparse:
@@ -454,9 +457,11 @@ class GenModel(nn.Module):
         for h in range(R):
             self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
         if P_.ENABLED and STAGES:
-            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs)
+            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher)
             if res is not None:
                 return res
+        if teacher is not None:
+            raise NotImplementedError('teacher forcing runs on the native stage path only')
         outputs = []
         locs, feats, out0 = self.dense_coarse_to_sparse(feat_rows, occ_rows, geo, truncation=3,
                                                         plan_depth=2 if runs[0] else 0)
@@ -479,7 +484,7 @@ class GenModel(nn.Module):
             return [locs_out, sdf], outputs
         return [[], []], outputs
 
-    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs):
+    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher=None):
         """forward() with every generative stage as one native program (Refinement.stage / SurfacePrediction.stage):
         the kept rows of a level are never gathered into their own tensor — the next stage's CONCAT_IN reads them
         through the compaction's index list.  Same results as the per-module path (tests/test_gpu_program.py)."""
@@ -490,7 +495,8 @@ class GenModel(nn.Module):
             geo.coords_i64 = F_.coords_to_i64(geo.coords)      # depends on the volume shape only (cached with geo)
         outputs = [[geo.coords_i64, occ_rows]]
         n_all = occ_rows.shape[0]
-        sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0)
+        tv = (lambda h: None) if teacher is None else (lambda h: teacher[h])
+        sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0, tv(0))
         # channel order of model.py:330: [occ, sdf | features]
         prev = (occ_rows if self.pass_occ else None, feat_rows if self.pass_feats else None, sel, locs, cnt)
         for h in range(R):
@@ -506,7 +512,7 @@ class GenModel(nn.Module):
                 return None if h == 0 else self._stage_fallback()
             y, out, coords_next = got
             outputs.append([F_.coords_to_i64(coords_next), out])
-            sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth)
+            sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth, tv(h + 1))
             # channel order of model.py:242: [features | occ, sdf]
             prev = (y if ref.pass_feats else None, out if ref.pass_occ else None, sel, locs, cnt)
         if not runs[R]:

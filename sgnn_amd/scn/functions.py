@@ -466,20 +466,36 @@ def compact_sigmoid(logits, stride, n):
     return sel[:count], count
 
 
-def compact_sigmoid_plan(logits, stride, n, coords_all, depth):
+def _compact_call(logits, stride, n, coords_all, sel, rt, ws, wsb, teacher):
+    if teacher is None:
+        _lib.call('sgnn_compact_sigmoid', ptr(logits), stride, n, ptr(sel), ptr(rt.state), ptr(ws), wsb)
+    else:       # masks from a dense target occupancy volume (B,1,d0,d1,d2) instead of the predicted logits
+        B, _, d0, d1, d2 = (int(v) for v in teacher.shape)
+        _lib.call('sgnn_compact_dense', ptr(coords_all), n, ptr(teacher), B, d0, d1, d2, ptr(sel), ptr(rt.state), ptr(ws),
+                  wsb)
+
+
+def compact_sigmoid_plan(logits, stride, n, coords_all, depth, teacher=None):
     """compact_sigmoid + the kept rows' coordinates + the stride-2 pyramid (`depth` levels) below them, with ONE host
     read-back for all row counts: the coordinate gather and the pyramid kernels read the kept-row count from device
     memory (sgnn_gather_rows_dn, sgnn_down2_chain).  Returns (sel[:count], count, locs (count,4) int32); when a
     pyramid was built, `locs` carries it (`_sgnn_plan`) and the next InputLayer adopts it instead of rebuilding."""
     from . import metadata as MD
-    if not MD.CHAIN or depth < 1 or n == 0:
-        sel, cnt = compact_sigmoid(logits, stride, n)
-        return sel, cnt, gather_coords(coords_all, sel, cnt)
     rt = runtime(logits.device)
+    if not MD.CHAIN or depth < 1 or n == 0:
+        if teacher is None:
+            sel, cnt = compact_sigmoid(logits, stride, n)
+        else:
+            sel = torch.empty(max(n, 1), dtype=torch.int32, device=logits.device)
+            wsb = _lib.query('sgnn_compact_ws_bytes', n)
+            _compact_call(logits, stride, n, coords_all, sel, rt, rt.workspace(wsb), wsb, teacher)
+            cnt = rt.read_count()
+            sel = sel[:cnt]
+        return sel, cnt, gather_coords(coords_all, sel, cnt)
     sel = torch.empty(n, dtype=torch.int32, device=logits.device)
     wsb = _lib.query('sgnn_compact_ws_bytes', n)
     ws = rt.workspace(wsb)
-    _lib.call('sgnn_compact_sigmoid', ptr(logits), stride, n, ptr(sel), ptr(rt.state), ptr(ws), wsb)
+    _compact_call(logits, stride, n, coords_all, sel, rt, ws, wsb, teacher)
     locs_cap = torch.empty(n, 4, dtype=torch.int32, device=logits.device)
     _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(rt.state), n, ptr(locs_cap))
     chain = MD.PendingChain(locs_cap, 0, True, depth)

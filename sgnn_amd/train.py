@@ -182,7 +182,8 @@ def _target_stream(dev):
 
 
 def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, truncation=3.0,
-               use_log_transform=True, weight_missing_geo=5.0, use_loss_masking=True, grad_sync=None):
+               use_log_transform=True, weight_missing_geo=5.0, use_loss_masking=True, grad_sync=None,
+               teacher_forced=False):
     """batch: device-resident dict in scene_dataloader.collate layout.  Returns (loss, losses, outputs)."""
     inputs = batch['input']
     known = batch['known'] if use_loss_masking else None
@@ -193,7 +194,11 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
                                                      use_loss_masking, known, weight_missing_geo, inputs[0])
 
     optimizer.zero_grad(set_to_none=True)
-    if dev.type == 'cuda' and OVERLAP_TARGETS:
+    if teacher_forced:
+        # generative masks come from the target occupancy pyramid: the targets are needed before the model runs
+        (tgt_sdf, tgt_occs, tgt_hier), weights = targets()
+        output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]), teacher=tgt_occs)
+    elif dev.type == 'cuda' and OVERLAP_TARGETS:
         # targets and loss weights depend on the batch only (a dozen dense element-wise / pooling passes over the
         # (B,1,D,D,D) volumes): they run on a second stream underneath the encoder, whose small launches leave the
         # memory system idle; the loss waits for them

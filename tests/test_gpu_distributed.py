@@ -42,8 +42,8 @@ def _kill_level(active):
     real = F_.compact_sigmoid_plan
     calls = [0]
 
-    def patched(logits, stride, n, coords_all, depth):
-        sel, cnt, locs = real(logits, stride, n, coords_all, depth)
+    def patched(logits, stride, n, coords_all, depth, teacher=None):
+        sel, cnt, locs = real(logits, stride, n, coords_all, depth, teacher)
         calls[0] += 1
         if active[0] and calls[0] == 2:
             return sel[:0], 0, locs[:0]

@@ -37,7 +37,7 @@ def test_conv_epilogue_add_stats_strided(batch, dim, cin, cout):
     w = torch.randn(27, cin, cout, device='cuda', generator=gen) * 0.2
     ywide = torch.full((n, cout + 24), 7.0, device='cuda')
     nblk = _lib.query('sgnn_conv_stats_blocks', n)
-    assert nblk == (-(-n // 64) if -(-n // 256) < 160 else -(-n // 256))
+    assert nblk == (-(-n // 16) if -(-n // 256) < 160 else -(-n // 256))    # 16-row workgroups on small levels
     part = torch.zeros(nblk, 2, cout, dtype=torch.float64, device='cuda')
     _lib.call('sgnn_conv_fwd_epi', xp, n, cin, cin + 8, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, cout,
               ywide.data_ptr() + 4 * 8, cout + 24, 0, ap, cout + 4, 1, part.data_ptr(), None, 0, None, None, None, None, 0.0)

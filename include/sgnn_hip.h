@@ -81,6 +81,10 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
 /* 3x3x3 submanifold rulebook (scn.SubmanifoldConvolution, torch/model.py:32,38,40,179,186,254):
  * nbr[k*ld + j] = row of the site at p_j + d_k, k = (dz+1)*9+(dy+1)*3+(dx+1), else -1.
  * ld >= n; entries j in [n, ld) are written as -1. */
+/* 1 selects the LDS-window builder (voxel index of a 768-row window around each 256-row tile hashed into LDS, global
+ * table only for neighbours not found there); default 0 = the global-probe kernel, which measured faster on MI355X
+ * (96.7 vs 123.9 us at N = 366 k).  Both produce identical tables.  Returns the previous setting. */
+int sgnn_rulebook_set_lds(int on);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         sgnn_stream_t stream);
@@ -175,6 +179,8 @@ int64_t sgnn_conv_stats_blocks(int64_t n_out);
 /* levels below ~40 k rows run a latency-oriented kernel (16 rows per workgroup, the four waves split the offsets);
  * 0 switches back to the 64-row variant of the big kernel (A/B measurements).  Returns the previous setting. */
 int sgnn_conv_set_small(int on);
+/* row count below which the small-level kernel is used (default ~41 k); returns the previous threshold */
+int64_t sgnn_conv_set_small_rows(int64_t rows);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,

@@ -39,9 +39,15 @@ def timeit(fn, iters=args.iters):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
-g._nbr = None
-us = timeit(lambda: (setattr(g, '_nbr', None), g.subm_table()), 10)
-print('rulebook_subm3: %.1f us  (%.1f GB/s on 16N+108N bytes)' % (us, g.n * 124 / us / 1e3))
+lib = _lib.load()
+nbr = torch.empty(27 * g.ld, dtype=torch.int32, device=dev)
+keys, vals, cap = g.hash()
+for on in (1, 0):
+    lib.sgnn_rulebook_set_lds(on)
+    us = timeit(lambda: _lib.call('sgnn_rulebook_subm3', keys.data_ptr(), vals.data_ptr(), cap, g.coords.data_ptr(), g.n,
+                                  nbr.data_ptr(), g.ld), 20)
+    print('rulebook_subm3 (%s): %.1f us  (%.1f GB/s on 16N+108N bytes)' % ('LDS window' if on else 'global probes', us, g.n * 124 / us / 1e3))
+lib.sgnn_rulebook_set_lds(1)
 for case in args.cases.split(','):
     cin, cout = (int(v) for v in case.split('x'))
     x = torch.randn(g.n, cin, device=dev); w = torch.randn(27, cin, cout, device=dev) * 0.1

@@ -12,13 +12,14 @@ opt = make_optimizer(m.parameters(), lr=1e-3)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 batch = to_device(synth.make_batch(NB, (64,) * 3, cfg=2), 'cuda')
 lw = np.ones(5, dtype=np.float32)
-for _ in range(3): train_step(m, opt, batch, lw)
+TF = True
+for _ in range(5): train_step(m, opt, batch, lw, teacher_forced=TF)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(10): train_step(m, opt, batch, lw)
+for _ in range(10): train_step(m, opt, batch, lw, teacher_forced=TF)
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('cumulative').print_stats(60)
 st.sort_stats('tottime').print_stats(30)

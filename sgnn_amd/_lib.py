@@ -24,6 +24,7 @@ PROTOTYPES = {
     'sgnn_coords_to_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_rulebook_set_lds': (c_i32, [c_i32]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
     'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -35,6 +36,7 @@ PROTOTYPES = {
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_conv_stats_blocks': (c_i64, [c_i64]),
     'sgnn_conv_set_small': (c_i32, [c_i32]),
+    'sgnn_conv_set_small_rows': (c_i64, [c_i64]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),

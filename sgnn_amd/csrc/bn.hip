@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__
 // workgroup sums the short partial table in the same fixed order into LDS, workgroup 0 also stores the results the
 // later passes / the caller need — and the separate finalize launch disappears.
 #define BN_U 2            // row groups a thread loads before it uses the first one
-#define BN_FUSE_BLOCKS 192
+#define BN_FUSE_BLOCKS 4096
 #define BN_FUSE_MAXC 64
 
 struct BnFuse {
@@ -421,6 +421,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
   }
 }
 
+// Finalising inside the apply kernels makes EVERY apply workgroup re-sum the partial table (L2-resident): worth it as
+// long as that re-read stays small next to a separate launch (~5 us of GPU time + ~3 us of host time per finalize, ~70
+// of them per training step).  Budget: 48 MB of partial reads per apply launch.
+static bool bn_fuse_ok(int64_t nblk, int c, int apply_grid) {
+  return c <= BN_FUSE_MAXC && nblk <= BN_FUSE_BLOCKS && nblk * (int64_t)apply_grid * 2 * c * (int64_t)sizeof(double) <= (48ll << 20);
+}
+
 static int bn_apply_grid(int64_t n, const BnGeom &g) {
   int64_t b = (n + (int64_t)g.rpb * BN_U - 1) / ((int64_t)g.rpb * BN_U);
   if (b < 1) b = 1;
@@ -462,7 +469,7 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
                            g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
       partial = (const double *)ws;
     }
-    if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)   // small level: k_bn_apply finalises
+    if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
       fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
       hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
@@ -573,7 +580,7 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
     partial = (const double *)ws;
   }
   BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (nblk <= BN_FUSE_BLOCKS && c <= BN_FUSE_MAXC)
+  if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))
     fuse = BnFuse{partial, (int)nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   else
     hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef);

@@ -47,6 +47,20 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
                      const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 bool sgnn_conv_epi_supported(int cin, int cout);
+// deferred weight-gradient reduces (conv.hip): partial[nblk][elems] -> dw[elems], many tensors in one launch
+#define DW_BATCH_MAX 28
+struct DwDesc {
+  const float *partial;
+  float *dw;
+  int64_t nblk, elems;
+  int blk0;
+};
+struct DwBatch {
+  DwDesc d[DW_BATCH_MAX];
+  int n;
+};
+extern DwBatch *sgnn_dw_batch;
+int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s);
 int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR);
 // linear.hip: heads whose weight rows / biases are separate tensors
 int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,

@@ -25,7 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CONV_MREP 4                        // 16-row MFMA tiles per wave in the large-grid variant
 #define CONV_ROWS_PER_WAVE (16 * CONV_MREP)
 #define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)   // also the required multiple of the table's ld
-#define CONV_SMALL_GRID 160                // below this many 256-row workgroups (~40 k rows) the 64-row variant wins (measured crossover)
+#define CONV_SMALL_GRID g_small_grid       // below this many 256-row workgroups the latency-oriented small-level kernel runs
+static int g_small_grid = 160;             // ~40 k rows (sgnn_conv_set_small_rows: measurements)
 
 template <int CIN, int COUT>
 struct ConvCfg {
@@ -522,6 +523,13 @@ int64_t sgnn_conv_grid_blocks(int64_t n_out) {
   return grid4 < CONV_SMALL_GRID ? (n_out + 15) / 16 : grid4;    // k_conv_small: 16 rows per workgroup
 }
 
+SGNN_EXPORT int64_t sgnn_conv_set_small_rows(int64_t rows) {
+  const int64_t prev = (int64_t)g_small_grid * CONV_ROWS_PER_BLOCK;
+  const int64_t g = rows < 0 ? 0 : (rows > (1ll << 36) ? (1ll << 28) : (rows + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
+  g_small_grid = (int)g;
+  return prev;
+}
+
 static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
 SGNN_EXPORT int sgnn_conv_set_small(int on) {
   const int prev = g_small_kernel;
@@ -963,6 +971,43 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ par
   }
 }
 
+// The reduce launches of many weight gradients as ONE launch (prog.hip: every convolution of a program's backward pass
+// keeps its partials in its own workspace slice; ~50 launches per training step become 5)
+__global__ __launch_bounds__(256) void k_dw_reduce_batch(DwBatch b) {
+  __shared__ float red[8][32];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.d[i + 1].blk0) ++i;
+  const DwDesc d = b.d[i];
+  const int part = threadIdx.x >> 5, le = threadIdx.x & 31;
+  const int64_t e = (int64_t)((int)blockIdx.x - d.blk0) * 32 + le;
+  float s = 0.f;
+  if (e < d.elems)
+    for (int64_t k = part; k < d.nblk; k += 8) s += d.partial[k * d.elems + e];
+  red[part][le] = s;
+  __syncthreads();
+  if (part == 0 && e < d.elems) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][le];
+    d.dw[e] = t;
+  }
+}
+
+DwBatch *sgnn_dw_batch = nullptr;   // non-NULL: sgnn_conv_bwd_weight* defer their reduce into it (set by prog.hip only)
+
+int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s) {
+  if (!b || b->n == 0) return SGNN_OK;
+  int blocks = 0;
+  for (int i = 0; i < b->n; ++i) {
+    b->d[i].blk0 = blocks;
+    blocks += (int)((b->d[i].elems + 31) / 32);
+  }
+  hipLaunchKernelGGL(k_dw_reduce_batch, dim3((unsigned)blocks), dim3(256), 0, s, *b);
+  b->n = 0;
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 // generic fallback: one workgroup per (k, ci, co) triple would be wasteful; instead one thread per
 // weight element loops over all rows (slow, correctness only)
 __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict__ x, int cin,
@@ -1040,8 +1085,12 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
                        dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, s, \
                        x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex);                  \
     sgnn_prof_end_launch(prof, s);                                                                         \
-    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                  \
-                       (const float *)ws, nblk, elems, dw);                                                \
+    if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
+      sgnn_dw_batch->d[sgnn_dw_batch->n++] = DwDesc{(const float *)ws, dw, nblk, elems, 0};                \
+    } else {                                                                                               \
+      hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                \
+                         (const float *)ws, nblk, elems, dw);                                              \
+    }                                                                                                      \
     done = true;                                                                                           \
   } while (0)
 #define X(CI, CO) \

@@ -84,18 +84,33 @@ int make_layout(const View &v, Layout &L) {
   return 0;
 }
 
+int64_t dw_slice(const View &v, int i) {   // workspace slice of op i's weight-gradient partials (256-byte multiple)
+  const int32_t *o = v.ops + OPW * i;
+  int64_t w = 0;
+  if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
+  if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
+  if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
+  return (w + 255) & ~int64_t(255);
+}
+
+// every convolution keeps its weight-gradient partials in its own slice (their reduces run as one launch at the end)
+int64_t dw_ws_need(const View &v) {
+  int64_t need = 0;
+  for (int i = 0; i < v.nops; ++i) need += dw_slice(v, i);
+  return need;
+}
+
 int64_t ws_main(const View &v) {
   int64_t need = 0;
   for (int i = 0; i < v.nops; ++i) {
     const int32_t *o = v.ops + OPW * i;
     int64_t w = 0;
-    if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
-    if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
-    if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
     if (o[0] == OP_BN) w = sgnn_bn_ws_bytes(v.lev_n[o[5]], o[6]);
     if (o[0] == OP_LINEAR) w = sgnn_linear_ws_bytes(v.lev_n[o[5]], o[6], o[7]);
     if (w > need) need = w;
   }
+  const int64_t dw = dw_ws_need(v);     // without a side lane the partial slices live in the main workspace too
+  if (dw > need) need = dw;
   return (need + 255) & ~int64_t(255);
 }
 
@@ -142,19 +157,6 @@ struct SideLane {
   int64_t ws_bytes = 0;
   hipEvent_t fork = nullptr, join = nullptr;
 } g_side;
-
-int64_t dw_ws_need(const View &v) {
-  int64_t need = 0;
-  for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + OPW * i;
-    int64_t w = 0;
-    if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
-    if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
-    if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
-    if (w > need) need = w;
-  }
-  return need;
-}
 
 }  // namespace
 
@@ -402,8 +404,15 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     forked = true;
     return g_side.stream;
   };
-  void *dw_ws = side ? g_side.ws : ws;
-  const int64_t dw_ws_bytes = side ? g_side.ws_bytes : ws_main(v);
+  char *dw_base = (char *)(side ? g_side.ws : ws);
+  int64_t dw_off = 0;
+  DwBatch batch{};
+  struct BatchGuard {            // the deferral is on only while this call runs, whatever path it leaves by
+    explicit BatchGuard(DwBatch *b) { sgnn_dw_batch = b; }
+    ~BatchGuard() { sgnn_dw_batch = nullptr; }
+  } guard(side ? &batch : nullptr);   // without the lane the slices share `ws` with the BatchNorm kernels: reduce at once
+  struct PendingExpand { const float *dwc; int cin, cout; float *dw; };
+  std::vector<PendingExpand> pending_expand;
   std::vector<const double *> pre(nops, nullptr);
   std::vector<int64_t> pre_nblk(nops, 0);
   double *stats_ws = (double *)((char *)ws + ws_main(v));
@@ -470,8 +479,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             PROG_TRY(commit(in0, t));
           }
         }
-        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, tab_f, ld_f, K, n_dy, PG(par), 0, dw_ws, dw_ws_bytes,
-                                      (sgnn_stream_t)lane));
+        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, tab_f, ld_f, K, n_dy, PG(par), 0, dw_base + dw_off,
+                                      dw_slice(v, i), (sgnn_stream_t)lane));
+        dw_off += dw_slice(v, i);
         break;
       }
       case OP_UNPOOL:
@@ -557,8 +567,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           PROG_TRY(commit(in0, t));
         }
         PROG_TRY(sgnn_conv_bwd_weight_ex(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1, 8, 27,
-                                         dw_ws, dw_ws_bytes, (sgnn_stream_t)lane));
-        PROG_TRY(sgnn_expand_weights_bwd(dwc, cin, cout, PG(par), (sgnn_stream_t)lane));
+                                         dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane));
+        dw_off += dw_slice(v, i);
+        pending_expand.push_back(PendingExpand{dwc, cin, cout, PG(par)});   // dwc is final after the batched reduce
         break;
       }
       case OP_LINEAR: {
@@ -585,6 +596,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       SGNN_HIP_TRY(hipMemcpyAsync(G(b), G(alias[b]), (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
     else if (init[b] == 0)
       SGNN_HIP_TRY(hipMemsetAsync(G(b), 0, (size_t)L.buf_floats[b] * sizeof(float), hs));
+  }
+  {
+    const hipStream_t lane = side ? g_side.stream : hs;
+    PROG_TRY(sgnn_dw_batch_flush(&batch, lane));      // all deferred weight-gradient reduces: one launch
+    for (const PendingExpand &pe : pending_expand)
+      PROG_TRY(sgnn_expand_weights_bwd(pe.dwc, pe.cin, pe.cout, pe.dw, (sgnn_stream_t)lane));
   }
   if (forked) {                                       // parameter gradients are complete once the lane has drained
     SGNN_HIP_TRY(hipEventRecord(g_side.join, g_side.stream));

@@ -195,3 +195,30 @@ def test_empty_input_is_legal():
     assert y.features.shape == (0, 16)
     z = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(y)
     assert z.features.shape == (0, 16)
+
+
+@pytest.mark.parametrize('order', ['raster', 'shuffled', 'children'])
+def test_lds_window_rulebook_equals_global_probe_rulebook(order):
+    """k_rulebook_subm3_lds (voxel index of a row window in LDS, global table only for misses) must produce the very
+    table of the global-probe kernel for every site order: sorted raster blocks, a random permutation (nothing is
+    near by: all look-ups fall through to the global table) and the 8-children-per-parent order of generated levels."""
+    from sgnn_amd import synth, _lib
+    from sgnn_amd.scn import functions as F_
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    lib = _lib.load()
+    locs = synth.make_batch(3, (32, 32, 32), cfg=9, occupancy=0.1)['input'][0]
+    if order == 'shuffled':
+        locs = locs[torch.randperm(locs.shape[0], generator=torch.Generator().manual_seed(0))]
+    coords = coords_from_locs(locs, torch.device('cuda'))
+    if order == 'children':
+        coords = F_.expand8_coords(coords)
+    tabs = []
+    for on in (1, 0):
+        prev = lib.sgnn_rulebook_set_lds(on)
+        try:
+            g = Grid(coords)
+            tabs.append(g.subm_table().clone())
+        finally:
+            lib.sgnn_rulebook_set_lds(prev)
+    assert torch.equal(tabs[0], tabs[1])
+    assert int((tabs[0].view(27, -1)[:, :coords.shape[0]] >= 0).sum()) > 27 * coords.shape[0] // 4

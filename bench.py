@@ -333,6 +333,8 @@ def main():
 
     from sgnn_amd import _lib, synth
     from sgnn_amd.model import GenModel
+    from sgnn_amd.scn import program as P_
+    P_.PERSISTENT_ARENAS = True          # grow-only program arenas (a training loop never keeps two forward results)
     from sgnn_amd.train import train_step, to_device, FlatGradAllReduce, make_optimizer, bind_to_device_numa
     bound = bind_to_device_numa(dev)          # one process per GPU, on that GPU's NUMA node
     lib = _lib.load()

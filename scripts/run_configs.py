@@ -9,6 +9,8 @@ from sgnn_amd import synth
 from sgnn_amd.model import GenModel
 from sgnn_amd.train import train_step, to_device, make_optimizer
 
+from sgnn_amd.scn import program as P_
+P_.PERSISTENT_ARENAS = True          # grow-only arenas: no allocator stalls when the generated level sizes change
 which = sys.argv[1] if len(sys.argv) > 1 else 'c5'
 lw = np.ones(5, dtype=np.float32)
 torch.manual_seed(1234)
@@ -19,7 +21,7 @@ if which == 'c5':
     print('C5 data: %d sites (%.1f s to generate)' % (batch['input'][0].shape[0], time.time() - t0))
     m = GenModel(8, (D,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
     opt = make_optimizer(m.parameters())
-    for i in range(4):
+    for i in range(10):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss, _, outs = train_step(m, opt, batch, lw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

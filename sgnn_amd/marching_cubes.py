@@ -171,14 +171,31 @@ def dense_from_sparse(locs, vals, dims, device=None):
     return dense
 
 
+def write_points_ply(points_xyz, filename):
+    """data_util.visualize_points for '.ply' (data_util.py:233-236): a vertex-only PLY of float x, y, z — what
+    plyfile.PlyData([PlyElement.describe(verts, 'vertex')]).write() emits (binary little endian)."""
+    pts = np.ascontiguousarray(np.asarray(points_xyz, dtype='<f4').reshape(-1, 3))
+    with open(filename, 'wb') as f:
+        f.write(('ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n'
+                 'property float z\nend_header\n' % pts.shape[0]).encode('ascii'))
+        f.write(pts.tobytes())
+
+
+def _np(t):
+    return np.asarray(t.detach().cpu() if torch.is_tensor(t) else t)
+
+
 def save_predictions(output_path, names, inputs, target_for_sdf, target_for_occs, output_sdf, output_occs, world2grids,
                      truncation, thresh=1):
-    """Mesh part of data_util.save_predictions (data_util.py:249-284): '<name>input-mesh.ply', '<name>pred-mesh.ply'
-    and, with targets, '<name>target-mesh.ply' — the files test_scene.py:98 writes.  The per-level point-cloud dumps
-    (output_occs / target_for_occs given) go through `plyfile` in the reference and are not reproduced."""
-    if output_occs is not None or target_for_occs is not None:
-        raise NotImplementedError('point-cloud dumps of the hierarchy levels are outside this build (plyfile)')
+    """data_util.save_predictions (data_util.py:249-284): '<name>input-mesh.ply', '<name>pred-mesh.ply', with targets
+    '<name>target-mesh.ply' (the files test_scene.py:98 writes), and — when the per-level occupancies are passed, as
+    train.py's visualisation path does — the point clouds '<name>target-<h>.ply' (voxel centres with target
+    occupancy 1) and '<name>pred-<h>.ply' (predicted sites), scaled to the finest resolution (data_util.py:252-273)."""
     os.makedirs(output_path, exist_ok=True)
+    factors = None
+    if output_occs is not None:
+        L = len(output_occs)
+        factors = [2 ** (L - 1 - h) for h in range(L)]                   # data_util.py:252-256
     in_locs = np.asarray(inputs[0].cpu() if torch.is_tensor(inputs[0]) else inputs[0])
     in_feats = np.asarray(inputs[1].cpu() if torch.is_tensor(inputs[1]) else inputs[1])
     if target_for_sdf is None:
@@ -192,6 +209,23 @@ def save_predictions(output_path, names, inputs, target_for_sdf, target_for_occs
         m = in_locs[:, -1] == k
         dense = dense_from_sparse(in_locs[m][:, :-1], in_feats[m], dims[:3])
         marching_cubes(dense, None, 0, trunc, 10, os.path.join(output_path, name + 'input-mesh.ply'))
+        if output_occs is not None:
+            for h in range(len(output_occs)):
+                if target_for_occs is not None:
+                    occ = _np(target_for_occs[h][k, 0]) == 1             # visualize_occ_as_points(occ == 1, 0.5, .., 1.5)
+                    z, y, x = np.nonzero(occ)                            # z-major raster order, like the reference's loops
+                    if len(z):
+                        write_points_ply((np.stack([x, y, z], 1) + 0.5) * factors[h],
+                                         os.path.join(output_path, '%starget-%d.ply' % (name, h)))
+                    else:
+                        print('warning: no valid occ points for %s' % os.path.join(output_path, '%starget-%d.ply' % (name, h)))
+                if output_occs[h][k] is not None:
+                    locs = _np(output_occs[h][k])[:, :3]                 # visualize_sparse_locs_as_points: z,y,x -> x,y,z
+                    if len(locs):
+                        write_points_ply((locs[:, ::-1].astype(np.float32) + 0.5) * factors[h],
+                                         os.path.join(output_path, '%spred-%d.ply' % (name, h)))
+                    else:
+                        print('warning: no valid occ points for %s' % os.path.join(output_path, '%spred-%d.ply' % (name, h)))
         if output_sdf[k] is not None:
             pl, pv = output_sdf[k]
             pl = np.asarray(pl.cpu() if torch.is_tensor(pl) else pl)

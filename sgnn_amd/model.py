@@ -459,6 +459,9 @@ class GenModel(nn.Module):
         if P_.ENABLED and STAGES:
             res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher)
             if res is not None:
+                if not self.training:     # inference: report input errors (duplicate / out-of-range sites) from THIS call
+                    from .scn.metadata import runtime
+                    runtime(feat_rows.device).check_status()
                 return res
         if teacher is not None:
             raise NotImplementedError('teacher forcing runs on the native stage path only')

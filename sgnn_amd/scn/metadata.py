@@ -55,6 +55,12 @@ class _Runtime(object):
         """One D2H copy: returns the count word and raises on pending input errors."""
         return self.read_counts()[0]
 
+    def check_status(self):
+        """Raise now if a kernel flagged an input error (duplicate / out-of-range coordinates) since the last read-back
+        (one D2H copy).  GenModel.forward calls it at the end of inference passes, so that the error is attributed to
+        the call that caused it; in training it surfaces at the next of the step's five read-backs."""
+        self.read_counts()
+
     def read_counts(self):
         """One D2H copy of the whole state block: [count, status, chain counts...] as Python ints."""
         self.syncs += 1
@@ -84,6 +90,11 @@ def runtime(device=None):
     if rt is None:
         _lib.require_gpu()
         rt = _runtimes[idx] = _Runtime(torch.device('cuda', idx))
+    if idx != torch.cuda.current_device():
+        # every entry point launches on the CURRENT device's stream: tensors of another GPU would be touched through
+        # a foreign stream (one process per GPU is the supported layout; torch.cuda.set_device selects it)
+        raise _lib.SgnnError('sgnn_amd: tensors live on cuda:%d but the current device is cuda:%d — call '
+                             'torch.cuda.set_device(%d) (one process per GPU)' % (idx, torch.cuda.current_device(), idx))
     return rt
 
 

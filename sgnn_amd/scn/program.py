@@ -24,6 +24,21 @@ from .metadata import runtime
 OP_SUBM, OP_DOWN, OP_UNPOOL, OP_BN, OP_ADD, OP_JOIN, OP_CONCAT_IN, OP_EXPAND, OP_LINEAR = range(9)
 OPW = 12
 ENABLED = True   # False: run the containers layer by layer (one autograd node per layer)
+# True: every Program keeps ONE grow-only arena (x1.25 head-room) and all programs share one gradient arena, instead of
+# a fresh torch allocation per call.  Generated level sizes change every step (masks are data dependent): with fresh
+# allocations the caching allocator meets a size it has no block for every few steps and falls back to hipMalloc /
+# hipFree — 10x step-time spikes on the 128^3 @ 20 % stress configuration (profiles/r01i_config5.txt).  Opt-in,
+# because the outputs of a forward call are views of the arena: they are overwritten by the NEXT forward call of the
+# same program (fine for a training loop, wrong for code that keeps two forward results alive).
+PERSISTENT_ARENAS = False
+_garenas = {}
+
+
+def _arena(owner, key, floats, dev):
+    t = owner.get(key)
+    if t is None or t.numel() < floats or t.device != dev:
+        t = owner[key] = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+    return t[:floats]
 
 
 class Unsupported(Exception):
@@ -279,7 +294,10 @@ class _ProgramFn(Function):
                            lev_n.ctypes.data, ncls)
         wsb = _lib.query('sgnn_prog_ws_bytes', ops.ctypes.data, nops, lev_n.ctypes.data, ncls)
         run.total, run.wsb = total, wsb
-        arena = torch.empty(total, dtype=torch.float32, device=dev)
+        if PERSISTENT_ARENAS:
+            arena = _arena(prog.__dict__.setdefault('_arenas', {}), 'fwd', total, dev)
+        else:
+            arena = torch.empty(total, dtype=torch.float32, device=dev)
         ws = rt.workspace(wsb)
         keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away
         keep[run.out_bufs] = 1
@@ -314,7 +332,10 @@ class _ProgramFn(Function):
         rt = runtime(dev)
         ops, opf, bufs = prog.ops_np, prog.opf_np, prog.bufs_np
         nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
-        garena = torch.empty(run.total, dtype=torch.float32, device=dev)
+        if PERSISTENT_ARENAS:      # one gradient arena per device: program backward calls never overlap
+            garena = _arena(_garenas, str(dev), run.total, dev)
+        else:
+            garena = torch.empty(run.total, dtype=torch.float32, device=dev)
         gout = [0] * nbuf
         held = []
         for b, g in zip(run.out_bufs, gouts):

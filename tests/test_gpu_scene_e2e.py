@@ -51,3 +51,28 @@ def test_scene_files_to_meshes(tmp_path):
     nv = int(head.split('element vertex ')[1].split('\n')[0])
     nf = int(head.split('element face ')[1].split('\n')[0])
     assert nv > 500 and nf > 500                            # the input surface is meshed
+
+
+def test_save_predictions_writes_level_point_clouds(tmp_path):
+    """train.py's visualisation call passes the per-level occupancies (data_util.py:264-270): the level point clouds
+    must be written next to the meshes instead of aborting."""
+    batch = synth.make_batch(1, (32, 32, 32), cfg=3, occupancy=0.1)
+    from sgnn_amd import loss as L
+    t = L.compute_targets(batch['sdf'].clone(), [h.clone() for h in batch['hierarchy']], 4, 3.0, True, batch['known'])
+    locs = batch['input'][0].numpy()
+    pred_locs = [[locs[::7][:, :3] // f] for f in (8, 4, 2, 1)]
+    pred_sdf = [[locs[:, :3], batch['input'][1].numpy()[:, 0]]]
+    out = tmp_path / 'vis'
+    mc.save_predictions(str(out), ['b0'], [locs, batch['input'][1].numpy()], t[0].numpy(), [o.numpy() for o in t[1]],
+                        pred_sdf, pred_locs, None, 3.0)
+    files = sorted(os.listdir(out))
+    assert files == sorted(['b0input-mesh.ply', 'b0pred-mesh.ply', 'b0target-mesh.ply'] +
+                           ['b0pred-%d.ply' % h for h in range(4)] + ['b0target-%d.ply' % h for h in range(4)])
+    raw = open(out / 'b0pred-3.ply', 'rb').read()
+    n = int(raw.split(b'element vertex ')[1].split(b'\n')[0])
+    pts = np.frombuffer(raw.split(b'end_header\n')[1], dtype='<f4').reshape(-1, 3)
+    assert n == pts.shape[0] == pred_locs[3][0].shape[0]
+    assert np.array_equal(pts, pred_locs[3][0][:, ::-1].astype(np.float32) + 0.5)      # x,y,z voxel centres, factor 1
+    raw0 = open(out / 'b0target-0.ply', 'rb').read()
+    pts0 = np.frombuffer(raw0.split(b'end_header\n')[1], dtype='<f4').reshape(-1, 3)
+    assert (pts0 % 8 == 4).all()                                                       # level-0 centres scaled by 8

@@ -122,3 +122,17 @@ def test_numa_cpulist_parsing_and_binding_is_harmless_without_a_gpu():
     assert bind_to_device_numa() is None or torch.cuda.is_available()
     if not torch.cuda.is_available():
         assert os.sched_getaffinity(0) == before
+
+
+def test_point_cloud_ply_writer(tmp_path):
+    """write_points_ply: the vertex-only PLY data_util.visualize_points writes through plyfile (header + float32 xyz)."""
+    import numpy as np
+    from sgnn_amd.marching_cubes import write_points_ply
+    pts = np.array([[0.5, 1.5, 2.5], [3.0, 4.0, 5.0]], dtype=np.float64)
+    f = tmp_path / 'p.ply'
+    write_points_ply(pts, str(f))
+    raw = f.read_bytes()
+    head, body = raw.split(b'end_header\n')
+    assert head.decode().splitlines() == ['ply', 'format binary_little_endian 1.0', 'element vertex 2', 'property float x',
+                                          'property float y', 'property float z']
+    assert np.array_equal(np.frombuffer(body, dtype='<f4').reshape(-1, 3), pts.astype(np.float32))

@@ -387,6 +387,33 @@ def main():
         elapsed = float(t.item())
 
     valid = measure_valid_ratios(step, args.warmup + args.steps)    # one more (untimed) step, on every rank: it all-reduces
+    # the other mask mode on the same batches (what BENCH_r01 measured: masks from the predicted occupancy, per-level
+    # row counts depend on the weights), reported next to the headline for comparability across rounds
+    other = None
+    if args.steps >= 20:
+        def step_other(i):
+            return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=not teacher)
+        k2 = max(10, args.steps // 3)
+        for i in range(6):
+            step_other(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(k2):
+            _, _, outs2 = step_other(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        other = {'masks': 'predicted occupancy (free-running)' if teacher else 'teacher-forced', 'steps': k2,
+                 'value': round(args.batch * world * k2 / el2, 2), 'ms_per_step': round(1e3 * el2 / k2, 3),
+                 'generated_sites_per_level': [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs2[1]] +
+                                              [int(outs2[0][0].shape[0]) if len(outs2[0][0]) else 0]}
     if rank == 0:
         agg = collect_prof(lib, valid)
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
@@ -453,7 +480,7 @@ def main():
                        'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
                        'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world,
                        'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'other_mask_mode': other,
         }
         if cpu:
             res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)

@@ -89,6 +89,18 @@ int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         sgnn_stream_t stream);
 
+/* Tile index of a 3x3x3 table (ld % 256 == 0): per 128-row tile the unique input rows its rules refer to and the
+ * table in 16-bit tile-local slots (tiles with more than 768 unique rows are flagged and keep using the int32 table).
+ * Large levels of narrow layers (cin, cout <= 16) then run sgnn_conv_fwd_tiled: each unique row is copied into LDS once
+ * and the MFMAs are fed from there - 3.5 instead of 23.7 row fetches per output row on surface data.  The program
+ * executor takes the index per level (lev_tile[], NULL = none).  index: sgnn_tile_index_bytes(ld) bytes. */
+int64_t sgnn_tile_index_bytes(int64_t ld);
+int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgnn_stream_t stream);
+int sgnn_conv_fwd_tiled(const float *x, int64_t n_in, int cin, const float *w, const int32_t *table, int64_t ld,
+                        int64_t n_out, int cout, float *y, int flags, const void *tile_index, sgnn_stream_t stream);
+/* 0: never use the tile kernel (A/B measurements, parity test); returns the previous setting */
+int sgnn_conv_set_tiled(int on);
+
 /* stride-2 / size-2 rulebook, phase 1 (scn.Convolution(...,2,2), torch/model.py:44):
  * finds the coarse active set unique(floor(p/2)) in FIRST-TOUCH order of the fine
  * rows (wave ballot + prefix-sum compaction), writes
@@ -377,28 +389,33 @@ int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *
  * same layout, the caller fills the output gradients and flags them in ginit[nbuf].
  * keep[nbuf] (host, may be NULL) flags the buffers the caller reads after the forward call (outputs / taps): the
  * executor fuses conv -> AddTable and conv -> BatchNorm statistics into the convolution epilogue and then never
- * materialises the convolution's own output buffer unless it is flagged.  sgnn_prog_set_fusion(0) switches the
- * fusions off (A/B measurements, parity tests); it returns the previous setting.
+ * materialises the convolution's own output buffer unless it is flagged; a JoinTable whose inputs can be produced in
+ * place gets no copy (its inputs live in column ranges of the join buffer and are read / written through a row
+ * stride).  The same `keep` must be passed to the arena / offset queries and to the backward call (the layout depends
+ * on it).  sgnn_prog_set_fusion(0) switches the fusions off (A/B measurements, parity tests); it returns the previous
+ * setting.
  * ------------------------------------------------------------------------- */
 int sgnn_prog_set_fusion(int on);
 int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                               const int64_t *lev_n, int nlev);
+                               const int64_t *lev_n, int nlev, const int32_t *keep);
 int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
 int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                const int64_t *lev_n, int nlev, int b);
+                                const int64_t *lev_n, int nlev, const int32_t *keep, int b);
 int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                      int nlev, void *const *params, int nparams, void *const *ext, void *const *idx, int nidx,
+                      void *const *lev_tile, int nlev, void *const *params, int nparams, void *const *ext,
+                      void *const *idx, int nidx,
                       float *arena, int64_t arena_floats, const int32_t *keep, int training, void *ws,
                       int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                       int nlev, void *const *params, void *const *pgrads, int nparams, void *const *ext,
+                       void *const *lev_tile, int nlev, void *const *params, void *const *pgrads, int nparams,
+                       void *const *ext,
                        void *const *gext, void *const *idx, int nidx, const float *arena, float *garena,
-                       int64_t arena_floats, void *const *gout, int training, void *ws, int64_t ws_bytes,
-                       sgnn_stream_t stream);
+                       int64_t arena_floats, void *const *gout, const int32_t *keep, int training, void *ws,
+                       int64_t ws_bytes, sgnn_stream_t stream);
 
 /* Optional second lane for sgnn_prog_backward: every weight-gradient launch (dW + its reduce) runs on `stream2`
  * with workspace `ws2`, concurrently with the dX / BatchNorm chain on the caller's stream (both only read dy); the

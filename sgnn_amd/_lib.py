@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsgnn_hip.so')
+LIB_PATH = os.environ.get('SGNN_LIB') or os.path.join(_HERE, 'lib', 'libsgnn_hip.so')   # SGNN_LIB: kernel-variant builds (measurements)
 
 c_i32, c_i64, c_f32, c_vp, c_cp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p
 
@@ -36,6 +36,10 @@ PROTOTYPES = {
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_conv_stats_blocks': (c_i64, [c_i64]),
     'sgnn_conv_set_small': (c_i32, [c_i32]),
+    'sgnn_conv_set_tiled': (c_i32, [c_i32]),
+    'sgnn_tile_index_bytes': (c_i64, [c_i64]),
+    'sgnn_tile_index': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_conv_fwd_tiled': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     'sgnn_conv_set_small_rows': (c_i64, [c_i64]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
@@ -75,15 +79,15 @@ PROTOTYPES = {
                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine_bwd': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
-    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32]),
+    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
-    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32]),
+    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
-    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                   c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
-    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
-                                   c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                   c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_concat3_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_concat3_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
                                       c_i64, c_vp]),

@@ -20,6 +20,9 @@ void sgnn_prof_end_launch(int slot, hipStream_t s);
 //    stats = 2: y is the gradient reaching a BatchNormReLU output; column sums of dz and dz*xhat with
 //    dz = y * (bn_out > 0 ? 1 : leak), xhat from bn_x / mean / invstd (what BatchNorm backward reduces first).
 //    partial[blk][2][COUT] doubles, blk = workgroup; summed later in fixed order (deterministic).
+#define TILE_ROWS 128     // rows per tile of the rulebook tile index (grid_rules.hip: k_tile_index)
+#define TILE_CAP 768      // unique input rows a tile may refer to before it falls back to the int32 table
+#define TILE_LTW 32       // 16-bit slots per row in the tile-local table (27 used): one 64-byte line per row
 struct ConvEpi {
   int64_t ldx, ldy, ld_add;
   const float *addend;
@@ -29,14 +32,28 @@ struct ConvEpi {
   int64_t ld_bnx;
   const float *mean, *invstd, *gamma, *beta;
   float leak;
+  // tile index of the 3x3x3 table (sgnn_tile_index), or NULL: large levels of narrow layers then stage each tile's
+  // unique input rows in LDS instead of gathering every rule entry
+  const int32_t *tile_cnt, *tile_u;
+  const uint16_t *tile_lt;
+  int tile_all;   // 1: every compiled tile shape (sgnn_conv_fwd_tiled); 0: only those that beat the gather kernel
 };
+
+// the three arrays inside a tile-index blob of a table with leading dimension ld
+static inline void sgnn_tile_ptrs(const void *index, int64_t ld, const int32_t **cnt, const int32_t **u, const uint16_t **lt) {
+  const int64_t tiles = ld / TILE_ROWS;
+  const int64_t a = (tiles * 4 + 255) & ~int64_t(255), b = (tiles * TILE_CAP * 4 + 255) & ~int64_t(255);
+  *cnt = (const int32_t *)index;
+  *u = (const int32_t *)((const char *)index + a);
+  *lt = (const uint16_t *)((const char *)index + a + b);
+}
 
 // conv.hip internals used by prog.hip
 int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                        int64_t n_out, int cout, float *y, int flags, int in_shift, const int32_t *kmap,
                        const int32_t *kadd, int in_mul, int groups, int table_rows, const ConvEpi *epi,
                        sgnn_stream_t stream);
-int64_t sgnn_conv_grid_blocks(int64_t n_out);
+int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K, bool tiled);
 // bn.hip internals used by prog.hip (strided rows, statistics partials supplied by a convolution epilogue)
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
@@ -47,6 +64,7 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
                      const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 bool sgnn_conv_epi_supported(int cin, int cout);
+bool dw_shape_ok(int cin, int cout);   // conv.hip: compiled weight-gradient shapes (strided rows need one)
 // deferred weight-gradient reduces (conv.hip): partial[nblk][elems] -> dw[elems], many tensors in one launch
 #define DW_BATCH_MAX 28
 struct DwDesc {
@@ -61,6 +79,17 @@ struct DwBatch {
 };
 extern DwBatch *sgnn_dw_batch;
 int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s);
+// rows.hip: strided row movement (prog.hip: JoinTable inputs written in place)
+int sgnn_gather_rows_ld(const float *src, int64_t ld_src, int c, const int32_t *idx, int64_t m, float *dst,
+                        int64_t ld_dst, sgnn_stream_t stream);
+int sgnn_gather_sum_ld(const float *src, int64_t ld_src, int c, const int32_t *table, int64_t ld, int K, int64_t n_out,
+                       float *dst, int64_t ld_dst, sgnn_stream_t stream);
+int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t n, int c, float *y, int64_t ldy,
+                sgnn_stream_t stream);
+int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
+                              const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
+                              const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
+                              int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR);
 // linear.hip: heads whose weight rows / biases are separate tensors
 int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,

@@ -40,14 +40,131 @@ struct View {
 
 inline int64_t round64(int64_t v) { return (v + 63) & ~int64_t(63); }
 
-// arena layout: [buffers..., per-op areas (BatchNorm: mean/invstd; up-sampling conv: its 64 pre-summed weight
-// slices)..., backward scratch: 2 x largest buffer, up-sampling weight gradient + its split data-gradient rows]
+// number of ops that read buffer b
+std::vector<int> count_readers(const View &v) {
+  std::vector<int> r(v.nbuf, 0);
+  auto hit = [&](int b) {
+    if (b >= 0 && b < v.nbuf) ++r[b];
+  };
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i;
+    hit(o[1]);
+    if (o[0] == OP_ADD || o[0] == OP_JOIN || o[0] == OP_CONCAT_IN) hit(o[2]);
+    if (o[0] == OP_CONCAT_IN) hit(o[8]);
+  }
+  return r;
+}
+
+bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
+
+// What the executor decides once per call, identically in forward and backward:
+//  * add_dst[i] >= 0: convolution i writes straight into the output of the AddTable right behind it (fused add);
+//  * views: a JoinTable whose inputs can be produced in place gets no copy — its inputs LIVE in column ranges of the
+//    join buffer (root / col / ld), every producer writes and every consumer reads through a row stride.
+struct Plan {
+  std::vector<int> add_dst;      // per op
+  std::vector<char> skip;        // per op: forward launches nothing (fused AddTable, in-place JoinTable)
+  std::vector<int> root, col;    // per buffer: storage owner and column offset inside it
+  std::vector<int64_t> ld;       // per buffer: row stride in floats
+  std::vector<char> join_view;   // per op: this JoinTable is in place
+};
+
+
+void make_plan(const View &v, const int32_t *keep, Plan &P) {
+  P.add_dst.assign(v.nops, -1);
+  P.skip.assign(v.nops, 0);
+  P.join_view.assign(v.nops, 0);
+  P.root.resize(v.nbuf);
+  P.col.assign(v.nbuf, 0);
+  P.ld.resize(v.nbuf);
+  for (int b = 0; b < v.nbuf; ++b) {
+    P.root[b] = b;
+    P.ld[b] = v.bufs[2 * b + 1];
+  }
+  if (!g_fuse) return;
+  std::vector<int> readers = count_readers(v);
+  if (keep)
+    for (int b = 0; b < v.nbuf; ++b)
+      if (keep[b]) ++readers[b];
+  // fused AddTable
+  for (int i = 0; i + 1 < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i, *a = v.ops + OPW * (i + 1);
+    if ((o[0] != OP_CONV_SUBM && o[0] != OP_CONV_DOWN) || a[0] != OP_ADD) continue;
+    const int64_t n_out = o[0] == OP_CONV_DOWN ? v.lev_n[o[5] + 1] : v.lev_n[o[5]];
+    if (!sgnn_conv_epi_supported(o[6], o[7]) || n_out <= 0 || readers[o[3]] != 1) continue;
+    if ((a[1] != o[3] && a[2] != o[3]) || a[1] == a[2]) continue;
+    P.add_dst[i] = a[3];
+    P.skip[i + 1] = 1;
+  }
+  // producer op of every buffer (the fused convolution for a fused AddTable output) and its last reader
+  std::vector<int> prod(v.nbuf, -1), last_reader(v.nbuf, -1);
+  std::vector<char> strided_ok(v.nbuf, 1);   // every reader / writer of the buffer can work through a row stride
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i;
+    if (!P.skip[i]) prod[P.add_dst[i] >= 0 ? P.add_dst[i] : o[3]] = i;
+    auto reads = [&](int b, bool ok) {
+      if (b < 0) return;
+      last_reader[b] = i;
+      if (!ok) strided_ok[b] = 0;
+    };
+    switch (o[0]) {
+      case OP_CONV_SUBM:
+      case OP_CONV_DOWN: reads(o[1], sgnn_conv_epi_supported(o[6], o[7]) && sgnn_conv_epi_supported(o[7], o[6]) && dw_shape_ok(o[6], o[7])); break;
+      case OP_BN: reads(o[1], true); break;
+      case OP_UNPOOL: reads(o[1], true); break;
+      case OP_JOIN:
+        reads(o[1], last_reader[o[1]] < 0 || v.ops[OPW * last_reader[o[1]]] != OP_JOIN);   // two JoinTables reading it: no view
+        reads(o[2], last_reader[o[2]] < 0 || v.ops[OPW * last_reader[o[2]]] != OP_JOIN);
+        break;
+      case OP_ADD: reads(o[1], P.skip[i] != 0); reads(o[2], P.skip[i] != 0); break;   // a fused AddTable reads through the conv epilogue
+      case OP_CONCAT_IN: reads(o[1], false); reads(o[2], false); reads(o[8], false); break;
+      default: reads(o[1], false); break;
+    }
+  }
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i;
+    if (o[0] != OP_JOIN || v.lev_n[o[5]] <= 0) continue;
+    bool ok = true;
+    for (int side = 0; side < 2 && ok; ++side) {
+      const int q = o[1 + side];
+      ok = q >= v.n_ext && !(keep && keep[q]) && P.root[q] == q && strided_ok[q] && last_reader[q] == i && prod[q] >= 0;
+      if (!ok) break;
+      const int32_t *p = v.ops + OPW * prod[q];
+      const bool conv = (p[0] == OP_CONV_SUBM || p[0] == OP_CONV_DOWN);
+      // writers that can store through a stride: conv epilogue (compiled shapes), BatchNorm apply, UnPooling gather;
+      // in backward the producer reads the buffer's gradient through the same stride (dX conv, dW, BN, gather_sum)
+      ok = (conv && sgnn_conv_epi_supported(p[6], p[7]) && sgnn_conv_epi_supported(p[7], p[6]) && dw_shape_ok(p[6], p[7])) ||
+           p[0] == OP_BN || p[0] == OP_UNPOOL;
+    }
+    if (!ok || o[1] == o[2]) continue;
+    P.join_view[i] = 1;
+    P.skip[i] = 1;
+    P.root[o[1]] = o[3];
+    P.col[o[1]] = 0;
+    P.root[o[2]] = o[3];
+    P.col[o[2]] = o[6];        // cin = channels of in0
+  }
+  for (int b = 0; b < v.nbuf; ++b) {   // nested joins: resolve to the outermost storage
+    int r = b, c = 0;
+    while (P.root[r] != r) {
+      c += P.col[r];
+      r = P.root[r];
+    }
+    P.root[b] = r;
+    P.col[b] = c;
+    P.ld[b] = v.bufs[2 * r + 1];
+  }
+}
+
+// arena layout: [buffers (in-place JoinTable inputs own no storage)..., per-op areas (BatchNorm: mean/invstd;
+// up-sampling conv: its 64 pre-summed weight slices)..., backward scratch: 2 x largest buffer, up-sampling weight
+// gradient + its split data-gradient rows]
 struct Layout {
   std::vector<int64_t> buf_off, buf_floats, aux_off;
   int64_t max_buf = 0, total = 0, scratch0 = 0, scratch1 = 0, bextra = 0;
 };
 
-int make_layout(const View &v, Layout &L) {
+int make_layout(const View &v, const Plan &P, Layout &L) {
   L.buf_off.assign(v.nbuf, -1);
   L.buf_floats.resize(v.nbuf);
   L.aux_off.assign(v.nops, -1);
@@ -57,10 +174,12 @@ int make_layout(const View &v, Layout &L) {
     if (lev < 0 || lev >= v.nlev || ch < 1) return -1;
     L.buf_floats[b] = v.lev_n[lev] * ch;
     if (L.buf_floats[b] > L.max_buf) L.max_buf = L.buf_floats[b];
-    if (b < v.n_ext) continue;
+    if (b < v.n_ext || P.root[b] != b) continue;
     L.buf_off[b] = off;
     off += round64(L.buf_floats[b]);
   }
+  for (int b = v.n_ext; b < v.nbuf; ++b)
+    if (P.root[b] != b) L.buf_off[b] = L.buf_off[P.root[b]] + P.col[b];
   int64_t bextra = 0;
   for (int i = 0; i < v.nops; ++i) {
     const int32_t *o = v.ops + OPW * i;
@@ -122,8 +241,9 @@ int64_t ws_stats(const View &v) {
     const int32_t *o = v.ops + OPW * i;
     if (o[0] != OP_CONV_SUBM && o[0] != OP_CONV_DOWN) continue;
     const int64_t rows_f = v.lev_n[o[5]], rows_o = o[0] == OP_CONV_DOWN ? v.lev_n[o[5] + 1] : rows_f;
-    const int64_t a = sgnn_conv_grid_blocks(rows_o > 0 ? rows_o : 1) * 2 * o[7] * (int64_t)sizeof(double);  // forward: out rows x cout
-    const int64_t b = sgnn_conv_grid_blocks(rows_f > 0 ? rows_f : 1) * 2 * o[6] * (int64_t)sizeof(double);  // data gradient: in rows x cin
+    // block counts of the finest-grained kernel that may run (16-row small kernel / 128-row tile kernel)
+    const int64_t a = ((rows_o > 0 ? rows_o : 1) + 15) / 16 * 2 * o[7] * (int64_t)sizeof(double);   // forward: out rows x cout
+    const int64_t b = ((rows_f > 0 ? rows_f : 1) + 15) / 16 * 2 * o[6] * (int64_t)sizeof(double);   // data gradient: in rows x cin
     if (a > need) need = a;
     if (b > need) need = b;
   }
@@ -131,23 +251,6 @@ int64_t ws_stats(const View &v) {
 }
 
 int64_t ws_need(const View &v) { return ws_main(v) + ws_stats(v); }
-
-// number of ops that read buffer b
-std::vector<int> count_readers(const View &v) {
-  std::vector<int> r(v.nbuf, 0);
-  auto hit = [&](int b) {
-    if (b >= 0 && b < v.nbuf) ++r[b];
-  };
-  for (int i = 0; i < v.nops; ++i) {
-    const int32_t *o = v.ops + OPW * i;
-    hit(o[1]);
-    if (o[0] == OP_ADD || o[0] == OP_JOIN || o[0] == OP_CONCAT_IN) hit(o[2]);
-    if (o[0] == OP_CONCAT_IN) hit(o[8]);
-  }
-  return r;
-}
-
-bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
 
 // weight-gradient lane: sgnn_prog_backward can run every dW (+ its reduce) on a second stream with its own
 // workspace, concurrently with the dX / BatchNorm chain that forms the critical path (both only READ dy)
@@ -185,10 +288,12 @@ SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
   } while (0)
 
 SGNN_EXPORT int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                           const int64_t *lev_n, int nlev) {
+                                           const int64_t *lev_n, int nlev, const int32_t *keep) {
   View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  Plan P;
+  make_plan(v, keep, P);
   Layout L;
-  if (make_layout(v, L) != 0) return -1;
+  if (make_layout(v, P, L) != 0) return -1;
   return L.total;
 }
 
@@ -199,24 +304,29 @@ SGNN_EXPORT int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64
 
 // float offset of buffer `b` inside an arena (so the host layer can hand out views); -1 for externals
 SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                            const int64_t *lev_n, int nlev, int b) {
+                                            const int64_t *lev_n, int nlev, const int32_t *keep, int b) {
   View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
+  Plan P;
+  make_plan(v, keep, P);
   Layout L;
-  if (make_layout(v, L) != 0 || b < 0 || b >= nbuf) return -1;
-  return L.buf_off[b];
+  if (make_layout(v, P, L) != 0 || b < 0 || b >= nbuf) return -1;
+  return P.root[b] == b ? L.buf_off[b] : -1;      // buffers the caller keeps are never views
 }
 
 SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                  int nlev, void *const *params, int nparams, void *const *ext, void *const *idx,
+                                  void *const *lev_tile, int nlev, void *const *params, int nparams, void *const *ext,
+                                  void *const *idx,
                                   int nidx, float *arena, int64_t arena_floats, const int32_t *keep, int training,
                                   void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1 &&
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || ext));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+  Plan PL;
+  make_plan(v, keep, PL);
   Layout L;
-  SGNN_CHECK_ARG(make_layout(v, L) == 0);
+  SGNN_CHECK_ARG(make_layout(v, PL, L) == 0);
   if (arena_floats < L.total) {
     sgnn_set_error("sgnn_prog_forward: arena too small (%lld < %lld floats)", (long long)arena_floats,
                    (long long)L.total);
@@ -227,20 +337,17 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
     return SGNN_ENOWS;
   }
   auto B = [&](int b) -> float * { return b < 0 ? nullptr : (b < n_ext ? (float *)ext[b] : arena + L.buf_off[b]); };
+  auto LD = [&](int b) -> int64_t { return PL.ld[b]; };       // row stride (floats): wider than the channels for a view
   auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
   auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
-  // Epilogue fusions (same arithmetic, fewer passes and launches):
+  // Epilogue fusions (same arithmetic, fewer passes and launches; planned by make_plan):
   //  * conv -> AddTable: the convolution adds the other AddTable input while it stores (the sum buffer is written
   //    directly, the convolution's own output buffer stays untouched) when nothing else reads the convolution output;
   //  * conv [-> AddTable] -> BatchNorm (training): the convolution epilogue reduces the column sums the BatchNorm
-  //    statistics pass would recompute from HBM.
-  std::vector<int> readers = count_readers(v);
-  if (keep)
-    for (int b = 0; b < nbuf; ++b)
-      if (keep[b]) ++readers[b];
-  std::vector<char> skip(nops, 0);
+  //    statistics pass would recompute from HBM;
+  //  * JoinTable in place: its inputs are written straight into their column range of the join buffer.
   std::vector<const double *> pre(nops, nullptr);
   std::vector<int64_t> pre_nblk(nops, 0);
   double *stats_ws = (double *)((char *)ws + ws_main(v));
@@ -250,7 +357,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
     SGNN_CHECK_ARG(out >= n_ext && out < nbuf && lev >= 0 && lev < nlev && in0 < nbuf && in1 < nbuf);
     SGNN_CHECK_ARG(type == OP_CONCAT_IN || in0 >= 0);
     const int64_t n = lev_n[lev];
-    if (skip[i]) continue;
+    if (PL.skip[i]) continue;
     switch (type) {
       case OP_CONV_SUBM:
       case OP_CONV_DOWN: {
@@ -260,58 +367,58 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         const int32_t *table = (const int32_t *)(down ? lev_children[lev] : lev_nbr[lev]);
         const int64_t ld = down ? lev_ld[lev + 1] : lev_ld[lev];
         ConvEpi epi{};
-        float *dst = B(out);
         int dst_buf = out;
-        if (g_fuse && sgnn_conv_epi_supported(cin, cout) && n_out > 0) {
-          int j = i + 1;
-          if (j < nops && ops[OPW * j] == OP_ADD && readers[out] == 1 &&
-              (ops[OPW * j + 1] == out || ops[OPW * j + 2] == out) && ops[OPW * j + 1] != ops[OPW * j + 2]) {
-            const int other = ops[OPW * j + 1] == out ? ops[OPW * j + 2] : ops[OPW * j + 1];
-            epi.addend = B(other);
-            dst_buf = ops[OPW * j + 3];
-            dst = B(dst_buf);
-            skip[j] = 1;
-            ++j;
-          }
-          if (training && j < nops && ops[OPW * j] == OP_BN && ops[OPW * j + 1] == dst_buf) {
-            epi.stats = 1;
-            epi.partial = stats_ws;
-            pre[j] = stats_ws;
-            pre_nblk[j] = sgnn_conv_grid_blocks(n_out);
-          }
+        if (PL.add_dst[i] >= 0) {
+          const int32_t *a = ops + OPW * (i + 1);
+          const int other = a[1] == out ? a[2] : a[1];
+          epi.addend = B(other);
+          epi.ld_add = LD(other);
+          dst_buf = PL.add_dst[i];
         }
-        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, dst, 0, 0, nullptr,
+        const bool tiled = !down && lev_tile && lev_tile[lev];
+        if (tiled) sgnn_tile_ptrs(lev_tile[lev], lev_ld[lev], &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
+        int j = i + 1 + (PL.add_dst[i] >= 0 ? 1 : 0);
+        if (g_fuse && training && n_out > 0 && j < nops && ops[OPW * j] == OP_BN && ops[OPW * j + 1] == dst_buf &&
+            sgnn_conv_epi_supported(cin, cout)) {
+          epi.stats = 1;
+          epi.partial = stats_ws;
+          pre[j] = stats_ws;
+          pre_nblk[j] = sgnn_conv_grid_blocks(n_out, cin, cout, down ? 8 : 27, tiled);
+        }
+        epi.ldx = LD(in0);
+        epi.ldy = LD(dst_buf);
+        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
                                     nullptr, 1, 1, down ? 8 : 27, &epi, stream));
         break;
       }
       case OP_UNPOOL:  // in0 lives on level lev+1, out on level lev
         SGNN_CHECK_ARG(lev + 1 < nlev);
-        PROG_TRY(sgnn_gather_rows(B(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), stream));
+        PROG_TRY(sgnn_gather_rows_ld(B(in0), LD(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), LD(out), stream));
         break;
       case OP_BN: {
         float *save = arena + L.aux_off[i];
-        PROG_TRY(sgnn_bn_fwd_impl(B(in0), cin, n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
-                                  opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), cin, pre[i],
+        PROG_TRY(sgnn_bn_fwd_impl(B(in0), LD(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
+                                  opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), LD(out), pre[i],
                                   pre_nblk[i], ws, ws_bytes, stream));
         break;
       }
       case OP_ADD:
         SGNN_CHECK_ARG(in1 >= 0);
-        PROG_TRY(sgnn_add(B(in0), B(in1), n * cin, B(out), stream));
+        PROG_TRY(sgnn_add_ld(B(in0), LD(in0), B(in1), LD(in1), n, cin, B(out), LD(out), stream));
         break;
       case OP_JOIN:  // cin = channels of in0, cout = channels of in1
-        SGNN_CHECK_ARG(in1 >= 0);
+        SGNN_CHECK_ARG(in1 >= 0 && LD(in0) == cin && LD(in1) == cout && LD(out) == cin + cout);
         PROG_TRY(sgnn_concat_rows(B(in0), cin, nullptr, B(in1), cout, nullptr, n, B(out), stream));
         break;
       case OP_CONCAT_IN: {
         const int in2 = o[8];
-        SGNN_CHECK_ARG(in2 < nbuf && CH(in0) + CH(in1) + CH(in2) == CH(out));
+        SGNN_CHECK_ARG(in2 < nbuf && CH(in0) + CH(in1) + CH(in2) == CH(out) && LD(out) == CH(out));
         PROG_TRY(sgnn_concat3_rows(B(in0), CH(in0), I(o[9]), B(in1), CH(in1), I(o[10]), B(in2), CH(in2), I(o[11]), n,
                                    B(out), stream));
         break;
       }
       case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
-        SGNN_CHECK_ARG(ROWS(out) == 8 * n);
+        SGNN_CHECK_ARG(ROWS(out) == 8 * n && LD(in0) == cin && LD(out) == cout);
         const int32_t *S, *ST, *PAR;
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         float *wc = arena + L.aux_off[i];
@@ -321,7 +428,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       }
       case OP_LINEAR: {
-        SGNN_CHECK_ARG(cout >= 1 && cout <= 4);
+        SGNN_CHECK_ARG(cout >= 1 && cout <= 4 && LD(in0) == cin);
         const float *w[4] = {}, *b[4] = {};
         for (int q = 0; q < cout; ++q) {
           w[q] = P(par + 2 * q);
@@ -344,15 +451,18 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
 SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                    const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                    void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                   int nlev, void *const *params, void *const *pgrads, int nparams,
+                                   void *const *lev_tile, int nlev, void *const *params, void *const *pgrads, int nparams,
                                    void *const *ext, void *const *gext, void *const *idx, int nidx,
                                    const float *arena, float *garena, int64_t arena_floats, void *const *gout,
-                                   int training, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+                                   const int32_t *keep, int training, void *ws, int64_t ws_bytes,
+                                   sgnn_stream_t stream) {
   SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && pgrads && arena && garena && gout &&
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || (ext && gext)));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
+  Plan PL;
+  make_plan(v, keep, PL);             // the same decisions the forward call took (same inputs)
   Layout L;
-  SGNN_CHECK_ARG(make_layout(v, L) == 0);
+  SGNN_CHECK_ARG(make_layout(v, PL, L) == 0);
   if (arena_floats < L.total || ws_bytes < ws_need(v)) {
     sgnn_set_error("sgnn_prog_backward: arena or workspace too small");
     return SGNN_ENOWS;
@@ -366,6 +476,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   auto X = [&](int b) -> const float * { return b < 0 ? nullptr : (b < n_ext ? (const float *)ext[b] : arena + L.buf_off[b]); };
   auto G = [&](int b) -> float * { return b < n_ext ? (float *)gext[b] : garena + L.buf_off[b]; };
   auto GR = [&](int b) -> const float * { return init[b] == 2 ? G(alias[b]) : G(b); };   // where b's gradient is read
+  auto LD = [&](int b) -> int64_t { return PL.ld[b]; };                                  // row stride of X(b) and G(b)
+  auto GRLD = [&](int b) -> int64_t { return init[b] == 2 ? PL.ld[alias[b]] : PL.ld[b]; };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto PG = [&](int p) { return (p >= 0 && p < nparams) ? (float *)pgrads[p] : nullptr; };
   auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
@@ -380,18 +492,19 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
   // where a kernel should write the gradient of buffer b: the buffer itself unless it already holds data
   auto target = [&](int b, int which) { return init[b] == 1 ? scratch[which] : G(b); };
+  auto TLD = [&](int b, const float *t) -> int64_t { return t == G(b) ? LD(b) : CH(b); };   // scratch rows are contiguous
   auto commit = [&](int b, float *wrote) -> int {  // fold a freshly written gradient into buffer b
     if (wrote == G(b)) {
       if (init[b] == 2) {                            // G(b) = fresh + the aliased gradient
         const int a = alias[b];
         alias[b] = -1;
         init[b] = 1;
-        return sgnn_add(G(b), G(a), L.buf_floats[b], G(b), stream);
+        return sgnn_add_ld(G(b), LD(b), G(a), LD(a), ROWS(b), CH(b), G(b), LD(b), stream);
       }
       init[b] = 1;
       return SGNN_OK;
     }
-    return sgnn_add(G(b), wrote, L.buf_floats[b], G(b), stream);
+    return sgnn_add_ld(G(b), LD(b), wrote, CH(b), ROWS(b), CH(b), G(b), LD(b), stream);
   };
   auto wants = [&](int b) { return b >= n_ext || gext[b] != nullptr; };
   // dW launches go to the side lane when one is configured and its workspace is big enough
@@ -436,6 +549,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       continue;
     }
     const float *dy = GR(out);
+    const int64_t ld_dy = GRLD(out);
     switch (type) {
       case OP_CONV_SUBM:
       case OP_CONV_DOWN: {
@@ -453,53 +567,73 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             // store (in place), and when in0 is the output of the BatchNormReLU right before this op and this is the
             // last contribution to its gradient, the epilogue also reduces sum dz / sum dz*xhat for that BatchNorm
             ConvEpi epi{};
-            if (init[in0] == 1) epi.addend = G(in0);
-            else if (init[in0] == 2) epi.addend = G(alias[in0]);
+            const bool tiled = !down && lev_tile && lev_tile[lev];      // symmetric rulebook: the same row sets
+            if (tiled) sgnn_tile_ptrs(lev_tile[lev], lev_ld[lev], &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
+            if (init[in0] == 1) {
+              epi.addend = G(in0);
+              epi.ld_add = LD(in0);
+            } else if (init[in0] == 2) {
+              epi.addend = G(alias[in0]);
+              epi.ld_add = LD(alias[in0]);
+            }
             if (i > 0 && ops[OPW * (i - 1)] == OP_BN && ops[OPW * (i - 1) + 3] == in0 && ops[OPW * (i - 1) + 6] == cin) {
               const int32_t *bo = ops + OPW * (i - 1);
               const float *save = arena + L.aux_off[i - 1];
               epi.stats = 2;
               epi.partial = stats_ws;
               epi.bn_x = X(bo[1]);
+              epi.ld_bnx = LD(bo[1]);
               epi.mean = save;
               epi.invstd = save + cin;
               epi.gamma = P(bo[4]);
               epi.beta = P(bo[4] + 1);
               epi.leak = opf[4 * (i - 1) + 2];
               pre[i - 1] = stats_ws;
-              pre_nblk[i - 1] = sgnn_conv_grid_blocks(n);
+              pre_nblk[i - 1] = sgnn_conv_grid_blocks(n, cout, cin, K, tiled);
             }
+            epi.ldx = ld_dy;
+            epi.ldy = LD(in0);
             PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
                                         nullptr, 1, 1, K, &epi, stream));
             init[in0] = 1;
             alias[in0] = -1;
           } else {
+            SGNN_CHECK_ARG(ld_dy == cout);               // views are only planned around compiled shapes
             float *t = target(in0, 0);
             PROG_TRY(sgnn_conv_fwd(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, t, flags_b, 0, stream));
             PROG_TRY(commit(in0, t));
           }
         }
-        PROG_TRY(sgnn_conv_bwd_weight(X(in0), n, cin, dy, cout, tab_f, ld_f, K, n_dy, PG(par), 0, dw_base + dw_off,
-                                      dw_slice(v, i), (sgnn_stream_t)lane));
+        PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, LD(in0), dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
+                                           nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
+                                           (sgnn_stream_t)lane));
         dw_off += dw_slice(v, i);
         break;
       }
       case OP_UNPOOL:
         if (wants(in0)) {
           float *t = target(in0, 0);
-          PROG_TRY(sgnn_gather_sum(dy, cin, (const int32_t *)lev_children[lev], lev_ld[lev + 1], 8, lev_n[lev + 1], t,
-                                   stream));
+          PROG_TRY(sgnn_gather_sum_ld(dy, ld_dy, cin, (const int32_t *)lev_children[lev], lev_ld[lev + 1], 8, lev_n[lev + 1],
+                                      t, TLD(in0, t), stream));
           PROG_TRY(commit(in0, t));
         }
         break;
       case OP_BN: {
         const float *save = arena + L.aux_off[i];
         // the kernel adds what the buffer already holds (in place) or the aliased gradient: no scratch pass, no k_add
-        const float *addend = !wants(in0) ? nullptr : (init[in0] == 1 ? G(in0) : (init[in0] == 2 ? G(alias[in0]) : nullptr));
+        const float *addend = nullptr;
+        int64_t ld_add = cin;
+        if (wants(in0) && init[in0] == 1) {
+          addend = G(in0);
+          ld_add = LD(in0);
+        } else if (wants(in0) && init[in0] == 2) {
+          addend = G(alias[in0]);
+          ld_add = LD(alias[in0]);
+        }
         float *t = wants(in0) ? G(in0) : scratch[0];
-        PROG_TRY(sgnn_bn_bwd_impl(X(in0), cin, dy, cin, n, cin, P(par), P(par + 1), save, save + cin, training,
-                                  opf[4 * i + 2], addend, cin, t, cin, PG(par), PG(par + 1), pre[i], pre_nblk[i], ws, ws_bytes,
-                                  stream));
+        PROG_TRY(sgnn_bn_bwd_impl(X(in0), LD(in0), dy, ld_dy, n, cin, P(par), P(par + 1), save, save + cin, training,
+                                  opf[4 * i + 2], addend, ld_add, t, wants(in0) ? LD(in0) : cin, PG(par), PG(par + 1), pre[i],
+                                  pre_nblk[i], ws, ws_bytes, stream));
         if (wants(in0)) {
           init[in0] = 1;
           alias[in0] = -1;
@@ -512,9 +646,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           const int b = side_ ? in1 : in0;
           if (!wants(b)) continue;
           if (init[b] == 1) {
-            PROG_TRY(sgnn_add(G(b), dy, L.buf_floats[b], G(b), stream));
+            PROG_TRY(sgnn_add_ld(G(b), LD(b), dy, ld_dy, n, cin, G(b), LD(b), stream));
           } else if (init[b] == 2) {                            // two aliased contributions: materialise the sum
-            PROG_TRY(sgnn_add(G(alias[b]), dy, L.buf_floats[b], G(b), stream));
+            PROG_TRY(sgnn_add_ld(G(alias[b]), LD(alias[b]), dy, ld_dy, n, cin, G(b), LD(b), stream));
             init[b] = 1;
             alias[b] = -1;
           } else {
@@ -525,6 +659,15 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         break;
       }
       case OP_JOIN: {
+        if (PL.join_view[i]) {                                   // in place: the inputs' gradients ARE column ranges of dy
+          if (init[out] != 1 || init[in0] || init[in1]) {
+            sgnn_set_error("sgnn_prog_backward: in-place JoinTable met an unexpected gradient state");
+            return SGNN_EINVAL;
+          }
+          init[in0] = init[in1] = 1;
+          break;
+        }
+        SGNN_CHECK_ARG(ld_dy == cin + cout && LD(in0) == cin && LD(in1) == cout);   // make_plan: a copying JoinTable never reads views
         float *ta = wants(in0) ? target(in0, 0) : nullptr;
         float *tb = wants(in1) ? target(in1, 1) : nullptr;
         PROG_TRY(sgnn_concat_rows_bwd(dy, cin, nullptr, cout, nullptr, n, ta, n, tb, n, stream));
@@ -544,6 +687,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             d[q] = G(src[q]);
             init[src[q]] = 1;
           }
+        SGNN_CHECK_ARG(ld_dy == CH(out));
         PROG_TRY(sgnn_concat3_rows_bwd(dy, CH(in0), I(o[9]), CH(in1), I(o[10]), CH(o[8]), I(o[11]), n, d[0],
                                        in0 >= 0 ? ROWS(in0) : 0, d[1], in1 >= 0 ? ROWS(in1) : 0, d[2],
                                        o[8] >= 0 ? ROWS(o[8]) : 0, stream));
@@ -557,6 +701,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         float *dwc = garena + L.bextra;
         float *part = dwc + round64(64 * (int64_t)cin * cout);
         const hipStream_t lane = dw_lane();
+        SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
         if (wants(in0) && n > 0) {
           // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
           const int Gs = EXPAND_DX_SPLIT;
@@ -580,6 +725,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           dw[q] = PG(par + 2 * q);
           db[q] = PG(par + 2 * q + 1);
         }
+        SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
         float *t = wants(in0) ? target(in0, 0) : nullptr;
         PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, t, dw, db, ws, ws_bytes, stream));
         if (t) PROG_TRY(commit(in0, t));

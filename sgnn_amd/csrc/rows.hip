@@ -5,6 +5,7 @@
 // :229-247 and :315-336 (mask compaction + concat) and :338-355 (skip join)
 // (SURVEY.md §8 rows a5, a7, a8, a11-a14).  One thread per 4-byte or 16-byte element of the
 // DESTINATION so that every store is coalesced; gathers read whole contiguous rows.
+#include <initializer_list>
 #include "common.h"
 
 // vector width (floats) usable for rows of c floats
@@ -58,6 +59,108 @@ SGNN_EXPORT int sgnn_gather_rows(const float *src, int c, const int32_t *idx, in
   SGNN_CHECK_ARG(src && idx && dst);
   const int cq = c / row_vec(c);
   ROWS_LAUNCH(k_gather_rows, c, m * cq, stream, src, cq, idx, m, dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// strided variants (rows that live in a column range of a wider buffer: JoinTable without a copy, prog.hip):
+// ld_* = row strides in floats; VEC = 4 needs every stride and base pointer 16-byte aligned
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows_ld(const float *__restrict__ src, int64_t ld_src, int cq,
+                                                       const int32_t *__restrict__ idx, int64_t m,
+                                                       float *__restrict__ dst, int64_t ld_dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = m * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    const int32_t i = idx[r];
+    *reinterpret_cast<T *>(dst + r * ld_dst + col * VEC) =
+        (i >= 0) ? *reinterpret_cast<const T *>(src + (int64_t)i * ld_src + col * VEC) : vzero<VEC>();
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_sum_ld(const float *__restrict__ src, int64_t ld_src, int cq,
+                                                      const int32_t *__restrict__ table, int64_t ld, int K,
+                                                      int64_t n_out, float *__restrict__ dst, int64_t ld_dst) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = n_out * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    T acc = vzero<VEC>();
+    for (int k = 0; k < K; ++k) {
+      const int32_t i = table[(int64_t)k * ld + r];
+      if (i >= 0) acc = vadd(acc, *reinterpret_cast<const T *>(src + (int64_t)i * ld_src + col * VEC));
+    }
+    *reinterpret_cast<T *>(dst + r * ld_dst + col * VEC) = acc;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_add_ld(const float *__restrict__ a, int64_t lda, const float *__restrict__ b,
+                                               int64_t ldb, int64_t n, int cq, float *y, int64_t ldy) {
+  typedef typename VecT<VEC>::T T;
+  const int64_t total = n * cq, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+    const int64_t r = g / cq;
+    const int col = (int)(g - r * cq);
+    *reinterpret_cast<T *>(y + r * ldy + col * VEC) =
+        vadd(*reinterpret_cast<const T *>(a + r * lda + col * VEC), *reinterpret_cast<const T *>(b + r * ldb + col * VEC));
+  }
+}
+
+static inline bool ld_vec4(int c, std::initializer_list<int64_t> lds, std::initializer_list<const void *> ptrs) {
+  if (c % 4) return false;
+  for (int64_t l : lds)
+    if (l % 4) return false;
+  for (const void *p : ptrs)
+    if ((uintptr_t)p & 15) return false;
+  return true;
+}
+
+#define ROWS_LAUNCH_V(KERNEL, vec4, total_groups, stream, ...)                                         \
+  do {                                                                                                 \
+    const int grid_ = sgnn_grid_for((total_groups), 256, 4096);                                        \
+    if (vec4)                                                                                          \
+      hipLaunchKernelGGL((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+    else                                                                                               \
+      hipLaunchKernelGGL((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+  } while (0)
+
+int sgnn_gather_rows_ld(const float *src, int64_t ld_src, int c, const int32_t *idx, int64_t m, float *dst,
+                        int64_t ld_dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && m >= 0 && ld_src >= c && ld_dst >= c);
+  if (m == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && idx && dst);
+  const bool v4 = ld_vec4(c, {ld_src, ld_dst}, {src, dst});
+  const int cq = v4 ? c / 4 : c;
+  ROWS_LAUNCH_V(k_gather_rows_ld, v4, m * cq, stream, src, ld_src, cq, idx, m, dst, ld_dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+int sgnn_gather_sum_ld(const float *src, int64_t ld_src, int c, const int32_t *table, int64_t ld, int K, int64_t n_out,
+                       float *dst, int64_t ld_dst, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && n_out >= 0 && K >= 1 && ld >= n_out && ld_src >= c && ld_dst >= c);
+  if (n_out == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(src && table && dst);
+  const bool v4 = ld_vec4(c, {ld_src, ld_dst}, {src, dst});
+  const int cq = v4 ? c / 4 : c;
+  ROWS_LAUNCH_V(k_gather_sum_ld, v4, n_out * cq, stream, src, ld_src, cq, table, ld, K, n_out, dst, ld_dst);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t n, int c, float *y, int64_t ldy,
+                sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(c >= 1 && n >= 0 && lda >= c && ldb >= c && ldy >= c);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(a && b && y);
+  const bool v4 = ld_vec4(c, {lda, ldb, ldy}, {a, b, y});
+  const int cq = v4 ? c / 4 : c;
+  ROWS_LAUNCH_V(k_add_ld, v4, n * cq, stream, a, lda, b, ldb, n, cq, y, ldy);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -219,7 +219,7 @@ def save_predictions(output_path, names, inputs, target_for_sdf, target_for_occs
                                          os.path.join(output_path, '%starget-%d.ply' % (name, h)))
                     else:
                         print('warning: no valid occ points for %s' % os.path.join(output_path, '%starget-%d.ply' % (name, h)))
-                if output_occs[h][k] is not None:
+                if output_occs[h] is not None and output_occs[h][k] is not None:
                     locs = _np(output_occs[h][k])[:, :3]                 # visualize_sparse_locs_as_points: z,y,x -> x,y,z
                     if len(locs):
                         write_points_ply((locs[:, ::-1].astype(np.float32) + 0.5) * factors[h],

@@ -277,21 +277,30 @@ class _ProgramFn(Function):
         for name, cid in prog.class_ids.items():
             lev_n[cid] = run.extra_rows[name]
         nbr = [0] * prog.n_classes
+        tile = [0] * prog.n_classes
+        run.tile_hold = []
         for l in prog.subm_levels:
             nbr[l] = run.grids[l].subm_table().data_ptr()
+            t = run.grids[l].tile_index()
+            if t is not None:
+                run.tile_hold.append(t)
+                tile[l] = t.data_ptr()
         pad = [0] * (prog.n_classes - len(run.downs))
         children = [d.children.data_ptr() for d in run.downs] + pad
         ptable = [d.ptable.data_ptr() for d in run.downs] + pad
         parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + pad
         run.lev_n, run.lev_ld = lev_n, lev_ld
-        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent)]
+        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, tile)]
         run.pptr = _ptr_array([0 if p is None else p.data_ptr() for p in params])
         run.eptr = _ptr_array([t.data_ptr() for t in ext])
         run.iptr = _ptr_array([t.data_ptr() for t in run.idx] + [0])
         ops, opf, bufs = prog.ops_np, prog.opf_np, prog.bufs_np
         nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
+        keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away / never views
+        keep[run.out_bufs] = 1
+        run.keep = keep
         total = _lib.query('sgnn_prog_arena_floats', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
-                           lev_n.ctypes.data, ncls)
+                           lev_n.ctypes.data, ncls, keep.ctypes.data)
         wsb = _lib.query('sgnn_prog_ws_bytes', ops.ctypes.data, nops, lev_n.ctypes.data, ncls)
         run.total, run.wsb = total, wsb
         if PERSISTENT_ARENAS:
@@ -299,18 +308,18 @@ class _ProgramFn(Function):
         else:
             arena = torch.empty(total, dtype=torch.float32, device=dev)
         ws = rt.workspace(wsb)
-        keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away
-        keep[run.out_bufs] = 1
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, ncls, run.pptr.ctypes.data, len(params),
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls, run.pptr.ctypes.data,
+                  len(params),
                   run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), total,
                   keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
         run.offsets = {}
         outs = []
         for b in run.out_bufs:
             off = _lib.query('sgnn_prog_buffer_offset', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
-                             lev_n.ctypes.data, ncls, b)
+                             lev_n.ctypes.data, ncls, keep.ctypes.data, b)
+            assert off >= 0
             rows, ch = int(lev_n[bufs[b, 0]]), int(bufs[b, 1])
             run.offsets[b] = (off, rows, ch)
             outs.append(arena[off:off + rows * ch].view(rows, ch))
@@ -365,10 +374,11 @@ class _ProgramFn(Function):
         rt.side_lane(run.wsb)
         _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, ncls, run.pptr.ctypes.data, gp.ctypes.data,
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls, run.pptr.ctypes.data,
+                  gp.ctypes.data,
                   len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
-                  arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, int(run.training), ws.data_ptr(),
-                  run.wsb)
+                  arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, run.keep.ctypes.data,
+                  int(run.training), ws.data_ptr(), run.wsb)
         return (None,) + tuple(gext) + tuple(views)
 
 

@@ -97,5 +97,10 @@ def test_save_predictions_files_match_reference(g, tmp_path):
     for f, key in (('scene0_input-mesh.ply', 'pred_scene0_input_mesh_ply'), ('scene0_pred-mesh.ply', 'pred_scene0_pred_mesh_ply')):
         got = np.fromfile(str(tmp_path / f), dtype=np.uint8)
         assert got.size > 1000 and np.array_equal(got, g[key]), f
-    with pytest.raises(NotImplementedError):
-        mc.save_predictions(str(tmp_path), names, inputs, None, None, pred, [None], None, 3.0)
+    # per-level occupancy point clouds (data_util.py:268-276): one vertex per predicted site, z,y,x -> x,y,z, voxel
+    # centres scaled to the finest resolution; a level without predictions writes nothing
+    locs = torch.tensor([[1, 2, 3, 0], [4, 5, 6, 0]])
+    mc.save_predictions(str(tmp_path), names, inputs, None, None, pred, [None, [locs]], None, 3.0)
+    assert not (tmp_path / 'scene0_pred-0.ply').exists()
+    txt = (tmp_path / 'scene0_pred-1.ply').read_bytes()
+    assert b'element vertex 2' in txt

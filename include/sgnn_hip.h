@@ -89,6 +89,16 @@ int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         sgnn_stream_t stream);
 
+/* The same table through a dense index volume (volume[((b*Z + z)*Y + y)*X + x] = row, -1 elsewhere): one coalesced
+ * 4-byte read per neighbour instead of a hash probe.  `volume` is a persistent workspace of volume_entries int32 that
+ * the caller fills with -1 ONCE; the call marks this level's rows, builds the table and clears the rows again, so the
+ * volume is all -1 on return.  Blocks with batch index >= volume_entries / (Z*Y*X) and positions outside [0, dims) go
+ * through the hash grid (keys / vals / cap): the table equals sgnn_rulebook_subm3's for every input.
+ * Measured at N = 366 k (64^3 x 32 blocks): see profiles/ (r02j). */
+int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords, int64_t n,
+                              int dim_z, int dim_y, int dim_x, int32_t *volume, int64_t volume_entries, int32_t *nbr,
+                              int64_t ld, sgnn_stream_t stream);
+
 /* Tile index of a 3x3x3 table (ld % 256 == 0): per 128-row tile the unique input rows its rules refer to and the
  * table in 16-bit tile-local slots (tiles with more than 768 unique rows are flagged and keep using the int32 table).
  * Large levels of narrow layers (cin, cout <= 16) then run sgnn_conv_fwd_tiled: each unique row is copied into LDS once

@@ -427,6 +427,108 @@ SGNN_EXPORT int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgn
   return SGNN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same rulebook through a dense index volume: vol[((b*Z + z)*Y + y)*X + x] = row of the site, -1 elsewhere.  A
+// neighbour look-up is then ONE 4-byte read next to the reads of the neighbouring threads (sites arrive in raster or
+// children order) instead of a hash probe into a random 8-byte key plus the value read, and all 27 entries of a site
+// are written by its own thread (coalesced; no mirror scatter, no pre-fill).  The volume is a persistent workspace that
+// is all -1 between calls: k_vol_mark writes the rows of this level, the table kernel reads, k_vol_mark clears them
+// again (n scattered 4-byte writes each, instead of a memset of the whole volume).  Positions the volume does not
+// cover — batch index >= bcap = entries / (Z*Y*X), or a coordinate outside [0, dims) — are looked up in the hash grid,
+// and such sites are not marked: the result is the hash rulebook's for every input.
+// ---------------------------------------------------------------------------
+struct VolDims {
+  int Z, Y, X, bcap;
+};
+
+__device__ __forceinline__ bool vol_covers(const VolDims d, int z, int y, int x, int b) {
+  return (unsigned)z < (unsigned)d.Z && (unsigned)y < (unsigned)d.Y && (unsigned)x < (unsigned)d.X &&
+         (unsigned)b < (unsigned)d.bcap;
+}
+
+__global__ __launch_bounds__(256) void k_vol_mark(const int4 *__restrict__ coords, int64_t n, int32_t *__restrict__ vol,
+                                                 VolDims d, int clear) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int4 c = coords[j];
+  if (vol_covers(d, c.x, c.y, c.z, c.w)) vol[(((int64_t)c.w * d.Z + c.x) * d.Y + c.y) * d.X + c.z] = clear ? -1 : (int32_t)j;
+}
+
+__global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__restrict__ keys,
+                                                           const int32_t *__restrict__ vals, uint64_t mask,
+                                                           const int4 *__restrict__ coords, int64_t n,
+                                                           const int32_t *__restrict__ vol, VolDims d,
+                                                           int32_t *__restrict__ nbr, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= ld) return;
+  if (j >= n) {                                 // padding entries: the conv kernels rely on them being -1
+#pragma unroll
+    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
+    return;
+  }
+  const int4 c = coords[j];
+  // interior site of a covered block: 26 plain reads, all in flight together
+  const bool inner = c.x >= 1 && c.x + 1 < d.Z && c.y >= 1 && c.y + 1 < d.Y && c.z >= 1 && c.z + 1 < d.X &&
+                     (unsigned)c.w < (unsigned)d.bcap;
+  if (inner) {
+    const int32_t *p = vol + (((int64_t)c.w * d.Z + c.x) * d.Y + c.y) * d.X + c.z;
+    int32_t r[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+      r[k] = k == 13 ? (int32_t)j : p[((int64_t)dz * d.Y + dy) * d.X + dx];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = r[k];
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < 27; ++k) {
+      const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+      const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
+      int32_t v = -1;
+      if (k == 13) {
+        v = (int32_t)j;
+      } else if (vol_covers(d, z, y, x, c.w)) {
+        v = vol[(((int64_t)c.w * d.Z + z) * d.Y + y) * d.X + x];
+      } else if (((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u)) {
+        const uint64_t key = sgnn_pack_key(z, y, x, c.w);
+        uint64_t sl = sgnn_hash64(key) & mask;
+        while (true) {
+          const uint64_t kk = keys[sl];
+          if (kk == key) {
+            v = vals[sl];
+            break;
+          }
+          if (kk == SGNN_EMPTY_KEY) break;
+          sl = (sl + 1) & mask;
+        }
+      }
+      nbr[(int64_t)k * ld + j] = v;
+    }
+  }
+}
+
+SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords,
+                                          int64_t n, int dim_z, int dim_y, int dim_x, int32_t *volume,
+                                          int64_t volume_entries, int32_t *nbr, int64_t ld, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
+  SGNN_CHECK_ARG(dim_z >= 1 && dim_y >= 1 && dim_x >= 1 && dim_z <= 65536 && dim_y <= 65536 && dim_x <= 65536 &&
+                 volume_entries >= 0 && (volume || volume_entries == 0));
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords && nbr);
+  const int64_t slab = (int64_t)dim_z * dim_y * dim_x;
+  const int64_t bcap = volume_entries / slab;
+  const VolDims d{dim_z, dim_y, dim_x, (int)(bcap > 65536 ? 65536 : bcap)};
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned gn = (unsigned)((n + 255) / 256);
+  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0);
+  hipLaunchKernelGGL(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, keys, vals,
+                     (uint64_t)(cap - 1), (const int4 *)coords, n, volume, d, nbr, ld);
+  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 static int g_rulebook_lds = 0;   // sgnn_rulebook_set_lds(1) selects the LDS-window kernel (parity test, A/B)
 SGNN_EXPORT int sgnn_rulebook_set_lds(int on) {
   const int prev = g_rulebook_lds;

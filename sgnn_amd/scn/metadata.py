@@ -29,6 +29,12 @@ class _Runtime(object):
         self.status32 = self.state[1:2].view(torch.int32)  # two int32 words, first one used
         self.syncs = 0                                     # host read-backs so far (bench / tests)
 
+    def index_volume(self):
+        """Persistent dense index volume of the rulebook builder (sgnn_rulebook_subm3_dense): all -1 between calls."""
+        if getattr(self, '_volume', None) is None:
+            self._volume = torch.full((INDEX_VOLUME_ENTRIES,), -1, dtype=torch.int32, device=self.device)
+        return self._volume
+
     def workspace(self, nbytes):
         if self.ws.numel() < nbytes:
             self.ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
@@ -110,6 +116,17 @@ if TILE_MIN_ROWS < 0:
     TILE_MIN_ROWS = 1 << 62
 
 
+# 3x3x3 rulebooks of levels with at least DENSE_RULEBOOK_MIN_ROWS rows whose spatial size is known (levels registered
+# in a Metadata) are built through a dense index volume instead of hash probes (grid_rules.hip: k_rulebook_subm3_vol;
+# identical tables).  Below that the three small launches of the dense path cost more than the probes save.
+# SGNN_DENSE_RULEBOOK_MIN_ROWS=-1 switches the path off; SGNN_INDEX_VOLUME_MB sizes the volume (blocks it does not cover
+# fall back to the hash inside the kernel).
+DENSE_RULEBOOK_MIN_ROWS = int(os.environ.get('SGNN_DENSE_RULEBOOK_MIN_ROWS', '16384'))
+if DENSE_RULEBOOK_MIN_ROWS < 0:
+    DENSE_RULEBOOK_MIN_ROWS = 1 << 62
+INDEX_VOLUME_ENTRIES = int(os.environ.get('SGNN_INDEX_VOLUME_MB', '128')) << 18
+
+
 def _round_up(n, m):
     return ((n + m - 1) // m) * m
 
@@ -125,6 +142,7 @@ class Grid(object):
         self.keys, self.vals, self.cap = keys, vals, cap
         self._nbr = None
         self._tile = None
+        self.dims = None       # spatial size (z, y, x) of the level once a Metadata registers the grid
         self.ld = _round_up(max(self.n, 1), 256)   # table leading dimension (conv kernels: multiple of 256)
 
     def hash(self):
@@ -150,8 +168,15 @@ class Grid(object):
         if self._nbr is None:
             keys, vals, cap = self.hash()
             self._nbr = torch.empty(27 * self.ld, dtype=torch.int32, device=self.device)
-            _lib.call('sgnn_rulebook_subm3', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, ptr(self._nbr),
-                      self.ld)
+            d = self.dims
+            if (d is not None and len(d) == 3 and self.n >= DENSE_RULEBOOK_MIN_ROWS
+                    and 0 < d[0] * d[1] * d[2] <= INDEX_VOLUME_ENTRIES and max(d) <= 65536):
+                vol = runtime(self.device).index_volume()
+                _lib.call('sgnn_rulebook_subm3_dense', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, int(d[0]),
+                          int(d[1]), int(d[2]), ptr(vol), vol.numel(), ptr(self._nbr), self.ld)
+            else:
+                _lib.call('sgnn_rulebook_subm3', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, ptr(self._nbr),
+                          self.ld)
         return self._nbr
 
     def tile_index(self):
@@ -262,17 +287,22 @@ class Metadata(object):
     def key(spatial_size):
         return spatial_size if isinstance(spatial_size, tuple) else tuple(int(s) for s in spatial_size)
 
+    def _register(self, key, grid):
+        self.grids[key] = grid
+        if grid.dims is None:
+            grid.dims = key
+
     def set_input(self, spatial_size, grid):
-        self.grids[self.key(spatial_size)] = grid
+        self._register(self.key(spatial_size), grid)
 
     def adopt(self, spatial_size, grid0, downs):
         """Register a finalized PendingChain: level 0 at `spatial_size`, level l at spatial_size / 2^l."""
         key = self.key(spatial_size)
-        self.grids[key] = grid0
+        self._register(key, grid0)
         for d in downs:
             nxt = tuple(v // 2 for v in key)
             self.down[(key, nxt)] = d
-            self.grids[nxt] = d.coarse
+            self._register(nxt, d.coarse)
             key = nxt
 
     def prebuild(self, spatial_size, depth):
@@ -311,7 +341,7 @@ class Metadata(object):
         if k not in self.down:
             d = build_down2(self.grid(in_size))
             if self.key(out_size) not in self.grids:
-                self.grids[self.key(out_size)] = d.coarse
+                self._register(self.key(out_size), d.coarse)
             self.down[k] = d
         return self.down[k]
 

@@ -121,7 +121,7 @@ class InputLayer(nn.Module):
             md.adopt(key, g, plan[1])
         else:
             g = Grid(coords)
-            md.grids[key] = g
+            md.set_input(key, g)
         return SparseConvNetTensor(feats, md, key, g)
 
 

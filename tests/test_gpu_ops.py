@@ -277,3 +277,55 @@ def test_tile_conv_equals_gather_conv(order, cin, cout):
     _lib.call('sgnn_conv_fwd', x.data_ptr(), g.n, cin, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, cout,
               ref.data_ptr(), 0, 0)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('order', ['raster', 'shuffled', 'children'])
+@pytest.mark.parametrize('volume_blocks', [8, 1, 0])
+def test_dense_volume_rulebook_equals_hash_rulebook(order, volume_blocks):
+    """sgnn_rulebook_subm3_dense (neighbours read from a dense index volume) must produce the hash rulebook's table for
+    every input: all site orders, sites on the volume boundary, sites outside the declared spatial size, and batch
+    indices the volume does not cover (volume_blocks = 1: blocks 1, 2 go through the hash; 0: everything does).  The
+    volume must be all -1 again afterwards."""
+    from sgnn_amd import synth, _lib
+    from sgnn_amd.scn import functions as F_
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    dev = torch.device('cuda')
+    dims = (32, 32, 32)
+    locs = synth.make_batch(3, dims, cfg=9, occupancy=0.1)['input'][0]
+    # boundary faces / corners and a few sites outside the declared size (their neighbours must still find them)
+    extra = torch.tensor([[0, 0, 0, 0], [31, 31, 31, 1], [0, 31, 0, 2], [32, 5, 5, 0], [31, 5, 5, 0], [33, 5, 5, 0],
+                          [5, 32, 31, 1], [5, 31, 31, 1]], dtype=locs.dtype)
+    locs = torch.unique(torch.cat([locs, extra]), dim=0)
+    if order == 'shuffled':
+        locs = locs[torch.randperm(locs.shape[0], generator=torch.Generator().manual_seed(0))]
+    coords = coords_from_locs(locs, dev)
+    if order == 'children':
+        coords = F_.expand8_coords(coords)
+        dims = (64, 64, 64)
+    g = Grid(coords)
+    ref = g.subm_table().clone()
+    keys, vals, cap = g.hash()
+    entries = volume_blocks * dims[0] * dims[1] * dims[2]
+    vol = torch.full((max(entries, 1),), -1, dtype=torch.int32, device=dev)
+    out = torch.full_like(ref, 12345)
+    _lib.call('sgnn_rulebook_subm3_dense', keys.data_ptr(), vals.data_ptr(), cap, coords.data_ptr(), g.n, dims[0],
+              dims[1], dims[2], vol.data_ptr(), entries, out.data_ptr(), g.ld)
+    assert torch.equal(out, ref)
+    assert int((vol != -1).sum()) == 0
+
+
+def test_registered_levels_use_the_dense_rulebook_and_match():
+    """Grids registered in a Metadata know their spatial size and build large rulebooks through the volume."""
+    from sgnn_amd import synth
+    import sgnn_amd.scn as scn
+    from sgnn_amd.scn import metadata as MD
+    locs = synth.make_batch(4, (64, 64, 64), cfg=2)['input'][0].cuda()
+    assert locs.shape[0] >= MD.DENSE_RULEBOOK_MIN_ROWS
+    feats = torch.zeros(locs.shape[0], 1, device='cuda')
+    x = scn.InputLayer(3, (64, 64, 64), mode=0)([locs, feats])
+    g = x.grid()
+    assert g.dims == (64, 64, 64)
+    tab = g.subm_table()
+    ref = MD.Grid(g.coords).subm_table()       # unregistered: hash path
+    assert torch.equal(tab, ref)
+    assert int((MD.runtime(locs.device).index_volume() != -1).sum()) == 0

@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--free-running', action='store_true',
                     help='generative masks from the predicted occupancy (the reference\'s behaviour; per-level row counts '
                          'then depend on the random weights).  Default: teacher-forced masks from the target hierarchy')
+    ap.add_argument('--no-other-mode', action='store_true', help='skip the extra steps in the other mask mode (profiling runs)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes behind roofline.traffic')
     ap.add_argument('--traffic-probe', action='store_true', help='internal: launch the dominant kernel a few times (run under rocprofv3 --pmc)')
     return ap.parse_args()
@@ -390,7 +391,7 @@ def main():
     # the other mask mode on the same batches (what BENCH_r01 measured: masks from the predicted occupancy, per-level
     # row counts depend on the weights), reported next to the headline for comparability across rounds
     other = None
-    if args.steps >= 20:
+    if args.steps >= 20 and not args.no_other_mode:
         def step_other(i):
             return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=not teacher)
         k2 = max(10, args.steps // 3)

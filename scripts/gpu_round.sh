@@ -14,16 +14,17 @@ timeout -k 10 200 python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline >
 cat gpurun_out/${TAG}_bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value'], d['unit'], d['ms_per_step'], 'ms/step', 'frac', d['roofline']['frac'], d['config']['generated_sites_per_level'])"
 export TMPDIR=/tmp; D=/tmp/prof_$TAG; rm -rf $D
 ROOT=$(pwd)
-(cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)
+(cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --no-traffic --no-other-mode > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)
 tail -3 $ROOT/gpurun_out/${TAG}_prof.err
 F=$(find $D -name '*kernel_stats.csv' | head -1)
 if [ -n "$F" ]; then
   cp $F gpurun_out/${TAG}_bench_kernel_stats.csv
-  python scripts/prof_summary.py $F $((STEPS+10)) 70 > gpurun_out/${TAG}_bench_kernel_summary.txt
+  python scripts/prof_summary.py $F $((STEPS+11)) 70 > gpurun_out/${TAG}_bench_kernel_summary.txt
+  python scripts/prof_categories.py $F $((STEPS+11)) > gpurun_out/${TAG}_bench_categories.txt 2>/dev/null
   head -30 gpurun_out/${TAG}_bench_kernel_summary.txt
   python - <<PY
 import csv
 rows=list(csv.DictReader(open("$F")))
-print('launches/step: %.0f' % (sum(int(r['Calls']) for r in rows)/float($STEPS+10)))
+print('launches/step: %.0f' % (sum(int(r['Calls']) for r in rows)/float($STEPS+11)))
 PY
 fi

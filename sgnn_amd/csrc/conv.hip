@@ -1020,14 +1020,14 @@ struct DwCfg {
   static constexpr int KPB = (MT * NT == 1) ? 9 : ((MT * NT <= 3) ? 5 : 3);
 };
 
-template <int CIN, int COUT, bool EX>
+template <int CIN, int COUT, bool EX, int KPBT = 0>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift, ConvEx ex, int64_t ldx,
                                                 int64_t ld_dy) {
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
-  constexpr int DW_KPB = DwCfg<CIN, COUT>::KPB;
+  constexpr int DW_KPB = KPBT > 0 ? KPBT : DwCfg<CIN, COUT>::KPB;
   constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
   constexpr int W = (COUT + 3) / 4, COUTP = 4 * W;      // dy quarter-row width
   constexpr int XS = 64 * CINP, YS = 64 * COUTP;        // per-wave LDS tiles (64 rows)
@@ -1302,6 +1302,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
   dw[e] = s;
 }
 
+#define DW_FINE_ROWS 16384   // below: one offset per weight-gradient workgroup
 static int64_t dw_rows_per_block(int64_t n_out) {
   int64_t rpb = (n_out + 255) / 256;           // <= 256 row blocks
   rpb = ((rpb + 255) / 256) * 256;             // whole 256-row wave rounds
@@ -1372,9 +1373,21 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     }                                                                                                      \
     constexpr int kpb_ = DwCfg<CI, CO>::KPB;                                                               \
     const int prof = sgnn_prof_begin_launch(1, n_out * groups, cin, cout, K, 0, s);                        \
-    hipLaunchKernelGGL((k_conv_dw<CI, CO, EXV>),                                                           \
-                       dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, s, \
-                       x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy);      \
+    if constexpr (!EXV && kpb_ == 9) {                                                                     \
+      /* small level of a narrow layer: 256 rows x 9 offsets per workgroup leaves most CUs idle and makes */ \
+      /* every wave walk 9 dependent gather rounds -> one offset per workgroup (same sums, same order)     */ \
+      if (n_out < DW_FINE_ROWS && g_small_kernel)                                                          \
+        hipLaunchKernelGGL((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
+                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy);  \
+      else                                                                                                 \
+        hipLaunchKernelGGL((k_conv_dw<CI, CO, false>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
+                           dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift,  \
+                           ex, ldx, ld_dy);                                                                \
+    } else {                                                                                               \
+      hipLaunchKernelGGL((k_conv_dw<CI, CO, EXV>),                                                         \
+                         dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, \
+                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy); \
+    }                                                                                                      \
     sgnn_prof_end_launch(prof, s);                                                                         \
     if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
       sgnn_dw_batch->d[sgnn_dw_batch->n++] = DwDesc{(const float *)ws, dw, nblk, elems, 0};                \

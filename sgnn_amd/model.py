@@ -16,6 +16,8 @@ and the same module/attribute names, so a reference checkpoint's state_dict load
     is the row BatchNorm.  (MIOpen fell back to naive 3D kernels here: ~45 % of the step in
     profiles/r01a_bench_kernel_stats_first.csv.)  Only the 1x1x1 convolutions remain plain rocBLAS GEMMs.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -28,6 +30,8 @@ from .scn.metadata import coords_from_locs
 
 
 STAGES = True   # each generative stage (skip join .. heads) as one native program; False: per-module glue
+# teacher-forced forward: all generative levels' geometry (and its host read-backs) before the first heavy kernel
+TEACHER_GEOMETRY_FIRST = os.environ.get('SGNN_TEACHER_GEOMETRY_FIRST', '1') != '0'
 
 
 def _dense_block(cin, cout, k, stride, pad, transposed=False):
@@ -315,7 +319,8 @@ class Refinement(nn.Module):
         x0 = self.p0([locs, ext[0]])
         outs, _, _ = P_.run_program(prog, x0, self.training, [prog.taps[id(self.n2)][0], prog.taps[id(self.linear)][0]],
                                     ext=ext, idx=idx, extra_rows=extra)
-        return outs[0], outs[1], F_.expand8_coords(locs)
+        children = getattr(locs, '_sgnn_children', None)     # already made by GenModel._teacher_plans
+        return outs[0], outs[1], (children if children is not None else F_.expand8_coords(locs))
 
 
 def _stage_program(owner, prev, skip, chain, nf_in, tail):
@@ -448,16 +453,25 @@ class GenModel(nn.Module):
         target_for_occs); when given, every generative mask is `target occupancy == 1` at the candidate site instead of
         sigmoid(predicted occupancy) > 0.5, so the per-level site counts do not depend on the weights (bench.py)."""
         x = [coords_from_locs(x[0], x[1].device), x[1]]
-        feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
-        if self.use_skip_sparse:
-            skips = [(t.grid(), t.features) for t in skips]
         R = len(self.refinement)
         # which later stage consumes a compaction's sites (its U-Net needs a 2-level stride-2 pyramid)?
         runs = [loss_weights[h + 1] > 0 for h in range(R)] + [bool(self.PRED_SURF and loss_weights[-1] > 0)]
         for h in range(R):
             self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
+        plans = None
+        if teacher is not None and batch_size is not None and TEACHER_GEOMETRY_FIRST and P_.ENABLED and STAGES:
+            # teacher-forced masks depend on the data only: build the site lists, index lists and stride-2 pyramids of
+            # ALL generative levels now, while the GPU queue is short.  Their row-count read-backs then wait for a few
+            # small kernels each instead of for a whole stage's convolutions, and everything after them — encoder,
+            # stages, loss, backward, Adam — is issued without a single host synchronisation.
+            enc = self.encoder
+            dims = tuple(int(v) >> len(enc.process_sparse) for v in enc.process_sparse[0].p0.spatial_size)
+            plans = self._teacher_plans(dense_geometry(batch_size, dims, x[1].device), runs, teacher)
+        feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
+        if self.use_skip_sparse:
+            skips = [(t.grid(), t.features) for t in skips]
         if P_.ENABLED and STAGES:
-            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher)
+            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher, plans)
             if res is not None:
                 if not self.training:     # inference: report input errors (duplicate / out-of-range sites) from THIS call
                     from .scn.metadata import runtime
@@ -487,7 +501,24 @@ class GenModel(nn.Module):
             return [locs_out, sdf], outputs
         return [[], []], outputs
 
-    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher=None):
+    def _teacher_plans(self, geo, runs, teacher):
+        """The compactions of _forward_stages for teacher-forced masks, without the features: plans[0] for the coarse
+        volume, plans[h + 1] after refinement h (None where _forward_stages would not compact)."""
+        R = len(self.refinement)
+        plan = F_.compact_sigmoid_plan(geo.coords, 2, int(geo.coords.shape[0]), geo.coords, 2 if runs[0] else 0, teacher[0])
+        plans = [plan]
+        for h in range(R):
+            if not runs[h] or plan[1] == 0:
+                plans.append(None)
+                continue
+            locs = plan[2]
+            locs._sgnn_children = F_.expand8_coords(locs)
+            plan = F_.compact_sigmoid_plan(locs._sgnn_children, 2, 8 * plan[1], locs._sgnn_children,
+                                           self.refinement[h].plan_depth, teacher[h + 1])
+            plans.append(plan)
+        return plans
+
+    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher=None, plans=None):
         """forward() with every generative stage as one native program (Refinement.stage / SurfacePrediction.stage):
         the kept rows of a level are never gathered into their own tensor — the next stage's CONCAT_IN reads them
         through the compaction's index list.  Same results as the per-module path (tests/test_gpu_program.py)."""
@@ -499,7 +530,10 @@ class GenModel(nn.Module):
         outputs = [[geo.coords_i64, occ_rows]]
         n_all = occ_rows.shape[0]
         tv = (lambda h: None) if teacher is None else (lambda h: teacher[h])
-        sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0, tv(0))
+        if plans is not None:
+            sel, cnt, locs = plans[0]
+        else:
+            sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0, tv(0))
         # channel order of model.py:330: [occ, sdf | features]
         prev = (occ_rows if self.pass_occ else None, feat_rows if self.pass_feats else None, sel, locs, cnt)
         for h in range(R):
@@ -515,7 +549,10 @@ class GenModel(nn.Module):
                 return None if h == 0 else self._stage_fallback()
             y, out, coords_next = got
             outputs.append([F_.coords_to_i64(coords_next), out])
-            sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth, tv(h + 1))
+            if plans is not None:
+                sel, cnt, locs = plans[h + 1]
+            else:
+                sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth, tv(h + 1))
             # channel order of model.py:242: [features | occ, sdf]
             prev = (y if ref.pass_feats else None, out if ref.pass_occ else None, sel, locs, cnt)
         if not runs[R]:

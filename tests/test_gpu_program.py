@@ -231,3 +231,35 @@ def test_program_with_tile_kernel_equals_gather_kernel():
 
 def prog_params(chain):
     return [p for m in chain for p in m.parameters()]
+
+
+def test_teacher_forced_geometry_first_is_the_same_computation():
+    """Teacher-forced step with all level geometry built up front (model.TEACHER_GEOMETRY_FIRST: one burst of cheap
+    read-backs, then a synchronisation-free step) == the interleaved order: same site lists, same logits, same loss,
+    same gradients, bit for bit; and the up-front variant does not touch the host between encoder and optimizer."""
+    from sgnn_amd import model as M
+    from sgnn_amd.train import train_step, to_device, make_optimizer
+    from sgnn_amd.scn.metadata import runtime
+    dims, cfg = (32, 32, 32), 17
+    batch = to_device(synth.make_batch(2, dims, cfg=cfg, occupancy=0.08), 'cuda')
+    lw = np.ones(5, dtype=np.float32)
+    res = []
+    for first in (False, True):
+        prev = M.TEACHER_GEOMETRY_FIRST
+        M.TEACHER_GEOMETRY_FIRST = first
+        try:
+            m = param_fill(M.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
+            opt = make_optimizer(m.parameters(), lr=1e-3)
+            rt = runtime(torch.device('cuda', torch.cuda.current_device()))
+            s0 = rt.syncs
+            loss, _, (osdf, oocc) = train_step(m, opt, batch, lw, teacher_forced=True)
+            res.append((loss.item(), osdf[0].clone(), osdf[1].clone(), [o[1].clone() for o in oocc],
+                        [p.detach().clone() for p in m.parameters()], rt.syncs - s0))
+        finally:
+            M.TEACHER_GEOMETRY_FIRST = prev
+    a, b = res
+    assert a[0] == b[0]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    assert all(torch.equal(x, y) for x, y in zip(a[4], b[4]))     # parameters after the Adam step
+    assert a[5] == b[5]                                            # same number of read-backs, only earlier

@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--free-running', action='store_true',
                     help='generative masks from the predicted occupancy (the reference\'s behaviour; per-level row counts '
                          'then depend on the random weights).  Default: teacher-forced masks from the target hierarchy')
+    ap.add_argument('--no-prefetch', action='store_true',
+                    help='teacher-forced steps build their own geometry (5 read-backs at the head of the step) instead of '
+                         'having it built one batch ahead on a second stream (train.GeometryPrefetcher)')
     ap.add_argument('--no-other-mode', action='store_true', help='skip the extra steps in the other mask mode (profiling runs)')
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes behind roofline.traffic')
     ap.add_argument('--traffic-probe', action='store_true', help='internal: launch the dominant kernel a few times (run under rocprofv3 --pmc)')
@@ -336,7 +339,8 @@ def main():
     from sgnn_amd.model import GenModel
     from sgnn_amd.scn import program as P_
     P_.PERSISTENT_ARENAS = True          # grow-only program arenas (a training loop never keeps two forward results)
-    from sgnn_amd.train import train_step, to_device, FlatGradAllReduce, make_optimizer, bind_to_device_numa
+    from sgnn_amd.train import (train_step, to_device, FlatGradAllReduce, make_optimizer, bind_to_device_numa,
+                                GeometryPrefetcher)
     bound = bind_to_device_numa(dev)          # one process per GPU, on that GPU's NUMA node
     lib = _lib.load()
     _lib.require_gpu()
@@ -354,8 +358,13 @@ def main():
 
     teacher = not args.free_running
 
+    # teacher-forced: batch i+1's geometry (all host read-backs of a step) is built on a second stream during step i,
+    # as a training loop with a prefetching loader would; every step's geometry is still computed once per step
+    pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch) else None
+
     def step(i):
-        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher)
+        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher, prefetch=pre,
+                          next_batch=batches[(i + 1) % 2] if pre is not None else None)
 
     n_prof_steps = 0
     for i in range(args.warmup):
@@ -480,6 +489,8 @@ def main():
                                       'the random weights)' if teacher else 'generative masks from the predicted occupancy'),
                        'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
                        'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world,
+                       'geometry': ('built one batch ahead on a second stream during the previous step (once per step; '
+                                    'train.GeometryPrefetcher)' if pre is not None else 'built at the head of its own step'),
                        'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
             'roofline': roof, 'cpu_baseline': cpu, 'other_mask_mode': other,
         }

@@ -448,18 +448,48 @@ class GenModel(nn.Module):
         self.surfacepred.p0.spatial_size[:] = torch.from_numpy(ref * 2 ** len(self.refinement))
 
     # -- forward -----------------------------------------------------------------------------------------
-    def forward(self, x, loss_weights, batch_size=None, teacher=None):
-        """teacher (optional, not in the reference): list of the L dense target occupancy volumes (loss.compute_targets'
-        target_for_occs); when given, every generative mask is `target occupancy == 1` at the candidate site instead of
-        sigmoid(predicted occupancy) > 0.5, so the per-level site counts do not depend on the weights (bench.py)."""
-        x = [coords_from_locs(x[0], x[1].device), x[1]]
+    def _runs(self, loss_weights):
         R = len(self.refinement)
         # which later stage consumes a compaction's sites (its U-Net needs a 2-level stride-2 pyramid)?
         runs = [loss_weights[h + 1] > 0 for h in range(R)] + [bool(self.PRED_SURF and loss_weights[-1] > 0)]
         for h in range(R):
             self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
-        plans = None
-        if teacher is not None and batch_size is not None and TEACHER_GEOMETRY_FIRST and P_.ENABLED and STAGES:
+        return runs
+
+    def plan_geometry(self, locs, loss_weights, batch_size, teacher):
+        """Everything a teacher-forced forward() reads back from the device, computed from the batch alone: the input
+        coordinates with the encoder's stride-2 pyramid attached, and the site / index lists + pyramids of every
+        generative level (_teacher_plans).  Returns `geometry` for forward(..., geometry=...), which then runs without a
+        host synchronisation.  A training loop may call this for batch i+1 on a second stream while batch i's backward
+        pass runs (train.GeometryPrefetcher)."""
+        from .scn import metadata as MD
+        dev = teacher[0].device
+        coords = coords_from_locs(locs, dev)
+        depth = len(self.encoder.process_sparse)
+        if MD.CHAIN and depth >= 2 and coords.shape[0]:
+            n = int(coords.shape[0])
+            chain = MD.PendingChain(coords, n, False, depth)
+            coords._sgnn_plan = chain.finalize(n, MD.runtime(dev).read_counts())
+        enc = self.encoder
+        dims = tuple(int(v) >> depth for v in enc.process_sparse[0].p0.spatial_size)
+        plans = self._teacher_plans(dense_geometry(batch_size, dims, dev), self._runs(loss_weights), teacher)
+        return coords, plans
+
+    def forward(self, x, loss_weights, batch_size=None, teacher=None, geometry=None):
+        """teacher (optional, not in the reference): list of the L dense target occupancy volumes (loss.compute_targets'
+        target_for_occs); when given, every generative mask is `target occupancy == 1` at the candidate site instead of
+        sigmoid(predicted occupancy) > 0.5, so the per-level site counts do not depend on the weights (bench.py).
+        geometry: result of plan_geometry() for this batch and these loss weights (teacher-forced only)."""
+        if geometry is not None:
+            if teacher is None or not (P_.ENABLED and STAGES):
+                raise ValueError('geometry plans belong to the teacher-forced native stage path')
+            x = [geometry[0], x[1]]
+        x = [coords_from_locs(x[0], x[1].device), x[1]]
+        R = len(self.refinement)
+        runs = self._runs(loss_weights)
+        plans = None if geometry is None else geometry[1]
+        if (plans is None and teacher is not None and batch_size is not None and TEACHER_GEOMETRY_FIRST and P_.ENABLED
+                and STAGES):
             # teacher-forced masks depend on the data only: build the site lists, index lists and stride-2 pyramids of
             # ALL generative levels now, while the GPU queue is short.  Their row-count read-backs then wait for a few
             # small kernels each instead of for a whole stage's convolutions, and everything after them — encoder,

@@ -181,10 +181,77 @@ def _target_stream(dev):
     return s
 
 
+class StepPlan(object):
+    """What a teacher-forced step needs from its batch alone: targets + loss weights, input coordinates with the
+    encoder pyramid, site / index lists of every generative level.  `ready` is recorded on the stream that built it."""
+    __slots__ = ('batch', 'loss_weights', 'targets', 'weights', 'geometry', 'ready')
+
+
+class GeometryPrefetcher(object):
+    """Teacher-forced training, one batch ahead: the geometry of a step (every host read-back it has) is a function of
+    the batch, so batch i+1's StepPlan is built on a second stream while batch i's backward pass occupies the GPU, and
+    the main stream never drains at a step boundary.
+
+        pre = GeometryPrefetcher(model)
+        for i, batch in enumerate(batches):
+            train_step(model, opt, batch, lw, teacher_forced=True, prefetch=pre, next_batch=batches[i + 1])
+
+    Memory discipline: plan tensors are allocated on the prefetch stream and read by main-stream kernels of the NEXT
+    step; a plan is dropped when its step has been issued, and the next allocation on the prefetch stream happens only
+    after the host has waited for the step BEFORE that one to finish on the GPU (`throttle`), which also keeps the
+    host at most one step ahead of the device.  The prefetch stream uses scratch lane 1 of the runtime
+    (scn.metadata.lane): its workspace and count block are not shared with main-stream kernels."""
+
+    def __init__(self, model, num_hierarchy_levels=4, truncation=3.0, weight_missing_geo=5.0, use_loss_masking=True):
+        self.model = model
+        self.args = (num_hierarchy_levels, truncation, use_loss_masking, weight_missing_geo)
+        self.stream = None
+        self.pending = None            # StepPlan of the announced next batch
+        self.done = []                 # end-of-step events of the last two issued steps (main stream)
+
+    def build(self, batch, loss_weights):
+        """StepPlan of `batch` on the prefetch stream (the host blocks for its five read-backs only)."""
+        from .scn.metadata import lane
+        dev = batch['sdf'].device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        nl, trunc, masking, wgeo = self.args
+        plan = StepPlan()
+        plan.batch, plan.loss_weights = batch, np.array(loss_weights, copy=True)
+        known = batch['known'] if masking else None
+        with torch.cuda.stream(self.stream), lane(1):
+            plan.targets, plan.weights = loss_util.compute_targets_and_weights(
+                batch['sdf'], batch['hierarchy'], nl, trunc, masking, known, wgeo, batch['input'][0])
+            plan.geometry = self.model.plan_geometry(batch['input'][0], loss_weights, int(batch['sdf'].shape[0]),
+                                                     plan.targets[1])
+            plan.ready = torch.cuda.Event()
+            plan.ready.record(self.stream)
+        return plan
+
+    def take(self, batch, loss_weights):
+        """The plan announced for `batch` (built now when it was not announced); the main stream waits for it."""
+        plan, self.pending = self.pending, None
+        if plan is None or plan.batch is not batch or not np.array_equal(plan.loss_weights, loss_weights):
+            plan = self.build(batch, loss_weights)
+        torch.cuda.current_stream(batch['sdf'].device).wait_event(plan.ready)
+        return plan
+
+    def step_issued(self, dev, next_batch, loss_weights):
+        """Call after the optimizer step of a step has been issued: throttle, then build the next batch's plan."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.done.append(ev)
+        if len(self.done) > 1:
+            self.done.pop(0).synchronize()       # the step before this one has left the GPU
+        if next_batch is not None:
+            self.pending = self.build(next_batch, loss_weights)
+
+
 def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, truncation=3.0,
                use_log_transform=True, weight_missing_geo=5.0, use_loss_masking=True, grad_sync=None,
-               teacher_forced=False):
-    """batch: device-resident dict in scene_dataloader.collate layout.  Returns (loss, losses, outputs)."""
+               teacher_forced=False, prefetch=None, next_batch=None):
+    """batch: device-resident dict in scene_dataloader.collate layout.  Returns (loss, losses, outputs).
+    prefetch / next_batch (teacher-forced only): a GeometryPrefetcher and the batch of the following step."""
     inputs = batch['input']
     known = batch['known'] if use_loss_masking else None
     dev = batch['sdf'].device
@@ -194,7 +261,12 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
                                                      use_loss_masking, known, weight_missing_geo, inputs[0])
 
     optimizer.zero_grad(set_to_none=True)
-    if teacher_forced:
+    if teacher_forced and prefetch is not None:
+        plan = prefetch.take(batch, loss_weights)
+        (tgt_sdf, tgt_occs, tgt_hier), weights = plan.targets, plan.weights
+        output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]), teacher=tgt_occs,
+                                        geometry=plan.geometry)
+    elif teacher_forced:
         # generative masks come from the target occupancy pyramid: the targets are needed before the model runs
         (tgt_sdf, tgt_occs, tgt_hier), weights = targets()
         output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]), teacher=tgt_occs)
@@ -219,6 +291,8 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
     if grad_sync is not None:
         grad_sync()
     optimizer.step()
+    if teacher_forced and prefetch is not None:
+        prefetch.step_issued(dev, next_batch, loss_weights)
     return loss, losses, (output_sdf, output_occs)
 
 

@@ -263,3 +263,35 @@ def test_teacher_forced_geometry_first_is_the_same_computation():
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
     assert all(torch.equal(x, y) for x, y in zip(a[4], b[4]))     # parameters after the Adam step
     assert a[5] == b[5]                                            # same number of read-backs, only earlier
+
+
+def test_prefetched_geometry_is_the_same_training_run():
+    """Six teacher-forced steps over two alternating batches with train.GeometryPrefetcher (batch i+1's targets and
+    geometry built on a second stream during step i) == the same steps without it: losses and final parameters bit
+    for bit; the main lane never reads back from the device."""
+    from sgnn_amd import model as M
+    from sgnn_amd.train import train_step, to_device, make_optimizer, GeometryPrefetcher
+    from sgnn_amd.scn.metadata import runtime
+    dims, cfg = (32, 32, 32), 17
+    batches = [to_device(synth.make_batch(2, dims, cfg=cfg + j, occupancy=0.08), 'cuda') for j in range(2)]
+    lw = np.ones(5, dtype=np.float32)
+    res = []
+    for use in (False, True):
+        m = param_fill(M.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
+        opt = make_optimizer(m.parameters(), lr=1e-3)
+        pre = GeometryPrefetcher(m) if use else None
+        rt = runtime(torch.device('cuda', torch.cuda.current_device()))
+        losses = []
+        for i in range(6):
+            if i == 1:
+                s0 = rt.syncs
+            loss, _, _ = train_step(m, opt, batches[i % 2], lw, teacher_forced=True, prefetch=pre,
+                                    next_batch=batches[(i + 1) % 2] if use else None)
+            losses.append(loss)
+        syncs = rt.syncs - s0
+        torch.cuda.synchronize()
+        res.append(([l.item() for l in losses], [p.detach().clone() for p in m.parameters()], syncs))
+    a, b = res
+    assert a[0] == b[0], (a[0], b[0])
+    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert a[2] == 25 and b[2] == 0          # 5 read-backs per step on the main lane vs none

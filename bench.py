@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# A rank drives four or more HIP streams at once (main, weight-gradient lane, geometry prefetch, RCCL's own): with the
+# ROCm default of 4 hardware queues per process, streams beyond that share a queue and the prefetch lane's small kernels
+# would wait behind whole convolutions (measured with 2 queues: 8.7 instead of 7.4 ms/step).  Read at HIP start-up.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -360,7 +365,9 @@ def main():
 
     # teacher-forced: batch i+1's geometry (all host read-backs of a step) is built on a second stream during step i,
     # as a training loop with a prefetching loader would; every step's geometry is still computed once per step
-    pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch) else None
+    # (not in the two-ranks-on-one-GPU test hook: the ranks' streams then outnumber the device's hardware queues)
+    share = os.environ.get('SGNN_BENCH_SHARE_GPU') == '1' and world > 1
+    pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch and not share) else None
 
     def step(i):
         return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher, prefetch=pre,
@@ -396,6 +403,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if pre is not None and os.environ.get('SGNN_PREFETCH_DEBUG'):
+        sys.stderr.write('rank %d prefetch: build %.3f ms/step, throttle %.3f ms/step\n' % (
+            rank, 1e3 * pre.t_build / (args.steps + args.warmup), 1e3 * pre.t_throttle / (args.steps + args.warmup)))
     valid = measure_valid_ratios(step, args.warmup + args.steps)    # one more (untimed) step, on every rank: it all-reduces
     # the other mask mode on the same batches (what BENCH_r01 measured: masks from the predicted occupancy, per-level
     # row counts depend on the weights), reported next to the headline for comparability across rounds

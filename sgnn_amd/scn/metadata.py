@@ -14,7 +14,7 @@ from .. import _lib
 from .._lib import ptr
 
 
-SIDE_LANE = True     # run dW on a second stream during program backward (sgnn_prog_set_side_stream)
+SIDE_LANE = os.environ.get('SGNN_SIDE_LANE', '1') != '0'     # run dW on a second stream during program backward (sgnn_prog_set_side_stream)
 
 
 class _Runtime(object):

@@ -208,6 +208,7 @@ class GeometryPrefetcher(object):
         self.stream = None
         self.pending = None            # StepPlan of the announced next batch
         self.done = []                 # end-of-step events of the last two issued steps (main stream)
+        self.t_build = self.t_throttle = 0.0   # host seconds spent building plans / waiting for the step before last
 
     def build(self, batch, loss_weights):
         """StepPlan of `batch` on the prefetch stream (the host blocks for its five read-backs only)."""
@@ -241,10 +242,15 @@ class GeometryPrefetcher(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         self.done.append(ev)
+        import time
+        t0 = time.perf_counter()
         if len(self.done) > 1:
             self.done.pop(0).synchronize()       # the step before this one has left the GPU
+        t1 = time.perf_counter()
         if next_batch is not None:
             self.pending = self.build(next_batch, loss_weights)
+        self.t_throttle += t1 - t0
+        self.t_build += time.perf_counter() - t1
 
 
 def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, truncation=3.0,

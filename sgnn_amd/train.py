@@ -6,6 +6,8 @@ per GPU, each rank owns `batch_size` independent TSDF blocks (batch index is par
 blocks never interact in a sparse op), BatchNorm statistics stay per replica, and the only exchange is one
 all-reduce of a flat fp32 gradient buffer (643 735 floats = 2.57 MB) over RCCL/xGMI after backward.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -215,7 +217,7 @@ class GeometryPrefetcher(object):
         from .scn.metadata import lane
         dev = batch['sdf'].device
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = torch.cuda.Stream(device=dev)    # (a high-priority stream measured no different)
         nl, trunc, masking, wgeo = self.args
         plan = StepPlan()
         plan.batch, plan.loss_weights = batch, np.array(loss_weights, copy=True)

@@ -469,7 +469,11 @@ class GenModel(nn.Module):
         if MD.CHAIN and depth >= 2 and coords.shape[0]:
             n = int(coords.shape[0])
             chain = MD.PendingChain(coords, n, False, depth)
-            coords._sgnn_plan = chain.finalize(n, MD.runtime(dev).read_counts())
+            plan = chain.finalize(n, MD.runtime(dev).read_counts())
+            # the level-0 Grid holds a view of `coords`; hanging the plan on `coords` itself would close a reference
+            # cycle through the view's base that the garbage collector cannot see (one leaked pyramid per step)
+            coords = coords[:]
+            coords._sgnn_plan = plan
         enc = self.encoder
         dims = tuple(int(v) >> depth for v in enc.process_sparse[0].p0.spatial_size)
         plans = self._teacher_plans(dense_geometry(batch_size, dims, dev), self._runs(loss_weights), teacher)

@@ -94,7 +94,8 @@ int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
  * the caller fills with -1 ONCE; the call marks this level's rows, builds the table and clears the rows again, so the
  * volume is all -1 on return.  Blocks with batch index >= volume_entries / (Z*Y*X) and positions outside [0, dims) go
  * through the hash grid (keys / vals / cap): the table equals sgnn_rulebook_subm3's for every input.
- * Measured at N = 366 k (64^3 x 32 blocks): see profiles/ (r02j). */
+ * One volume serves one stream at a time (calls are stream-ordered by the caller).  Measured at N = 366 k (64^3 x 32
+ * blocks): 18 us against 97 us for sgnn_rulebook_subm3 (profiles/r02j_rulebook.txt). */
 int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords, int64_t n,
                               int dim_z, int dim_y, int dim_x, int32_t *volume, int64_t volume_entries, int32_t *nbr,
                               int64_t ld, sgnn_stream_t stream);
@@ -108,7 +109,8 @@ int64_t sgnn_tile_index_bytes(int64_t ld);
 int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgnn_stream_t stream);
 int sgnn_conv_fwd_tiled(const float *x, int64_t n_in, int cin, const float *w, const int32_t *table, int64_t ld,
                         int64_t n_out, int cout, float *y, int flags, const void *tile_index, sgnn_stream_t stream);
-/* 0: never use the tile kernel (A/B measurements, parity test); returns the previous setting */
+/* 0: never use the tile kernel (A/B measurements, parity test); 1: use it where a tile index is passed; n > 1: the same
+ * and n (rounded up to a multiple of 8) persistent workgroups instead of 512.  Returns the previous on/off setting. */
 int sgnn_conv_set_tiled(int on);
 
 /* stride-2 / size-2 rulebook, phase 1 (scn.Convolution(...,2,2), torch/model.py:44):

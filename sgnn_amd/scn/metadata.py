@@ -7,6 +7,7 @@ torch tensors that back the tables and caches them per (spatial size, filter) li
 """
 import numpy as np
 import os
+import threading
 
 import torch
 
@@ -86,23 +87,23 @@ class _Runtime(object):
 
 
 _runtimes = {}
-_lane = 0      # scratch lane: work issued on a second stream (geometry prefetch) gets its own workspace + state block
+_lanes = threading.local()     # .n = scratch lane of this thread (0 = main); see `lane`
 
 
 class lane(object):
-    """`with lane(1):` — runtime() hands out the scratch (workspace, count/status block) of lane 1 inside the block.
-    Kernels of different streams must not share them; the caller pairs a lane with ONE stream."""
+    """`with lane(1):` — runtime() hands out the scratch (workspace, count/status block) of lane 1 inside the block, in
+    this thread.  Kernels of different streams must not share them; the caller pairs a lane with ONE stream (geometry
+    prefetch: train.GeometryPrefetcher, possibly on a worker thread)."""
 
     def __init__(self, n):
         self.n = n
 
     def __enter__(self):
-        global _lane
-        self.prev, _lane = _lane, self.n
+        self.prev = getattr(_lanes, 'n', 0)
+        _lanes.n = self.n
 
     def __exit__(self, *exc):
-        global _lane
-        _lane = self.prev
+        _lanes.n = self.prev
 
 
 def runtime(device=None):
@@ -111,10 +112,11 @@ def runtime(device=None):
         idx = torch.cuda.current_device() if device is None else torch.device(device).index
         if idx is None:
             idx = torch.cuda.current_device()
-    rt = _runtimes.get((idx, _lane))
+    ln = getattr(_lanes, 'n', 0)
+    rt = _runtimes.get((idx, ln))
     if rt is None:
         _lib.require_gpu()
-        rt = _runtimes[(idx, _lane)] = _Runtime(torch.device('cuda', idx))
+        rt = _runtimes[(idx, ln)] = _Runtime(torch.device('cuda', idx))
     if idx != torch.cuda.current_device():
         # every entry point launches on the CURRENT device's stream: tensors of another GPU would be touched through
         # a foreign stream (one process per GPU is the supported layout; torch.cuda.set_device selects it)

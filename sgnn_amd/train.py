@@ -191,29 +191,36 @@ class StepPlan(object):
 
 class GeometryPrefetcher(object):
     """Teacher-forced training, one batch ahead: the geometry of a step (every host read-back it has) is a function of
-    the batch, so batch i+1's StepPlan is built on a second stream while batch i's backward pass occupies the GPU, and
-    the main stream never drains at a step boundary.
+    the batch, so batch i+1's StepPlan is built on a second stream while batch i occupies the GPU, and the main stream
+    never drains at a step boundary.
 
         pre = GeometryPrefetcher(model)
         for i, batch in enumerate(batches):
             train_step(model, opt, batch, lw, teacher_forced=True, prefetch=pre, next_batch=batches[i + 1])
 
-    Memory discipline: plan tensors are allocated on the prefetch stream and read by main-stream kernels of the NEXT
-    step; a plan is dropped when its step has been issued, and the next allocation on the prefetch stream happens only
-    after the host has waited for the step BEFORE that one to finish on the GPU (`throttle`), which also keeps the
-    host at most one step ahead of the device.  The prefetch stream uses scratch lane 1 of the runtime
-    (scn.metadata.lane): its workspace and count block are not shared with main-stream kernels."""
+    threaded=False (default) builds the next plan after the optimizer step has been issued (1.6 ms of host time per
+    step at the BASELINE batch); threaded=True builds it on a worker thread started at the head of the step — correct and
+    tested, but measured slower on this workload (7.8 vs 7.3–7.4 ms/step: the builder is Python-bound, its 3.3 ms under
+    the GIL slow the issuing thread by more than the five read-back waits it hides).
 
-    def __init__(self, model, num_hierarchy_levels=4, truncation=3.0, weight_missing_geo=5.0, use_loss_masking=True):
+    Memory discipline: plan tensors are allocated on the prefetch stream's pool and read by main-stream kernels of
+    their step.  A plan is retained until the host has seen its step finish on the GPU (end-of-step events, `_retire`),
+    only then may the pool hand its blocks to a new plan; the same wait keeps the host at most two steps ahead of the
+    device.  The prefetch stream uses scratch lane 1 of the runtime (scn.metadata.lane): its workspace and count block
+    are not shared with main-stream kernels."""
+
+    def __init__(self, model, num_hierarchy_levels=4, truncation=3.0, weight_missing_geo=5.0, use_loss_masking=True,
+                 threaded=None):
         self.model = model
         self.args = (num_hierarchy_levels, truncation, use_loss_masking, weight_missing_geo)
+        self.threaded = (os.environ.get('SGNN_PREFETCH_THREAD', '0') == '1') if threaded is None else bool(threaded)
         self.stream = None
-        self.pending = None            # StepPlan of the announced next batch
-        self.done = []                 # end-of-step events of the last two issued steps (main stream)
-        self.t_build = self.t_throttle = 0.0   # host seconds spent building plans / waiting for the step before last
+        self.pending = None            # the announced next batch's plan: {'plan' | 'error', 'thread'}
+        self.issued = []               # [(end-of-step event on the main stream, plan of that step)], oldest first
+        self.t_build = self.t_throttle = 0.0   # host seconds spent building plans / waiting for old steps
 
     def build(self, batch, loss_weights):
-        """StepPlan of `batch` on the prefetch stream (the host blocks for its five read-backs only)."""
+        """StepPlan of `batch` on the prefetch stream (the calling thread blocks for its five read-backs only)."""
         from .scn.metadata import lane
         dev = batch['sdf'].device
         if self.stream is None:
@@ -222,7 +229,7 @@ class GeometryPrefetcher(object):
         plan = StepPlan()
         plan.batch, plan.loss_weights = batch, np.array(loss_weights, copy=True)
         known = batch['known'] if masking else None
-        with torch.cuda.stream(self.stream), lane(1):
+        with torch.cuda.device(dev), torch.cuda.stream(self.stream), lane(1):
             plan.targets, plan.weights = loss_util.compute_targets_and_weights(
                 batch['sdf'], batch['hierarchy'], nl, trunc, masking, known, wgeo, batch['input'][0])
             plan.geometry = self.model.plan_geometry(batch['input'][0], loss_weights, int(batch['sdf'].shape[0]),
@@ -231,28 +238,68 @@ class GeometryPrefetcher(object):
             plan.ready.record(self.stream)
         return plan
 
+    def _retire(self, keep):
+        """Wait for all but the `keep` most recently issued steps to leave the GPU and let go of their plans."""
+        import time
+        t0 = time.perf_counter()
+        while len(self.issued) > keep:
+            ev, _plan = self.issued.pop(0)
+            ev.synchronize()
+        self.t_throttle += time.perf_counter() - t0
+
+    def _start(self, batch, loss_weights):
+        import threading
+        import time
+        box = {}
+
+        def work():
+            t0 = time.perf_counter()
+            try:
+                box['plan'] = self.build(batch, loss_weights)
+            except BaseException as e:          # re-raised by take() on the training thread
+                box['error'] = e
+            self.t_build += time.perf_counter() - t0
+
+        if not self.threaded:
+            work()
+            return box
+        th = threading.Thread(target=work, name='sgnn-geometry-prefetch', daemon=True)
+        box['thread'] = th
+        th.start()
+        return box
+
+    @staticmethod
+    def _result(box):
+        if box.get('thread') is not None:
+            box['thread'].join()
+        if 'error' in box:
+            raise box['error']
+        return box['plan']
+
     def take(self, batch, loss_weights):
         """The plan announced for `batch` (built now when it was not announced); the main stream waits for it."""
-        plan, self.pending = self.pending, None
+        box, self.pending = self.pending, None
+        plan = self._result(box) if box is not None else None
         if plan is None or plan.batch is not batch or not np.array_equal(plan.loss_weights, loss_weights):
-            plan = self.build(batch, loss_weights)
+            plan = self._result(self._start(batch, loss_weights))
         torch.cuda.current_stream(batch['sdf'].device).wait_event(plan.ready)
         return plan
 
-    def step_issued(self, dev, next_batch, loss_weights):
-        """Call after the optimizer step of a step has been issued: throttle, then build the next batch's plan."""
+    def announce(self, next_batch, loss_weights):
+        """Head of a step, right after take(): start building `next_batch`'s plan on the worker thread."""
+        if self.threaded and next_batch is not None:
+            self._retire(1)     # the pool may recycle plans older than the previous step's from here on
+            self.pending = self._start(next_batch, loss_weights)
+
+    def step_issued(self, dev, plan, next_batch, loss_weights):
+        """Call after the optimizer step of a step has been issued: remember when it ends, keep its plan until then."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self.done.append(ev)
-        import time
-        t0 = time.perf_counter()
-        if len(self.done) > 1:
-            self.done.pop(0).synchronize()       # the step before this one has left the GPU
-        t1 = time.perf_counter()
-        if next_batch is not None:
-            self.pending = self.build(next_batch, loss_weights)
-        self.t_throttle += t1 - t0
-        self.t_build += time.perf_counter() - t1
+        self.issued.append((ev, plan))
+        if not self.threaded and next_batch is not None:
+            self._retire(1)
+            self.pending = self._start(next_batch, loss_weights)
+        self._retire(2)
 
 
 def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, truncation=3.0,
@@ -271,6 +318,7 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
     optimizer.zero_grad(set_to_none=True)
     if teacher_forced and prefetch is not None:
         plan = prefetch.take(batch, loss_weights)
+        prefetch.announce(next_batch, loss_weights)
         (tgt_sdf, tgt_occs, tgt_hier), weights = plan.targets, plan.weights
         output_sdf, output_occs = model(inputs, loss_weights, batch_size=int(batch['sdf'].shape[0]), teacher=tgt_occs,
                                         geometry=plan.geometry)
@@ -300,7 +348,7 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
         grad_sync()
     optimizer.step()
     if teacher_forced and prefetch is not None:
-        prefetch.step_issued(dev, next_batch, loss_weights)
+        prefetch.step_issued(dev, plan, next_batch, loss_weights)
     return loss, losses, (output_sdf, output_occs)
 
 

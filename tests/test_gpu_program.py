@@ -276,10 +276,10 @@ def test_prefetched_geometry_is_the_same_training_run():
     batches = [to_device(synth.make_batch(2, dims, cfg=cfg + j, occupancy=0.08), 'cuda') for j in range(2)]
     lw = np.ones(5, dtype=np.float32)
     res = []
-    for use in (False, True):
+    for use in (None, 'after', 'thread'):       # no prefetcher / plan built after the step / on a worker thread
         m = param_fill(M.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
         opt = make_optimizer(m.parameters(), lr=1e-3)
-        pre = GeometryPrefetcher(m) if use else None
+        pre = GeometryPrefetcher(m, threaded=(use == 'thread')) if use else None
         rt = runtime(torch.device('cuda', torch.cuda.current_device()))
         losses, mem = [], []
         for i in range(8):
@@ -295,11 +295,13 @@ def test_prefetched_geometry_is_the_same_training_run():
         syncs = rt.syncs - s0
         torch.cuda.synchronize()
         res.append(([l.item() for l in losses], [p.detach().clone() for p in m.parameters()], syncs, mem))
-    a, b = res
-    assert a[0] == b[0], (a[0], b[0])
-    assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
-    assert a[2] == 35 and b[2] == 0          # 5 read-backs per step on the main lane vs none
-    # no plan may outlive its step (a plan hung on a tensor its own Grid views is an uncollectable cycle)
-    # (the kept loss scalars account for 512 bytes per step)
-    assert max(b[3]) - min(b[3]) < 65536, b[3]
+    a = res[0]
+    assert a[2] == 35                            # 5 read-backs per step on the main lane without the prefetcher
     assert max(a[3]) - min(a[3]) < 65536, a[3]
+    for b in res[1:]:
+        assert a[0] == b[0], (a[0], b[0])
+        assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+        assert b[2] == 0                         # ... none with it
+        # no plan may outlive its step by more than the retention window (a plan hung on a tensor its own Grid views
+        # is an uncollectable cycle); the kept loss scalars account for 512 bytes per step
+        assert max(b[3]) - min(b[3]) < 65536, b[3]

@@ -136,3 +136,45 @@ def test_point_cloud_ply_writer(tmp_path):
     assert head.decode().splitlines() == ['ply', 'format binary_little_endian 1.0', 'element vertex 2', 'property float x',
                                           'property float y', 'property float z']
     assert np.array_equal(np.frombuffer(body, dtype='<f4').reshape(-1, 3), pts.astype(np.float32))
+
+
+def test_scratch_lanes_are_per_thread_and_levels_remember_their_size():
+    """scn.metadata.lane selects the runtime scratch of the geometry-prefetch stream for the CURRENT thread only (a
+    worker thread building a plan must not switch the training thread's lane), and a Grid registered in a Metadata
+    learns the level's spatial size (what routes its rulebook through the dense index volume)."""
+    import threading
+    from sgnn_amd.scn import metadata as MD
+    assert getattr(MD._lanes, 'n', 0) == 0
+    seen = {}
+
+    def worker():
+        with MD.lane(1):
+            seen['inside'] = getattr(MD._lanes, 'n', 0)
+            ready.set()
+            done.wait(5)
+        seen['after'] = getattr(MD._lanes, 'n', 0)
+
+    ready, done = threading.Event(), threading.Event()
+    t = threading.Thread(target=worker)
+    t.start()
+    assert ready.wait(5)
+    assert getattr(MD._lanes, 'n', 0) == 0          # the other thread's lane is its own
+    with MD.lane(1):
+        assert MD._lanes.n == 1
+        with MD.lane(0):
+            assert MD._lanes.n == 0
+        assert MD._lanes.n == 1
+    assert MD._lanes.n == 0
+    done.set()
+    t.join()
+    assert seen == {'inside': 1, 'after': 0}
+
+    coords = torch.zeros(5, 4, dtype=torch.int32)
+    g = MD.Grid(coords)
+    assert g.dims is None and g.ld == 256
+    md = MD.Metadata(3)
+    md.set_input((64, 32, 16), g)
+    assert g.dims == (64, 32, 16) and md.grid((64, 32, 16)) is g
+    md2 = MD.Metadata(3)
+    md2.set_input((128, 128, 128), g)                 # the first registration wins: the size is a property of the level
+    assert g.dims == (64, 32, 16)

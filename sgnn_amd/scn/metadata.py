@@ -67,14 +67,20 @@ class _Runtime(object):
     def check_status(self):
         """Raise now if a kernel flagged an input error (duplicate / out-of-range coordinates) since the last read-back
         (one D2H copy).  GenModel.forward calls it at the end of inference passes, so that the error is attributed to
-        the call that caused it; in training it surfaces at the next of the step's five read-backs."""
+        the call that caused it; in training it surfaces at the next of the step's five read-backs (with the geometry
+        prefetcher, which leaves the training stream without read-backs: when that step's end-of-step event is seen)."""
         self.read_counts()
 
     def read_counts(self):
         """One D2H copy of the whole state block: [count, status, chain counts...] as Python ints."""
         self.syncs += 1
         host = self.state.cpu().tolist()
-        status = int(host[1]) & 0xFFFFFFFF
+        self.raise_status(int(host[1]))
+        return host
+
+    def raise_status(self, word):
+        """Turn a copy of the status word into the input error it stands for (and clear the device word)."""
+        status = int(word) & 0xFFFFFFFF
         if status:
             self.state[1] = 0
             msgs = []
@@ -83,7 +89,6 @@ class _Runtime(object):
             if status & 2:
                 msgs.append('InputLayer(mode=0): duplicate coordinates are a caller error')
             raise _lib.SgnnError('; '.join(msgs))
-        return host
 
 
 _runtimes = {}

@@ -216,8 +216,9 @@ class GeometryPrefetcher(object):
         self.threaded = (os.environ.get('SGNN_PREFETCH_THREAD', '0') == '1') if threaded is None else bool(threaded)
         self.stream = None
         self.pending = None            # the announced next batch's plan: {'plan' | 'error', 'thread'}
-        self.issued = []               # [(end-of-step event on the main stream, plan of that step)], oldest first
+        self.issued = []               # [(end-of-step event on the main stream, plan of that step, status copy)]
         self.t_build = self.t_throttle = 0.0   # host seconds spent building plans / waiting for old steps
+        self._status, self._n, self._rt = [], 0, None   # pinned copies of the training lane's status word, per step
 
     def build(self, batch, loss_weights):
         """StepPlan of `batch` on the prefetch stream (the calling thread blocks for its five read-backs only)."""
@@ -243,8 +244,12 @@ class GeometryPrefetcher(object):
         import time
         t0 = time.perf_counter()
         while len(self.issued) > keep:
-            ev, _plan = self.issued.pop(0)
+            ev, _plan, status = self.issued.pop(0)
             ev.synchronize()
+            if status is not None and int(status[0]):
+                # the training stream has no read-back of its own any more: input errors its kernels flagged during
+                # that step (duplicate / out-of-range sites) surface here, two steps later at most
+                self._rt.raise_status(int(status[0]))
         self.t_throttle += time.perf_counter() - t0
 
     def _start(self, batch, loss_weights):
@@ -293,9 +298,16 @@ class GeometryPrefetcher(object):
 
     def step_issued(self, dev, plan, next_batch, loss_weights):
         """Call after the optimizer step of a step has been issued: remember when it ends, keep its plan until then."""
+        from .scn.metadata import runtime
+        self._rt = runtime(dev)
+        if not self._status:
+            self._status = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(4)]
+        status = self._status[self._n % len(self._status)]
+        self._n += 1
+        status.copy_(self._rt.state[1:2], non_blocking=True)       # rides the training stream, no synchronisation
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self.issued.append((ev, plan))
+        self.issued.append((ev, plan, status))
         if not self.threaded and next_batch is not None:
             self._retire(1)
             self.pending = self._start(next_batch, loss_weights)

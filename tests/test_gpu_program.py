@@ -307,3 +307,23 @@ def test_prefetched_geometry_is_the_same_training_run():
         # no plan may outlive its step by more than the retention window (a plan hung on a tensor its own Grid views
         # is an uncollectable cycle); the kept loss scalars account for 512 bytes per step
         assert max(b[3]) - min(b[3]) < (1 << 20), b[3]      # a leaked plan is >= 1.5 MB per step here
+
+
+def test_input_errors_still_surface_with_the_prefetcher():
+    """With the geometry prefetcher the training stream has no read-back that would report a duplicate input site
+    (flagged on the device by the level-0 hash build); the end-of-step status copy must raise it within two steps."""
+    from sgnn_amd import model as M
+    from sgnn_amd._lib import SgnnError
+    from sgnn_amd.train import train_step, to_device, make_optimizer, GeometryPrefetcher
+    dims, cfg = (32, 32, 32), 17
+    batch = to_device(synth.make_batch(2, dims, cfg=cfg, occupancy=0.08), 'cuda')
+    locs, feats = batch['input']
+    batch['input'] = [torch.cat([locs, locs[:1]]), torch.cat([feats, feats[:1]])]      # site 0 twice
+    m = param_fill(M.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
+    opt = make_optimizer(m.parameters(), lr=1e-3)
+    pre = GeometryPrefetcher(m)
+    lw = np.ones(5, dtype=np.float32)
+    with pytest.raises(SgnnError, match='duplicate'):
+        for _ in range(4):
+            train_step(m, opt, batch, lw, teacher_forced=True, prefetch=pre, next_batch=batch)
+    torch.cuda.synchronize()

@@ -77,3 +77,37 @@ def test_model_forward_uses_five_readbacks_and_same_results():
     for h in range(4):
         assert torch.equal(oa[h][0], ob[h][0]) and torch.equal(oa[h][1], ob[h][1])
     assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1])
+
+
+def test_teacher_forced_compaction_equals_boolean_indexing():
+    """sgnn_compact_dense (the bench's teacher-forced masks): site i is kept iff the dense target occupancy volume is
+    > 0.5 at its coordinates — stable order, sites outside the volume dropped — against torch boolean indexing; the
+    plan variant (compaction + coordinates + stride-2 pyramid, one read-back) must agree with it."""
+    from sgnn_amd.scn import functions as F_
+    g = torch.Generator().manual_seed(5)
+    B, d = 3, 16
+    vol = (torch.rand(B, 1, d, d, d, generator=g) < 0.3).float()
+    vol[vol == 0] = torch.rand(int((vol == 0).sum()), generator=g) * 0.5          # anything <= 0.5 is "empty"
+    zz, yy, xx, bb = torch.meshgrid(torch.arange(d), torch.arange(d), torch.arange(d), torch.arange(B), indexing='ij')
+    coords = torch.stack([zz, yy, xx, bb], -1).view(-1, 4)
+    coords = coords[torch.randperm(coords.shape[0], generator=g)[:5000]]
+    coords = torch.cat([coords, torch.tensor([[d, 0, 0, 0], [0, 0, 0, B], [-1, 2, 2, 1]])])   # outside: never kept
+    keep = torch.zeros(coords.shape[0], dtype=torch.bool)
+    inside = ((coords[:, :3] >= 0) & (coords[:, :3] < d)).all(1) & (coords[:, 3] >= 0) & (coords[:, 3] < B)
+    c = coords[inside]
+    keep[inside] = vol[c[:, 3], 0, c[:, 0], c[:, 1], c[:, 2]] > 0.5
+    want = torch.nonzero(keep)[:, 0].to(torch.int32)
+    c32 = coords.to(torch.int32).cuda()
+    n = int(c32.shape[0])
+    for depth in (0, 2):
+        sel, cnt, locs = F_.compact_sigmoid_plan(c32, 2, n, c32, depth, vol.cuda())
+        assert cnt == int(want.numel()) and 0 < cnt < n
+        assert torch.equal(sel.cpu(), want)
+        assert torch.equal(locs.cpu(), coords[keep].to(torch.int32))
+        assert (getattr(locs, '_sgnn_plan', None) is not None) == (depth == 2)
+    grid0, downs = locs._sgnn_plan
+    assert grid0.n == cnt and len(downs) == 2
+    coarse = torch.unique(torch.cat([coords[keep][:, :3] // 2, coords[keep][:, 3:]], 1), dim=0)
+    assert downs[0].coarse.n == coarse.shape[0]
+    got = torch.unique(downs[0].coarse.coords[:downs[0].coarse.n].cpu().to(torch.int64), dim=0)
+    assert torch.equal(got, coarse)

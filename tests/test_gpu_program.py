@@ -327,3 +327,32 @@ def test_input_errors_still_surface_with_the_prefetcher():
         for _ in range(4):
             train_step(m, opt, batch, lw, teacher_forced=True, prefetch=pre, next_batch=batch)
     torch.cuda.synchronize()
+
+
+def test_teacher_forced_hierarchy_is_the_target_hierarchy():
+    """Teacher-forced forward (bench.py's workload): the candidate sites of level h+1 are exactly the 8 children (order
+    4dz+2dy+dx, model.py:195-207) of the level-h candidates whose target occupancy is 1, in stable order, and the
+    final sites are the last level's candidates with target occupancy 1 — checked with tensor ops on the outputs."""
+    from sgnn_amd import model as M, loss as L
+    dims, cfg = (32, 32, 32), 17
+    data = synth.make_batch(2, dims, cfg=cfg, occupancy=0.08)
+    m = param_fill(M.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
+    lw = np.ones(5, dtype=np.float32)
+    tgt = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
+                            data['known'].cuda())
+    occs = tgt[1]
+    with torch.no_grad():
+        osdf, oocc = m([data['input'][0].cuda(), data['input'][1].cuda()], lw, batch_size=2, teacher=occs)
+    offs = torch.tensor([[dz, dy, dx, 0] for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)])
+    prev = None
+    for h, (locs, out) in enumerate(oocc):
+        locs = locs.cpu()
+        assert out.shape[0] == locs.shape[0] > 0
+        if prev is not None:
+            assert torch.equal(locs, prev)
+        t = occs[h].cpu()
+        keep = t[locs[:, 3], 0, locs[:, 0], locs[:, 1], locs[:, 2]] > 0.5
+        kept = locs[keep]
+        assert 0 < kept.shape[0] < locs.shape[0]
+        prev = (kept[:, None, :] * torch.tensor([2, 2, 2, 1]) + offs[None]).reshape(-1, 4)
+    assert torch.equal(osdf[0].cpu(), kept) and osdf[1].shape[0] == kept.shape[0]

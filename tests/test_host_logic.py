@@ -178,3 +178,51 @@ def test_scratch_lanes_are_per_thread_and_levels_remember_their_size():
     md2 = MD.Metadata(3)
     md2.set_input((128, 128, 128), g)                 # the first registration wins: the size is a property of the level
     assert g.dims == (64, 32, 16)
+
+
+def test_program_planner_turns_join_inputs_into_column_views():
+    """Native executor planning (prog.hip: make_plan / make_layout, host code — runs without a GPU): in a Refinement
+    program the inputs of both JoinTables live inside the joined buffer (no storage of their own, no concat kernel);
+    a join input the caller wants to read back (`keep`) gets its own rows again; materialised buffers never overlap."""
+    from sgnn_amd import _lib
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.scn import program as P
+    m = GenModel(8, (64,) * 3, 1, 16, 16, 4, True, True, 1, 1)
+    ref = m.refinement[0]
+    prog = P.compile_or_none([ref.p1, ref.p2, ref.p3], ref.nf_in)
+    assert prog is not None
+    ops, bufs = prog.ops_np, prog.bufs_np
+    nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
+    lev_n = np.array([1000, 300, 90], dtype=np.int64)[:ncls]
+
+    def plan(keep_bufs):
+        keep = np.zeros(nbuf, dtype=np.int32)
+        keep[list(keep_bufs)] = 1
+        a = (ops.ctypes.data, nops, bufs.ctypes.data, nbuf, prog.n_ext, lev_n.ctypes.data, ncls, keep.ctypes.data)
+        total = _lib.query('sgnn_prog_arena_floats', *a)
+        return total, [_lib.query('sgnn_prog_buffer_offset', *(a + (b,))) for b in range(nbuf)]
+
+    OP_JOIN = 5
+    joins = [o for o in ops if o[0] == OP_JOIN]
+    assert len(joins) == 2
+    total, offs = plan([prog.out])
+    spans = []
+    for b in range(prog.n_ext, nbuf):
+        if offs[b] >= 0:
+            spans.append((offs[b], offs[b] + int(lev_n[bufs[b, 0]]) * int(bufs[b, 1]), b))
+    spans.sort()
+    assert spans[-1][1] <= total
+    for (s0, e0, b0), (s1, e1, b1) in zip(spans, spans[1:]):
+        assert e0 <= s1, 'buffers %d and %d overlap' % (b0, b1)
+    for o in joins:
+        a, b, out = int(o[1]), int(o[2]), int(o[3])
+        assert offs[a] == -1 and offs[b] == -1 and offs[out] >= 0          # views of the joined buffer
+        assert int(bufs[out, 1]) == int(bufs[a, 1]) + int(bufs[b, 1])
+    # reading a join input back forces it out of the view
+    a0 = int(joins[0][1])
+    total2, offs2 = plan([prog.out, a0])
+    assert offs2[a0] >= 0 and total2 >= total + int(lev_n[bufs[a0, 0]]) * int(bufs[a0, 1])
+    # twice the rows: twice the arena (256-byte alignment aside)
+    lev_n = lev_n * 2
+    total3, _ = plan([prog.out])
+    assert abs(total3 - 2 * total) <= 64 * nbuf

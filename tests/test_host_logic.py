@@ -226,3 +226,22 @@ def test_program_planner_turns_join_inputs_into_column_views():
     lev_n = lev_n * 2
     total3, _ = plan([prog.out])
     assert abs(total3 - 2 * total) <= 64 * nbuf
+
+
+def test_host_side_size_queries_of_the_c_abi():
+    """Workspace / blob size queries are plain host arithmetic (callable without a GPU): the caller sizes its buffers
+    with them, so their formulas are part of the contract (include/sgnn_hip.h)."""
+    from sgnn_amd import _lib
+    al = lambda v: (v + 255) // 256 * 256
+    for ld in (256, 1024, 366336):
+        tiles = ld // 128
+        assert _lib.query('sgnn_tile_index_bytes', ld) == al(4 * tiles) + al(4 * 768 * tiles) + al(2 * 32 * 128 * tiles)
+    assert _lib.query('sgnn_tile_index_bytes', 0) == 0
+    # a plain (gather-kernel) launch: one statistics partial per 256-row workgroup above ~40 k rows, per 16 rows below
+    assert _lib.query('sgnn_conv_stats_blocks', 366085) == (366085 + 255) // 256
+    assert _lib.query('sgnn_conv_stats_blocks', 1000) == (1000 + 15) // 16
+    assert _lib.query('sgnn_conv_stats_blocks', 0) == 0
+    cap = _lib.query('sgnn_hash_capacity', 366085)
+    assert cap >= 2 * 366085 and cap & (cap - 1) == 0
+    assert _lib.query('sgnn_conv_bwd_weight_ws_bytes', 0, 27, 16, 16) == 0
+    assert _lib.query('sgnn_conv_bwd_weight_ws_bytes', 1000, 27, 16, 16) == 4 * 27 * 16 * 16 * 4      # 4 row blocks of 256

@@ -434,6 +434,31 @@ def main():
                  'value': round(args.batch * world * k2 / el2, 2), 'ms_per_step': round(1e3 * el2 / k2, 3),
                  'generated_sites_per_level': [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs2[1]] +
                                               [int(outs2[0][0].shape[0]) if len(outs2[0][0]) else 0]}
+    # the headline workload with every step building its own geometry (five read-backs at the head of the step, the
+    # GPU drains at every step boundary): what the prefetch lane buys, on the same box, in the same process
+    unprefetched = None
+    if pre is not None and args.steps >= 20 and not args.no_other_mode:
+        def step_plain(i):
+            return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=True)
+        k3 = max(10, args.steps // 3)
+        for i in range(4):
+            step_plain(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for i in range(k3):
+            step_plain(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el3 = time.perf_counter() - t2
+        if world > 1:
+            t = torch.tensor([el3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el3 = float(t.item())
+        unprefetched = {'steps': k3, 'value': round(args.batch * world * k3 / el3, 2),
+                        'ms_per_step': round(1e3 * el3 / k3, 3)}
     if rank == 0:
         agg = collect_prof(lib, valid)
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
@@ -502,7 +527,7 @@ def main():
                        'geometry': ('built one batch ahead on a second stream during the previous step (once per step; '
                                     'train.GeometryPrefetcher)' if pre is not None else 'built at the head of its own step'),
                        'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
-            'roofline': roof, 'cpu_baseline': cpu, 'other_mask_mode': other,
+            'roofline': roof, 'cpu_baseline': cpu, 'other_mask_mode': other, 'without_geometry_prefetch': unprefetched,
         }
         if cpu:
             res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)

@@ -394,7 +394,10 @@ int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *
  *         linear heads (weight row o = slot par+2o, bias par+2o+1).  Buffers [0, n_ext) are caller-owned inputs
  *         (ext[] pointers; their gradients go to gext[]), the rest live in the arena.
  *   lev_* per level: rows, table ld, nbr table, and for the transition level -> level+1 the children /
- *         ptable tables and the parent array (device pointers, NULL where unused)
+ *         ptable tables and the parent array (device pointers, NULL where unused); lev_tile: the level's tile index
+ *         (sgnn_tile_index) or NULL — the array itself may be NULL — selecting the LDS-staged 3x3x3 kernel for 16->16
+ *         layers of that level; a JoinTable's inputs are column ranges of its output (no concat pass) unless `keep`
+ *         asks for one of them
  *   params / pgrads: host arrays of device pointers.
  * Feature buffers live in a caller-owned arena (sgnn_prog_arena_floats floats; layout via
  * sgnn_prog_buffer_offset); `input` optionally points buffer 0 outside the arena.  Backward: garena has the

@@ -48,9 +48,14 @@ def parse():
                     help='CPU leg: torch-op oracle only (default: its C/OpenMP kernels for convolutions + rulebooks when built)')
     ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='internal: thread count of a CPU-baseline child process')
-    ap.add_argument('--free-running', action='store_true',
-                    help='generative masks from the predicted occupancy (the reference\'s behaviour; per-level row counts '
-                         'then depend on the random weights).  Default: teacher-forced masks from the target hierarchy')
+    ap.add_argument('--teacher-forced', action='store_true',
+                    help='generative masks from the target hierarchy instead of the predicted occupancy (per-level row counts '
+                         'then do not depend on the random weights).  Default: the reference\'s sigmoid(pred) > 0.5 masks')
+    ap.add_argument('--free-running', action='store_true', help='(default now; kept for older command lines)')
+    ap.add_argument('--classic', action='store_true',
+                    help='the classic eager step (host read-backs of the level sizes, one launch at a time from Python) '
+                         'instead of the capacity-mode step replayed from a HIP graph')
+    ap.add_argument('--headroom', type=float, default=1.5, help='capacity = measured rows x headroom (graph mode)')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='teacher-forced steps build their own geometry (5 read-backs at the head of the step) instead of '
                          'having it built one batch ahead on a second stream (train.GeometryPrefetcher)')
@@ -343,122 +348,165 @@ def main():
     from sgnn_amd import _lib, synth
     from sgnn_amd.model import GenModel
     from sgnn_amd.scn import program as P_
-    P_.PERSISTENT_ARENAS = True          # grow-only program arenas (a training loop never keeps two forward results)
     from sgnn_amd.train import (train_step, to_device, FlatGradAllReduce, make_optimizer, bind_to_device_numa,
-                                GeometryPrefetcher)
+                                GeometryPrefetcher, GraphStep)
     bound = bind_to_device_numa(dev)          # one process per GPU, on that GPU's NUMA node
     lib = _lib.load()
     _lib.require_gpu()
 
-    torch.manual_seed(1234)  # same initial weights on every rank
-    model = GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
-    opt = make_optimizer(model.parameters(), lr=1e-3)
-    sync = FlatGradAllReduce(model.parameters()) if world > 1 else None
     lw = np.ones(5, dtype=np.float32)
-    # two distinct resident batches per rank, alternated, so no step sees cached results
-    batches = [to_device(synth.make_batch(args.batch, (args.dim,) * 3, cfg=2,
-                                          first_block=(rank * 2 + j) * args.batch, occupancy=args.occupancy), dev)
-               for j in range(2)]
-    n_sites = [int(b['input'][0].shape[0]) for b in batches]
-
-    teacher = not args.free_running
-
-    # teacher-forced: batch i+1's geometry (all host read-backs of a step) is built on a second stream during step i,
-    # as a training loop with a prefetching loader would; every step's geometry is still computed once per step
-    # (not in the two-ranks-on-one-GPU test hook: the ranks' streams then outnumber the device's hardware queues)
     share = os.environ.get('SGNN_BENCH_SHARE_GPU') == '1' and world > 1
-    pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch and not share) else None
 
-    def step(i):
-        return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher, prefetch=pre,
-                          next_batch=batches[(i + 1) % 2] if pre is not None else None)
+    def make_batches(nb):
+        # two distinct resident batches per rank, alternated, so no step sees cached results
+        return [to_device(synth.make_batch(nb, (args.dim,) * 3, cfg=2, first_block=(rank * 2 + j) * nb,
+                                           occupancy=args.occupancy), dev) for j in range(2)]
 
+    def make_model():
+        torch.manual_seed(1234)  # same initial weights on every rank and in every leg
+        return GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
+
+    def timed(step, warmup, steps, hook=None):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize brackets; max over ranks."""
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if hook is not None:
+                hook(i, True)
+            step(warmup + i)
+            if hook is not None:
+                hook(i, False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def flat_sync(flat):        # data parallel: ONE all-reduce of the flat gradient buffer (+ its reached-flags tail)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    batches = make_batches(args.batch)
+    n_sites = [int(b['input'][0].shape[0]) for b in batches]
+    teacher = bool(args.teacher_forced)
+    classic = bool(args.classic)
     n_prof_steps = 0
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    lib.sgnn_prof_enable(1 << 15)
-    lib.sgnn_prof_disable()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = None
-    for i in range(args.steps):
-        # HIP events around every conv launch of every 4th timed step (the step loop is host-bound: two
-        # hipEventRecord per launch on all steps would itself cost ~5 % of the step)
-        sampled = (i % 4 == 0)
-        if sampled:
-            lib.sgnn_prof_resume()
-        _, _, outs = step(args.warmup + i)
-        if sampled:
-            lib.sgnn_prof_disable()
-            n_prof_steps += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    graph_info = None
 
-    if pre is not None and os.environ.get('SGNN_PREFETCH_DEBUG'):
-        sys.stderr.write('rank %d prefetch: build %.3f ms/step, throttle %.3f ms/step\n' % (
-            rank, 1e3 * pre.t_build / (args.steps + args.warmup), 1e3 * pre.t_throttle / (args.steps + args.warmup)))
-    valid = measure_valid_ratios(step, args.warmup + args.steps)    # one more (untimed) step, on every rank: it all-reduces
-    # the other mask mode on the same batches (what BENCH_r01 measured: masks from the predicted occupancy, per-level
-    # row counts depend on the weights), reported next to the headline for comparability across rounds
-    other = None
-    if args.steps >= 20 and not args.no_other_mode:
-        def step_other(i):
-            return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=not teacher)
-        k2 = max(10, args.steps // 3)
-        for i in range(6):
-            step_other(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        for i in range(k2):
-            _, _, outs2 = step_other(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([el2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        other = {'masks': 'predicted occupancy (free-running)' if teacher else 'teacher-forced', 'steps': k2,
-                 'value': round(args.batch * world * k2 / el2, 2), 'ms_per_step': round(1e3 * el2 / k2, 3),
-                 'generated_sites_per_level': [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs2[1]] +
-                                              [int(outs2[0][0].shape[0]) if len(outs2[0][0]) else 0]}
-    # the headline workload with every step building its own geometry (five read-backs at the head of the step, the
-    # GPU drains at every step boundary): what the prefetch lane buys, on the same box, in the same process
-    unprefetched = None
-    if pre is not None and args.steps >= 20 and not args.no_other_mode:
-        def step_plain(i):
-            return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=True)
-        k3 = max(10, args.steps // 3)
+    # ---- the headline leg ------------------------------------------------------------------------------------
+    if not classic:
+        # capacity mode: every level's row count stays on the device, the whole step (targets, forward, loss, backward,
+        # Adam) is captured once in a HIP graph and replayed; masks = sigmoid(predicted occupancy) > 0.5 like the
+        # reference (torch/model.py:233, 322) unless --teacher-forced
+        model = make_model()
+        gs = GraphStep(model, lr=1e-3, teacher_forced=teacher, headroom=args.headroom,
+                       grad_sync=flat_sync if world > 1 else None, world_size=world)
+
+        def step(i):
+            return gs(batches[i % 2], lw)
+        elapsed = timed(step, args.warmup, args.steps)
+        graph_info = dict(gs.stats)
+        graph_info['capacity'] = gs.capacity.describe()
+        graph_info['live_rows'] = gs.capacity.read()
+        live = graph_info['live_rows']
+        levels = [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live['gen'][:-1]] + [live['gen'][-1][0]]
+        # roofline leg: the same capacity-mode steps issued eagerly (same kernels, same sizes) with HIP events around
+        # every convolution launch — events cannot sit inside a replayed graph
+        gs._drain()
+        gs.stage = 2
+        lib.sgnn_prof_enable(1 << 15)
         for i in range(4):
-            step_plain(i)
+            step(i)
+            n_prof_steps += 1
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for i in range(k3):
-            step_plain(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el3 = time.perf_counter() - t2
-        if world > 1:
-            t = torch.tensor([el3], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el3 = float(t.item())
-        unprefetched = {'steps': k3, 'value': round(args.batch * world * k3 / el3, 2),
-                        'ms_per_step': round(1e3 * el3 / k3, 3)}
+        lib.sgnn_prof_disable()
+        valid = measure_valid_ratios(step, 0)
+        pre = None
+    else:
+        P_.PERSISTENT_ARENAS = True          # grow-only program arenas (a training loop never keeps two forward results)
+        model = make_model()
+        opt = make_optimizer(model.parameters(), lr=1e-3)
+        sync = FlatGradAllReduce(model.parameters()) if world > 1 else None
+        pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch and not share) else None
+
+        def step(i):
+            return train_step(model, opt, batches[i % 2], lw, grad_sync=sync, teacher_forced=teacher, prefetch=pre,
+                              next_batch=batches[(i + 1) % 2] if pre is not None else None)
+        lib.sgnn_prof_enable(1 << 15)
+        lib.sgnn_prof_disable()
+        holder = {}
+
+        def hook(i, before):   # HIP events around every conv launch of every 4th timed step
+            if i % 4:
+                return
+            if before:
+                lib.sgnn_prof_resume()
+            else:
+                lib.sgnn_prof_disable()
+                holder['n'] = holder.get('n', 0) + 1
+        outs_box = {}
+
+        def step_keep(i):
+            outs_box['o'] = step(i)[2]
+        elapsed = timed(step_keep, args.warmup, args.steps, hook)
+        n_prof_steps = holder.get('n', 0)
+        outs = outs_box['o']
+        levels = [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs[1]] + [int(outs[0][0].shape[0]) if len(outs[0][0]) else 0]
+        valid = measure_valid_ratios(step, args.warmup + args.steps)
+
+    # ---- comparison legs, same process, same box (fresh model each: same initial weights) ------------------------
+    legs = {}
+    if args.steps >= 20 and not args.no_other_mode and not share:
+        k2 = max(10, args.steps // 3)
+        P_.PERSISTENT_ARENAS = True
+        if not classic:
+            # (a) the classic eager path with the reference's masks: five host read-backs per step, ~680 launches issued
+            #     from Python (what BENCH_r01 / BENCH_r02's `other_mask_mode` measured)
+            m2 = make_model()
+            o2 = make_optimizer(m2.parameters(), lr=1e-3)
+            s2 = FlatGradAllReduce(m2.parameters()) if world > 1 else None
+            el = timed(lambda i: train_step(m2, o2, batches[i % 2], lw, grad_sync=s2, teacher_forced=False), 8, k2)
+            legs['classic_eager_free_running'] = {'steps': k2, 'value': round(args.batch * world * k2 / el, 2),
+                                                  'ms_per_step': round(1e3 * el / k2, 3)}
+            # (b) BENCH_r02's headline: teacher-forced masks + geometry built one batch ahead on a second stream
+            m3 = make_model()
+            o3 = make_optimizer(m3.parameters(), lr=1e-3)
+            s3 = FlatGradAllReduce(m3.parameters()) if world > 1 else None
+            p3 = GeometryPrefetcher(m3)
+            el = timed(lambda i: train_step(m3, o3, batches[i % 2], lw, grad_sync=s3, teacher_forced=True, prefetch=p3,
+                                            next_batch=batches[(i + 1) % 2]), 8, k2)
+            legs['classic_eager_teacher_forced_prefetch'] = {'steps': k2, 'value': round(args.batch * world * k2 / el, 2),
+                                                             'ms_per_step': round(1e3 * el / k2, 3)}
+            del m2, o2, m3, o3, p3
+            # (c) graph replay with teacher-forced masks (row counts independent of the weights)
+            m4 = make_model()
+            g4 = GraphStep(m4, lr=1e-3, teacher_forced=not teacher, headroom=args.headroom,
+                           grad_sync=flat_sync if world > 1 else None, world_size=world)
+            el = timed(lambda i: g4(batches[i % 2], lw), 8, k2)
+            live4 = g4.capacity.read()
+            legs['graph_teacher_forced' if not teacher else 'graph_free_running'] = {
+                'steps': k2, 'value': round(args.batch * world * k2 / el, 2), 'ms_per_step': round(1e3 * el / k2, 3),
+                'generated_sites_per_level': [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live4['gen'][:-1]] +
+                                             [live4['gen'][-1][0]], 'stats': dict(g4.stats)}
+            del m4, g4
+            # (d) the fixed cost of a step: the same graph-replayed step on ONE block per GPU
+            if args.batch > 1:
+                b1 = make_batches(1)
+                m5 = make_model()
+                g5 = GraphStep(m5, lr=1e-3, teacher_forced=teacher, headroom=max(args.headroom, 2.0),
+                               grad_sync=flat_sync if world > 1 else None, world_size=world)
+                el = timed(lambda i: g5(b1[i % 2], lw), 8, k2)
+                legs['batch1'] = {'steps': k2, 'ms_per_step': round(1e3 * el / k2, 3), 'stats': dict(g5.stats)}
+                del m5, g5, b1
+    other = legs or None
+    unprefetched = None
     if rank == 0:
         agg = collect_prof(lib, valid)
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
@@ -495,6 +543,10 @@ def main():
                          'TFLOPs': round(tfs, 2), 'frac_of_fp32_mfma_peak': round(tfs / FP32_MFMA_PEAK_TF, 4),
                          'conv_ms_per_step': round(sum(a['ms'] for a in agg.values()) / max(n_prof_steps, 1), 3),
                          'profiled_steps': n_prof_steps,
+                         'timing': ('HIP events around every convolution launch of %d capacity-mode steps issued eagerly '
+                                    'right after the timed region (same kernels and sizes as the replayed graph; events '
+                                    'cannot be recorded inside a replay)' % n_prof_steps) if not classic else
+                                   'HIP events around every convolution launch of every 4th timed step',
                          # `frac` above is over ALL launches of the kernel; split by level size it is throughput-bound
                          # only on the big levels and launch/latency-bound on the small ones
                          'by_level_size': [
@@ -505,9 +557,6 @@ def main():
                               'frac_of_fp32_mfma_peak': round(b['flops'] / (b['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
                              for _, b in sorted(dom['by_size'].items(), reverse=True) if b['ms'] > 0],
                          'top_kernels': kernels[:6]})
-        levels = None
-        if outs is not None:
-            levels = [int(o[0].shape[0]) if len(o[0]) else 0 for o in outs[1]] + [int(outs[0][0].shape[0]) if len(outs[0][0]) else 0]
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_subprocess(args)
@@ -518,16 +567,22 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: full SG-NN 4-level GenModel (643735 params, random init), %d synthetic '
-                                   '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam; %s'
+                                   '%d^3 TSDF surface blocks per GPU at ~%.0f%% occupancy, compute_targets+fwd+loss+bwd+Adam; %s; %s'
                                    % (args.batch, args.dim, 100 * args.occupancy,
                                       'generative masks teacher-forced from the target hierarchy (row counts independent of '
-                                      'the random weights)' if teacher else 'generative masks from the predicted occupancy'),
+                                      'the random weights)' if teacher else
+                                      'generative masks = sigmoid(predicted occupancy) > 0.5 as in the reference (torch/model.py:233,322)',
+                                      'classic eager step (host read-backs of the level sizes)' if classic else
+                                      'capacity mode: row counts stay on the device, the whole step is ONE replayed HIP graph '
+                                      '(train.GraphStep)'),
                        'host_cpus_bound': (len(bound) if bound else None), 'global_batch': args.batch * world, 'input_sites_per_batch': n_sites,
                        'generated_sites_per_level': levels, 'parallelism': 'dp%d' % world,
                        'geometry': ('built one batch ahead on a second stream during the previous step (once per step; '
-                                    'train.GeometryPrefetcher)' if pre is not None else 'built at the head of its own step'),
+                                    'train.GeometryPrefetcher)' if pre is not None else
+                                    'built inside its own step' + ('' if classic else ' (inside the graph)')),
+                       'graph': graph_info,
                        'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
-            'roofline': roof, 'cpu_baseline': cpu, 'other_mask_mode': other, 'without_geometry_prefetch': unprefetched,
+            'roofline': roof, 'cpu_baseline': cpu, 'other_legs': other,
         }
         if cpu:
             res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)

@@ -24,6 +24,14 @@
  *  - feature matrices are row-major float32 (N, C), contiguous.
  *  - neighbour / children tables are int32 [K][ld] (offset-major), -1 = no rule.
  *    A "rulebook" in upstream's sense is { (k, table[k][j], j) : table[k][j] >= 0 }.
+ *  - capacity mode (device-side row counts): wherever a function takes a trailing `const int64_t *n_dev`
+ *    (or nf_dev / m_dev ...), a non-NULL pointer makes the kernels read the row count from device memory at
+ *    run time, clamped to the host value n, which then is only the CAPACITY the launch and the buffers are
+ *    sized for.  The generative path (torch/model.py:229-247, 315-336) decides every level's row count from
+ *    predicted logits; with the counts left on the device a whole training step has no host read-back and a
+ *    fixed launch sequence, i.e. it can be captured in a HIP graph and replayed (sgnn_amd/train.py GraphStep).
+ *    NULL = the host value is exact (the classic path).  Counts that exceed a capacity are clamped and
+ *    SGNN_STATUS_OVERFLOW is raised in the status word; sgnn_adam_flat then leaves the parameters untouched.
  */
 #ifndef SGNN_HIP_H
 #define SGNN_HIP_H
@@ -43,6 +51,7 @@ extern "C" {
 /* status bits written (atomically OR-ed) into the device `status` word */
 #define SGNN_STATUS_COORD_RANGE 1 /* a coordinate was outside the supported range */
 #define SGNN_STATUS_DUPLICATE 2   /* InputLayer(mode=0) saw the same site twice */
+#define SGNN_STATUS_OVERFLOW 4    /* capacity mode: a level produced more rows than its buffers hold (step discarded) */
 
 typedef void *sgnn_stream_t; /* hipStream_t */
 
@@ -61,18 +70,19 @@ int64_t sgnn_hash_capacity(int64_t n);
 /* int64 [z,y,x,b] rows (the reference's LongTensor locs) -> int32 rows; sets
  * SGNN_STATUS_COORD_RANGE if a value is out of range */
 int sgnn_coords_from_i64(const int64_t *locs, int64_t n, int32_t *coords, int32_t *status,
-                         sgnn_stream_t stream);
+                         const int64_t *n_dev, sgnn_stream_t stream);
 /* and back (metadata.getSpatialLocations, torch/model.py:380) */
-int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, sgnn_stream_t stream);
+int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, const int64_t *n_dev,
+                       sgnn_stream_t stream);
 
 /* build key->row table: keys[cap] (uint64), vals[cap] (int32).  The function
  * clears the table itself.  Sets SGNN_STATUS_DUPLICATE on repeated sites. */
 int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
-                    int32_t *status, sgnn_stream_t stream);
+                    int32_t *status, const int64_t *n_dev, sgnn_stream_t stream);
 
 /* row of each query site, or -1 (concat_skip join, torch/model.py:338-355) */
 int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *query,
-                     int64_t m, int32_t *rows, sgnn_stream_t stream);
+                     int64_t m, int32_t *rows, const int64_t *m_dev, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Rulebooks
@@ -87,7 +97,7 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
 int sgnn_rulebook_set_lds(int on);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
-                        sgnn_stream_t stream);
+                        const int64_t *n_dev, sgnn_stream_t stream);
 
 /* The same table through a dense index volume (volume[((b*Z + z)*Y + y)*X + x] = row, -1 elsewhere): one coalesced
  * 4-byte read per neighbour instead of a hash probe.  `volume` is a persistent workspace of volume_entries int32 that
@@ -98,7 +108,7 @@ int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
  * blocks): 18 us against 97 us for sgnn_rulebook_subm3 (profiles/r02j_rulebook.txt). */
 int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords, int64_t n,
                               int dim_z, int dim_y, int dim_x, int32_t *volume, int64_t volume_entries, int32_t *nbr,
-                              int64_t ld, sgnn_stream_t stream);
+                              int64_t ld, const int64_t *n_dev, sgnn_stream_t stream);
 
 /* Tile index of a 3x3x3 table (ld % 256 == 0): per 128-row tile the unique input rows its rules refer to and the
  * table in 16-bit tile-local slots (tiles with more than 768 unique rows are flagged and keep using the int32 table).
@@ -133,19 +143,21 @@ int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint64_t *ckeys,
  * children drives the forward conv / unpool-backward, ptable the data-gradient. */
 int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t nf,
                       int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
-                      sgnn_stream_t stream);
+                      const int64_t *nf_dev, const int64_t *nc_dev, sgnn_stream_t stream);
 
 /* Phase 1 for `depth` successive levels in one submission (a U-Net's whole stride-2 pyramid), row counts staying on
  * the device: level 0 = fine_coords with *n0_dev rows (n0_dev NULL: n0 rows), at most `cap` rows; for l < depth it
  * writes parent[l] (cap ints: coarse row of every site of level l), coarse_coords[l] (cap x 4), the hash of level l+1
  * (ckeys[l], cvals[l]; ccap = sgnn_hash_capacity(cap) each) and counts_dev[l] = rows of level l+1.  ckeys .. coarse_coords
  * are HOST arrays of device pointers.  Results are identical to `depth` calls of sgnn_rulebook_down2 (first-touch
- * order); the host reads all counts with one copy and then calls sgnn_down2_tables per level. */
+ * order); the host reads all counts with one copy and then calls sgnn_down2_tables per level.
+ * Capacity mode: level_caps (HOST array, depth entries, or NULL) clamps counts_dev[l] to the capacity of the buffers
+ * that will hold level l+1's features and raises SGNN_STATUS_OVERFLOW in *status when it had to. */
 int64_t sgnn_down2_chain_ws_bytes(int64_t cap);
 int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_dev, int64_t cap, int depth,
                      void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
-                     void *const *coarse_coords, int64_t *counts_dev, void *ws, int64_t ws_bytes,
-                     sgnn_stream_t stream);
+                     void *const *coarse_coords, int64_t *counts_dev, const int64_t *level_caps, int32_t *status,
+                     void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Sparse convolution: out[j] = sum_k W[k]^T x[table[k][j]]   (fp32 MFMA 16x16x4)
@@ -274,7 +286,7 @@ int sgnn_concat3_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, 
                           int64_t nc, sgnn_stream_t stream);
 /* dst (n_dst rows, zero-filled here) ; dst[idx[r]] = src[r]   (idx unique) */
 int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
-                      int64_t n_dst, sgnn_stream_t stream);
+                      int64_t n_dst, const int64_t *m_dev, sgnn_stream_t stream);
 /* dst[j] = sum_k src[table[k*ld+j]] over valid entries (UnPooling bwd: table = children) */
 int sgnn_gather_sum(const float *src, int c, const int32_t *table, int64_t ld, int K,
                     int64_t n_out, float *dst, sgnn_stream_t stream);
@@ -300,7 +312,7 @@ int sgnn_add(const float *a, const float *b, int64_t count, float *y, sgnn_strea
  * ------------------------------------------------------------------------- */
 /* children coords: out[(8i+j)] = {2z+dz, 2y+dy, 2x+dx, b}, j = 4dz+2dy+dx
  * (Refinement.to_next_level_locs, torch/model.py:192-207) */
-int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, sgnn_stream_t stream);
+int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, const int64_t *n_dev, sgnn_stream_t stream);
 /* all voxel coordinates of a dense (B, d0, d1, d2) volume, batch-major raster order
  * (GenModel.dense_coarse_to_sparse, torch/model.py:319-321) */
 int sgnn_dense_coords(int batch, int d0, int d1, int d2, int32_t *out, sgnn_stream_t stream);
@@ -315,6 +327,15 @@ int sgnn_compact_dense(const int32_t *coords, int64_t n, const float *vol, int b
                        int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, int64_t *count, void *ws,
                       int64_t ws_bytes, sgnn_stream_t stream);
+/* capacity mode of the two generative mask compactions: the number of candidates is *n_dev (NULL: n), the kept count
+ * count2[0] is clamped to keep_cap (SGNN_STATUS_OVERFLOW in *status otherwise) and count2[1] = 8 * count2[0], the row
+ * count of the kept sites' 8-child expansion (torch/model.py:192-207), is published with it */
+int sgnn_compact_sigmoid_cap(const float *logits, int64_t stride, int64_t n, const int64_t *n_dev, int32_t *sel,
+                             int64_t *count2, int64_t keep_cap, int32_t *status, void *ws, int64_t ws_bytes,
+                             sgnn_stream_t stream);
+int sgnn_compact_dense_cap(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol, int batch, int d0,
+                           int d1, int d2, int32_t *sel, int64_t *count2, int64_t keep_cap, int32_t *status, void *ws,
+                           int64_t ws_bytes, sgnn_stream_t stream);
 
 /* scn.SparseToDense (torch/model.py:47): dense (B, C, d0, d1, d2) zero-filled here */
 int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, int c, float *dense,
@@ -350,12 +371,12 @@ int64_t sgnn_loss_ws_bytes(void);
 int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
                         const float *tgt_occ, const float *tgt_sdf, const float *weights,
                         const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
-                        int mask_mode, double *sums, float *out2, void *ws, int64_t ws_bytes,
+                        int mask_mode, const int64_t *m_dev, double *sums, float *out2, void *ws, int64_t ws_bytes,
                         sgnn_stream_t stream);
 int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
                         const float *tgt_occ, const float *tgt_sdf, const float *weights,
                         const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
-                        int mask_mode, const double *sums, const float *gout2, float *dvals,
+                        int mask_mode, const int64_t *m_dev, const double *sums, const float *gout2, float *dvals,
                         sgnn_stream_t stream);
 
 /* Targets of the hierarchical loss in three launches — compute_targets + compute_weights_missing_geo
@@ -364,7 +385,8 @@ int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int
  * coarser levels, listed from the second finest downwards in the host pointer arrays hier_in / occ / w / hier:
  * occ = 2x2x2 max-pool of the level above, w = that level's w[::2,::2,::2], hier = clamp(hier_in).  w_last NULL: no
  * weights.  input_locs = the (n_locs, 4) int64 [z,y,x,b] input sites.  Dimensions must be divisible by 2^ncoarse. */
-int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *input_locs, int64_t n_locs, int batch,
+int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *input_locs, int64_t n_locs,
+                      const int64_t *n_locs_dev, int batch,
                       int d0, int d1, int d2, float trunc, int masking, float weight_missing_geo, int ncoarse,
                       void *const *hier_in, float *tsdf, float *hier_last, float *occ_last, float *w_last,
                       void *const *occ, void *const *w, void *const *hier, sgnn_stream_t stream);
@@ -397,7 +419,8 @@ int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *
  *         ptable tables and the parent array (device pointers, NULL where unused); lev_tile: the level's tile index
  *         (sgnn_tile_index) or NULL — the array itself may be NULL — selecting the LDS-staged 3x3x3 kernel for 16->16
  *         layers of that level; a JoinTable's inputs are column ranges of its output (no concat pass) unless `keep`
- *         asks for one of them
+ *         asks for one of them; lev_cnt (the array may be NULL): per rows class a device int64 with the live row
+ *         count (capacity mode, see the conventions above; lev_n then holds the capacities) or NULL
  *   params / pgrads: host arrays of device pointers.
  * Feature buffers live in a caller-owned arena (sgnn_prog_arena_floats floats; layout via
  * sgnn_prog_buffer_offset); `input` optionally points buffer 0 outside the arena.  Backward: garena has the
@@ -419,15 +442,15 @@ int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *buf
 int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                      void *const *lev_tile, int nlev, void *const *params, int nparams, void *const *ext,
-                      void *const *idx, int nidx,
+                      void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, int nparams,
+                      void *const *ext, void *const *idx, int nidx,
                       float *arena, int64_t arena_floats, const int32_t *keep, int training, void *ws,
                       int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                       void *const *lev_tile, int nlev, void *const *params, void *const *pgrads, int nparams,
-                       void *const *ext,
+                       void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, void *const *pgrads,
+                       int nparams, void *const *ext,
                        void *const *gext, void *const *idx, int nidx, const float *arena, float *garena,
                        int64_t arena_floats, void *const *gout, const int32_t *keep, int training, void *ws,
                        int64_t ws_bytes, sgnn_stream_t stream);
@@ -438,6 +461,22 @@ int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int
  * Process-wide setting; ws2 must be private to the lane and >= the largest sgnn_conv_bwd_weight_ws_bytes of the
  * program (smaller: the lane is silently not used). */
 int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_bytes);
+
+/* ---------------------------------------------------------------------------
+ * Optimizer step (torch/train.py:81 optim.Adam, :264 optimizer.step()) as one launch over flat buffers of all n
+ * parameters.  seg: HOST array of nseg (<= 8) x 5 int64 = {begin, end, cnt, flag, step}: elements [begin, end) are
+ * updated iff the segment was reached this step — *flag > 0 (device float, if flag != 0), else *cnt > 0 (device
+ * int64 row count, if cnt != 0), else always — which is torch.optim.Adam skipping parameters whose grad is None (a
+ * generative stage without input sites, torch/model.py:211,260) decided on the device; step: device float counter
+ * of the segment's updates (bias correction), incremented here.  lr_dev: device float.  grads are multiplied by
+ * grad_scale (1 / world size after a sum all-reduce).  Nothing is updated while *status has SGNN_STATUS_OVERFLOW.
+ * sgnn_seg_flags writes flags[t] = (*cnt_ptrs[t] > 0) for a data-parallel step's all-reduce (cnt_ptrs: HOST array of
+ * device addresses, 0 = always 1).
+ * ------------------------------------------------------------------------- */
+int sgnn_adam_flat(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const int64_t *seg,
+                   int nseg, const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, const int32_t *status, sgnn_stream_t stream);
+int sgnn_seg_flags(const int64_t *cnt_ptrs, int nseg, float *flags, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * On-disk formats feeding the path: .sdfs training chunks, .sdf scenes, .knw masks.

@@ -20,18 +20,18 @@ PROTOTYPES = {
     'sgnn_version': (c_i32, []),
     'sgnn_arch': (c_cp, []),
     'sgnn_hash_capacity': (c_i64, [c_i64]),
-    'sgnn_coords_from_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
-    'sgnn_coords_to_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
-    'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_coords_from_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_coords_to_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_rulebook_set_lds': (c_i32, [c_i32]),
-    'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
-    'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
     'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_down2_chain_ws_bytes': (c_i64, [c_i64]),
-    'sgnn_down2_chain': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_down2_chain': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_conv_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'sgnn_conv_fwd_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
@@ -53,19 +53,23 @@ PROTOTYPES = {
     'sgnn_bn_bwd_ex': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_gather_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_gather_rows_dn': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    'sgnn_scatter_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_scatter_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_gather_sum': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),
     'sgnn_repeat_rows': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     'sgnn_sum_groups': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     'sgnn_concat_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_concat_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_add': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
-    'sgnn_expand8_coords': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_expand8_coords': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_dense_coords': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'sgnn_compact_ws_bytes': (c_i64, [c_i64]),
     'sgnn_compact_sigmoid': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_compact_dense': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_compact_mask': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_compact_sigmoid_cap': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_compact_dense_cap': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_adam_flat': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
+    'sgnn_seg_flags': (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     'sgnn_sparse_to_dense': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_dense_to_sparse': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_linear_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
@@ -73,10 +77,10 @@ PROTOTYPES = {
     'sgnn_linear_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_loss_ws_bytes': (c_i64, []),
     'sgnn_loss_level_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
-                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_loss_level_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64,
-                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    'sgnn_loss_targets': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp,
+                                    c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_loss_targets': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine_bwd': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
@@ -85,9 +89,9 @@ PROTOTYPES = {
     'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
-    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                   c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
-    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                    c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_concat3_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_concat3_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                                                    const float *__restrict__ invstd,
                                                    const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float leak,
-                                                   double *__restrict__ partial) {
+                                                   double *__restrict__ partial, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   extern __shared__ double sh[];  // [rpb][2][c] would be large; reduce per column group instead
   const int tid = threadIdx.x;
   const int col = tid % cq, rloc = tid / cq;
@@ -193,12 +194,18 @@ __global__ __launch_bounds__(256) void k_bn_finalize_fwd(const double *__restric
                                                         float *__restrict__ running_mean,
                                                         float *__restrict__ running_var,
                                                         float *__restrict__ save_mean,
-                                                        float *__restrict__ save_invstd) {
+                                                        float *__restrict__ save_invstd, const int64_t *n_dev) {
   __shared__ double sh[512];
+  n = sgnn_dyn_n(n, n_dev);
   const int ch = blockIdx.x;
   double s, s2;
   bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
   if (threadIdx.x == 0) {
+    if (n <= 0) {   // capacity mode, empty level: the reference never runs the layer — running statistics untouched
+      save_mean[ch] = 0.f;
+      save_invstd[ch] = 0.f;
+      return;
+    }
     const double mean = s / (double)n;
     double var = s2 / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -273,9 +280,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
                                                  const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma,
                                                  const float *__restrict__ beta, float leak,
-                                                 float *__restrict__ y, int64_t ldy, BnFuse fuse) {
+                                                 float *__restrict__ y, int64_t ldy, BnFuse fuse,
+                                                 const int64_t *n_dev) {
   __shared__ float s_mean[BN_FUSE_MAXC], s_inv[BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
+  n = sgnn_dyn_n(n, n_dev);
+  if (n <= 0) return;        // capacity mode, empty level (whole grid: no barrier is skipped by a part of a workgroup)
   if (fuse.partial) {
     bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
@@ -339,16 +349,18 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
 // coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); also dgamma/dbeta.  One workgroup per channel.
 __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restrict__ partial, int nblk,
                                                         int64_t n, int c, float *__restrict__ dgamma,
-                                                        float *__restrict__ dbeta, float *__restrict__ coef) {
+                                                        float *__restrict__ dbeta, float *__restrict__ coef,
+                                                        const int64_t *n_dev) {
   __shared__ double sh[512];
+  n = sgnn_dyn_n(n, n_dev);
   const int ch = blockIdx.x;
   double s, s2;
   bn_reduce_channel(partial, nblk, c, ch, sh, s, s2);
   if (threadIdx.x == 0) {
     if (dbeta) dbeta[ch] = (float)s;
     if (dgamma) dgamma[ch] = (float)s2;
-    coef[ch] = (float)(s / (double)n);
-    coef[c + ch] = (float)(s2 / (double)n);
+    coef[ch] = n > 0 ? (float)(s / (double)n) : 0.f;
+    coef[c + ch] = n > 0 ? (float)(s2 / (double)n) : 0.f;
   }
 }
 
@@ -360,15 +372,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float leak, int training,
                                                      const float *__restrict__ coef, float *dx, int64_t ld_dx,
-                                                     BnFuse fuse, const float *addend, int64_t ld_add) {
+                                                     BnFuse fuse, const float *addend, int64_t ld_add,
+                                                     const int64_t *n_dev) {
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
+  n = sgnn_dyn_n(n, n_dev);
   if (fuse.partial) {
     bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
       const double s1 = s_tot[ch], s2 = s_tot[c + ch];
-      s_coef[ch] = (float)(s1 / (double)n);
-      s_coef[c + ch] = (float)(s2 / (double)n);
+      s_coef[ch] = n > 0 ? (float)(s1 / (double)n) : 0.f;
+      s_coef[c + ch] = n > 0 ? (float)(s2 / (double)n) : 0.f;
       if (blockIdx.x == 0) {
         if (fuse.dbeta) fuse.dbeta[ch] = (float)s1;
         if (fuse.dgamma) fuse.dgamma[ch] = (float)s2;
@@ -440,7 +454,7 @@ static int bn_apply_grid(int64_t n, const BnGeom &g) {
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
                      float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
-                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
@@ -463,17 +477,17 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
       const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
       if (g.vec == 4)
         hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
-                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
       else
         hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
-                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws);
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
       partial = (const double *)ws;
     }
     if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
       fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
       hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
-                         running_mean, running_var, save_mean, save_invstd);
+                         running_mean, running_var, save_mean, save_invstd, n_dev);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
     SGNN_HIP_TRY(hipMemsetAsync(save_invstd, 0, c * sizeof(float), s));
@@ -486,10 +500,10 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
     const int grid = bn_apply_grid(n, g);
     if (g.vec == 4)
       hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
-                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse);
+                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
     else
       hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
-                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse);
+                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -542,7 +556,8 @@ SGNN_EXPORT int sgnn_bn_bwd_ex(const float *x, int64_t ldx, const float *dy, int
 int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
                      const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
-                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream,
+                     const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   if (n == 0) {
@@ -573,24 +588,24 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
     const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
     if (g.vec == 4)
       hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
-                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws);
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
     else
       hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
-                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws);
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
     partial = (const double *)ws;
   }
   BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))
     fuse = BnFuse{partial, (int)nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   else
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef, n_dev);
   const int grid = bn_apply_grid(n, g);
   if (g.vec == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add);
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add);
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -37,6 +37,9 @@ struct ConvEpi {
   const int32_t *tile_cnt, *tile_u;
   const uint16_t *tile_lt;
   int tile_all;   // 1: every compiled tile shape (sgnn_conv_fwd_tiled); 0: only those that beat the gather kernel
+  // capacity mode: the output row count lives in device memory (*n_dev, clamped to the n_out the launch was sized
+  // for); NULL = the host value is exact.  Lets a whole training step be captured in a HIP graph.
+  const int64_t *n_dev;
 };
 
 // the three arrays inside a tile-index blob of a table with leading dimension ld
@@ -55,14 +58,17 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                        sgnn_stream_t stream);
 int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K, bool tiled);
 // bn.hip internals used by prog.hip (strided rows, statistics partials supplied by a convolution epilogue)
+// n_dev (every internal entry point below, default NULL): device row count, clamped to the host value n, which then
+// is the capacity the launch is sized for
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
                      float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
-                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
                      const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
-                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+                     const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream,
+                     const int64_t *n_dev = nullptr);
 bool sgnn_conv_epi_supported(int cin, int cout);
 bool dw_shape_ok(int cin, int cout);   // conv.hip: compiled weight-gradient shapes (strided rows need one)
 // deferred weight-gradient reduces (conv.hip): partial[nblk][elems] -> dw[elems], many tensors in one launch
@@ -81,22 +87,33 @@ extern DwBatch *sgnn_dw_batch;
 int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s);
 // rows.hip: strided row movement (prog.hip: JoinTable inputs written in place)
 int sgnn_gather_rows_ld(const float *src, int64_t ld_src, int c, const int32_t *idx, int64_t m, float *dst,
-                        int64_t ld_dst, sgnn_stream_t stream);
+                        int64_t ld_dst, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_gather_sum_ld(const float *src, int64_t ld_src, int c, const int32_t *table, int64_t ld, int K, int64_t n_out,
-                       float *dst, int64_t ld_dst, sgnn_stream_t stream);
+                       float *dst, int64_t ld_dst, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t n, int c, float *y, int64_t ldy,
-                sgnn_stream_t stream);
+                sgnn_stream_t stream, const int64_t *n_dev = nullptr);
+int sgnn_sum_groups_dn(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream, const int64_t *n_dev);
+int sgnn_concat_rows_dn(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib, int64_t m,
+                        float *dst, sgnn_stream_t stream, const int64_t *n_dev);
+int sgnn_concat_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int64_t m, float *da,
+                            int64_t na, float *db, int64_t nb, sgnn_stream_t stream, const int64_t *n_dev);
+int sgnn_concat3_rows_dn(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
+                         const float *c, int cc, const int32_t *ic, int64_t m, float *dst, sgnn_stream_t stream,
+                         const int64_t *n_dev);
+int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int cc,
+                             const int32_t *ic, int64_t m, float *da, int64_t na, float *db, int64_t nb, float *dc,
+                             int64_t nc, sgnn_stream_t stream, const int64_t *n_dev);
 int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
                               const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
-                              int64_t ws_bytes, sgnn_stream_t stream);
+                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR);
 // linear.hip: heads whose weight rows / biases are separate tensors
 int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,
-                         float *y, sgnn_stream_t stream);
+                         float *y, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
                          float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
-                         sgnn_stream_t stream);
+                         sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 
 #define SGNN_CHECK_ARG(cond)                                                    \
   do {                                                                          \
@@ -123,6 +140,13 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
       return SGNN_EHIP;                                                         \
     }                                                                           \
   } while (0)
+
+// row count of a launch: the host value, or — capacity mode — the device value clamped to it
+__device__ __forceinline__ int64_t sgnn_dyn_n(int64_t n_host, const int64_t *n_dev) {
+  if (!n_dev) return n_host;
+  const int64_t v = *n_dev;
+  return v < n_host ? (v < 0 ? 0 : v) : n_host;
+}
 
 static inline int sgnn_grid_for(int64_t work, int block, int cap = 1 << 20) {
   int64_t g = (work + block - 1) / block;

@@ -186,6 +186,14 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const unsigned lin = sgnn_xcd_tile(blockIdx.x, gridDim.x);
   const unsigned groups = EX ? (unsigned)ex.groups : 1u;
   const unsigned tile = lin / groups, grp = lin % groups;
+  if (epi.n_dev) {   // capacity mode: the launch covers the level's capacity, the live row count is on the device
+    n_out = sgnn_dyn_n(n_out, epi.n_dev);
+    if ((int64_t)tile * 4 * RPW >= n_out) {   // workgroup past the end: nothing to compute, zero statistics partials
+      if (!EX && epi.stats)
+        for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
+      return;
+    }
+  }
   const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
   const int32_t *kmap = nullptr, *kadd_g = nullptr;
   if constexpr (EX) {
@@ -589,6 +597,14 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
+  if (epi.n_dev) {   // capacity mode (see k_conv_fwd)
+    n_out = sgnn_dyn_n(n_out, epi.n_dev);
+    if (row0 >= n_out) {
+      if (epi.stats)
+        for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
+      return;
+    }
+  }
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
   const int per = (K + 3) >> 2;               // offsets of this wave: [k0, k0 + nk)
   const int k0 = wave * per;
@@ -725,7 +741,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
                                                          const float *__restrict__ w, int K,
                                                          const int32_t *__restrict__ table, int64_t ld,
                                                          int64_t n_out, int cout, float *__restrict__ y,
-                                                         int flags, int in_shift, ConvEx ex) {
+                                                         int flags, int in_shift, ConvEx ex, const int64_t *n_dev) {
+  n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_out * ex.groups * cout) return;
   const int64_t orow = t / cout;
@@ -843,7 +860,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   } while (0)
   // large level of a narrow 3x3x3 layer with a tile index: unique rows through LDS (k_conv_tile)
   if (plain && !small && K == 27 && in_shift == 0 && g_tile_kernel && epi.tile_cnt && epi.tile_u && epi.tile_lt &&
-      conv_tile_shape(cin, cout, epi.tile_all != 0)) {
+      conv_tile_shape(cin, cout, epi.tile_all != 0) && !epi.n_dev) {
     // persistent workgroups, two per CU (76.8 KiB of LDS each); grid % 8 == 0 for the XCD schedule
     const int ntiles = (int)((n_out + TILE_ROWS - 1) / TILE_ROWS);
     const unsigned tgrid = (unsigned)(ntiles < g_tile_grid ? ((ntiles + 7) & ~7) : g_tile_grid);
@@ -871,7 +888,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
     }
     const int64_t total = n_out * groups * cout;
     hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
-                       table, ld, n_out, cout, y, flags, in_shift, ex);
+                       table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev);
   }
   sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
@@ -1025,7 +1042,8 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift, ConvEx ex, int64_t ldx,
-                                                int64_t ld_dy) {
+                                                int64_t ld_dy, const int64_t *n_dev) {
+  n_out = sgnn_dyn_n(n_out, n_dev);   // capacity mode: row blocks past the live count write zero partials
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
   constexpr int DW_KPB = KPBT > 0 ? KPBT : DwCfg<CIN, COUT>::KPB;
   constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
@@ -1287,7 +1305,8 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
                                                         const float *__restrict__ dy, int cout,
                                                         const int32_t *__restrict__ table, int64_t ld, int K,
                                                         int64_t n_out, float *__restrict__ dw, int in_shift,
-                                                        ConvEx ex) {
+                                                        ConvEx ex, const int64_t *n_dev) {
+  n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)ex.groups * K * cin * cout) return;
   const int co = (int)(e % cout), ci = (int)((e / cout) % cin), k = (int)((e / ((int64_t)cin * cout)) % K);
@@ -1342,7 +1361,7 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
 int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
                               const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
-                              int64_t ws_bytes, sgnn_stream_t stream) {
+                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(ldx >= cin && ldx <= 1024 && ld_dy >= cout && ld_dy <= 1024);
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
                  in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
@@ -1378,15 +1397,15 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       /* every wave walk 9 dependent gather rounds -> one offset per workgroup (same sums, same order)     */ \
       if (n_out < DW_FINE_ROWS && g_small_kernel)                                                          \
         hipLaunchKernelGGL((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
-                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy);  \
+                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
       else                                                                                                 \
         hipLaunchKernelGGL((k_conv_dw<CI, CO, false>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
                            dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift,  \
-                           ex, ldx, ld_dy);                                                                \
+                           ex, ldx, ld_dy, n_dev);                                                         \
     } else {                                                                                               \
       hipLaunchKernelGGL((k_conv_dw<CI, CO, EXV>),                                                         \
                          dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, \
-                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy); \
+                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
     }                                                                                                      \
     sgnn_prof_end_launch(prof, s);                                                                         \
     if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
@@ -1409,7 +1428,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       return SGNN_EINVAL;
     }
     hipLaunchKernelGGL(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
-                       cout, table, ld, K, n_out, dw, in_shift, ex);
+                       cout, table, ld, K, n_out, dw, in_shift, ex, n_dev);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -34,7 +34,9 @@ SGNN_EXPORT int64_t sgnn_hash_capacity(int64_t n) {
 // coordinate conversion
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_coords_from_i64(const int64_t *__restrict__ locs, int64_t n,
-                                                        int4 *__restrict__ coords, int32_t *status) {
+                                                        int4 *__restrict__ coords, int32_t *status,
+                                                        const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   bool bad = false;
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(256) void k_coords_from_i64(const int64_t *__restri
 }
 
 __global__ __launch_bounds__(256) void k_coords_to_i64(const int4 *__restrict__ coords, int64_t n,
-                                                      int64_t *__restrict__ locs) {
+                                                      int64_t *__restrict__ locs, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n; i += stride) {
@@ -60,22 +63,23 @@ __global__ __launch_bounds__(256) void k_coords_to_i64(const int4 *__restrict__ 
 }
 
 SGNN_EXPORT int sgnn_coords_from_i64(const int64_t *locs, int64_t n, int32_t *coords, int32_t *status,
-                                     sgnn_stream_t stream) {
+                                     const int64_t *n_dev, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && status != nullptr);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs && coords);
   hipLaunchKernelGGL(k_coords_from_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, locs, n, (int4 *)coords, status);
+                     (hipStream_t)stream, locs, n, (int4 *)coords, status, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
 
-SGNN_EXPORT int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *locs, const int64_t *n_dev,
+                                   sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs && coords);
   hipLaunchKernelGGL(k_coords_to_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, (const int4 *)coords, n, locs);
+                     (hipStream_t)stream, (const int4 *)coords, n, locs, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -86,7 +90,8 @@ SGNN_EXPORT int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *lo
 __global__ __launch_bounds__(256) void k_hash_build(const int4 *__restrict__ coords, int64_t n,
                                                    unsigned long long *__restrict__ keys,
                                                    int32_t *__restrict__ vals, uint64_t mask,
-                                                   int32_t *status) {
+                                                   int32_t *status, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n; i += stride) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void k_hash_build(const int4 *__restrict__ coo
 }
 
 SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals,
-                                int64_t cap, int32_t *status, sgnn_stream_t stream) {
+                                int64_t cap, int32_t *status, const int64_t *n_dev, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && keys && vals && status);
   SGNN_CHECK_ARG(cap >= 2 * n && cap >= 2 && (cap & (cap - 1)) == 0);
   if (n >= (1ll << 31)) {
@@ -121,7 +126,7 @@ SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys
   SGNN_CHECK_ARG(coords);
   hipLaunchKernelGGL(k_hash_build, dim3(sgnn_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const int4 *)coords, n, (unsigned long long *)keys, vals, (uint64_t)(cap - 1),
-                     status);
+                     status, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -129,7 +134,8 @@ SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys
 __global__ __launch_bounds__(256) void k_hash_lookup(const uint64_t *__restrict__ keys,
                                                     const int32_t *__restrict__ vals, uint64_t mask,
                                                     const int4 *__restrict__ query, int64_t m,
-                                                    int32_t *__restrict__ rows) {
+                                                    int32_t *__restrict__ rows, const int64_t *m_dev) {
+  m = sgnn_dyn_n(m, m_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < m; i += stride) {
@@ -141,12 +147,13 @@ __global__ __launch_bounds__(256) void k_hash_lookup(const uint64_t *__restrict_
 }
 
 SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap,
-                                 const int32_t *query, int64_t m, int32_t *rows, sgnn_stream_t stream) {
+                                 const int32_t *query, int64_t m, int32_t *rows, const int64_t *m_dev,
+                                 sgnn_stream_t stream) {
   SGNN_CHECK_ARG(m >= 0 && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(query && rows);
   hipLaunchKernelGGL(k_hash_lookup, dim3(sgnn_grid_for(m, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     keys, vals, (uint64_t)(cap - 1), (const int4 *)query, m, rows);
+                     keys, vals, (uint64_t)(cap - 1), (const int4 *)query, m, rows, m_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -160,7 +167,8 @@ SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int6
 __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restrict__ keys,
                                                        const int32_t *__restrict__ vals, uint64_t mask,
                                                        const int4 *__restrict__ coords, int64_t n,
-                                                       int32_t *__restrict__ nbr, int64_t ld) {
+                                                       int32_t *__restrict__ nbr, int64_t ld, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= ld) return;
   if (j >= n) {  // padding entries: the conv kernels rely on them being -1 (rows 14..26 come from the memset)
@@ -221,7 +229,9 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
 __global__ __launch_bounds__(256) void k_rulebook_subm3_lds(const uint64_t *__restrict__ keys,
                                                            const int32_t *__restrict__ vals, uint64_t mask,
                                                            const int4 *__restrict__ coords, int64_t n,
-                                                           int32_t *__restrict__ nbr, int64_t ld) {
+                                                           int32_t *__restrict__ nbr, int64_t ld,
+                                                           const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   __shared__ unsigned long long lk[RB_LDS_SLOTS];
   __shared__ int32_t lv[RB_LDS_SLOTS];
   const int tid = threadIdx.x;
@@ -447,7 +457,8 @@ __device__ __forceinline__ bool vol_covers(const VolDims d, int z, int y, int x,
 }
 
 __global__ __launch_bounds__(256) void k_vol_mark(const int4 *__restrict__ coords, int64_t n, int32_t *__restrict__ vol,
-                                                 VolDims d, int clear) {
+                                                 VolDims d, int clear, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int4 c = coords[j];
@@ -458,7 +469,9 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__re
                                                            const int32_t *__restrict__ vals, uint64_t mask,
                                                            const int4 *__restrict__ coords, int64_t n,
                                                            const int32_t *__restrict__ vol, VolDims d,
-                                                           int32_t *__restrict__ nbr, int64_t ld) {
+                                                           int32_t *__restrict__ nbr, int64_t ld,
+                                                           const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= ld) return;
   if (j >= n) {                                 // padding entries: the conv kernels rely on them being -1
@@ -510,7 +523,8 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__re
 
 SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords,
                                           int64_t n, int dim_z, int dim_y, int dim_x, int32_t *volume,
-                                          int64_t volume_entries, int32_t *nbr, int64_t ld, sgnn_stream_t stream) {
+                                          int64_t volume_entries, int32_t *nbr, int64_t ld, const int64_t *n_dev,
+                                          sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   SGNN_CHECK_ARG(dim_z >= 1 && dim_y >= 1 && dim_x >= 1 && dim_z <= 65536 && dim_y <= 65536 && dim_x <= 65536 &&
                  volume_entries >= 0 && (volume || volume_entries == 0));
@@ -521,10 +535,10 @@ SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *v
   const VolDims d{dim_z, dim_y, dim_x, (int)(bcap > 65536 ? 65536 : bcap)};
   hipStream_t s = (hipStream_t)stream;
   const unsigned gn = (unsigned)((n + 255) / 256);
-  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0);
+  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev);
   hipLaunchKernelGGL(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, keys, vals,
-                     (uint64_t)(cap - 1), (const int4 *)coords, n, volume, d, nbr, ld);
-  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1);
+                     (uint64_t)(cap - 1), (const int4 *)coords, n, volume, d, nbr, ld, n_dev);
+  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -538,19 +552,19 @@ SGNN_EXPORT int sgnn_rulebook_set_lds(int on) {
 
 SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                                     const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
-                                    sgnn_stream_t stream) {
+                                    const int64_t *n_dev, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && nbr);
   if (g_rulebook_lds) {
     hipLaunchKernelGGL(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
-                       vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld);
+                       vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
   }
   SGNN_HIP_TRY(hipMemsetAsync(nbr + 14 * ld, 0xFF, (size_t)(13 * ld) * sizeof(int32_t), (hipStream_t)stream));
   hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld);
+                     keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -593,7 +607,9 @@ struct FlagOwner {  // fine site i owns its parent iff it is the smallest row th
 };
 
 template <class F>
-__global__ __launch_bounds__(256) void k_scan_count(F flag, int64_t n, int32_t *__restrict__ block_sums) {
+__global__ __launch_bounds__(256) void k_scan_count(F flag, int64_t n, int32_t *__restrict__ block_sums,
+                                                   const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   __shared__ int lds[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
   int cnt = 0;
@@ -608,9 +624,19 @@ __global__ __launch_bounds__(256) void k_scan_count(F flag, int64_t n, int32_t *
   if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-// single workgroup: exclusive scan of block_sums in place, total -> *count
+// single workgroup: exclusive scan of block_sums in place, total -> *count.  Capacity mode (lim.cap >= 0): the
+// count is clamped to the capacity of the buffers that will hold the selected rows (SGNN_STATUS_OVERFLOW is raised
+// when it had to be), and lim.mul > 0 also publishes count * mul (rows of the 8-child expansion) at lim.count_mul.
+struct ScanLimit {
+  int64_t cap;
+  int64_t *count_mul;
+  int mul;
+  int32_t *status;
+};
+static const ScanLimit kNoLimit{-1, nullptr, 0, nullptr};
+
 __global__ __launch_bounds__(1024) void k_scan_block_sums(int32_t *__restrict__ block_sums, int64_t nblk,
-                                                         int64_t *__restrict__ count) {
+                                                         int64_t *__restrict__ count, ScanLimit lim) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -638,12 +664,21 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(int32_t *__restrict__ 
     if (threadIdx.x == 0) carry_s = carry + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *count = (int64_t)carry_s;
+  if (threadIdx.x == 0) {
+    int64_t c = (int64_t)carry_s;
+    if (lim.cap >= 0 && c > lim.cap) {
+      c = lim.cap;
+      if (lim.status) atomicOr(lim.status, SGNN_STATUS_OVERFLOW);
+    }
+    *count = c;
+    if (lim.count_mul) *lim.count_mul = c * lim.mul;
+  }
 }
 
 template <class F, class Emit>
 __global__ __launch_bounds__(256) void k_scan_emit(F flag, Emit emit, int64_t n,
-                                                  const int32_t *__restrict__ block_offsets) {
+                                                  const int32_t *__restrict__ block_offsets, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   __shared__ int lds[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
   int running = block_offsets[blockIdx.x];
@@ -670,7 +705,7 @@ SGNN_EXPORT int64_t sgnn_compact_ws_bytes(int64_t n) {
 
 template <class F>
 static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes,
-                        hipStream_t s) {
+                        hipStream_t s, const int64_t *n_dev = nullptr, const ScanLimit &lim = kNoLimit) {
   if (n == 0) {
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), s);
     if (e != hipSuccess) {
@@ -686,10 +721,10 @@ static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *w
   }
   const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   int32_t *block_sums = (int32_t *)ws;
-  hipLaunchKernelGGL((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count);
+  hipLaunchKernelGGL((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums, n_dev);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count, lim);
   hipLaunchKernelGGL((k_scan_emit<F, EmitSel>), dim3((unsigned)nblk), dim3(256), 0, s, flag, EmitSel{sel}, n,
-                     (const int32_t *)block_sums);
+                     (const int32_t *)block_sums, n_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     sgnn_set_error("compact: HIP error: %s", hipGetErrorString(e));
@@ -703,6 +738,30 @@ SGNN_EXPORT int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_
   SGNN_CHECK_ARG(n >= 0 && count && stride >= 1 && n < (1ll << 31));
   SGNN_CHECK_ARG(n == 0 || (logits && sel));
   return compact_impl(FlagSigmoid{logits, stride}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Capacity mode of the two generative mask compactions: the candidate count comes from device memory (*n_dev, NULL =
+// n), the kept count is clamped to keep_cap (SGNN_STATUS_OVERFLOW in *status otherwise) and count[1] = 8 * count[0] is
+// published for the 8-child expansion of the kept sites — everything a following stage needs without a host round trip.
+SGNN_EXPORT int sgnn_compact_sigmoid_cap(const float *logits, int64_t stride, int64_t n, const int64_t *n_dev,
+                                         int32_t *sel, int64_t *count2, int64_t keep_cap, int32_t *status, void *ws,
+                                         int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count2 && stride >= 1 && n < (1ll << 31) && keep_cap >= 0 && status);
+  SGNN_CHECK_ARG(n == 0 || (logits && sel));
+  if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
+  return compact_impl(FlagSigmoid{logits, stride}, n, sel, count2, ws, ws_bytes, (hipStream_t)stream, n_dev,
+                      ScanLimit{keep_cap, count2 + 1, 8, status});
+}
+
+SGNN_EXPORT int sgnn_compact_dense_cap(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol, int batch,
+                                       int d0, int d1, int d2, int32_t *sel, int64_t *count2, int64_t keep_cap,
+                                       int32_t *status, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count2 && n < (1ll << 31) && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0 && keep_cap >= 0 &&
+                 status);
+  SGNN_CHECK_ARG(n == 0 || (coords && vol && sel));
+  if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
+  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, n, sel, count2, ws, ws_bytes,
+                      (hipStream_t)stream, n_dev, ScanLimit{keep_cap, count2 + 1, 8, status});
 }
 
 // keep site i iff vol[b, z, y, x] > 0.5 at coords[i] = {z, y, x, b}: the generative masks taken from the TARGET
@@ -827,11 +886,12 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
   hipLaunchKernelGGL(k_down2_insert, dim3(g), dim3(256), 0, s, (const int4 *)fine_coords, nf,
                      (unsigned long long *)ckeys, cvals, (uint64_t)(ccap - 1), slot_of);
   FlagOwner flag{slot_of, cvals};
-  hipLaunchKernelGGL((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse);
+  hipLaunchKernelGGL((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums,
+                     (const int64_t *)nullptr);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse, kNoLimit);
   hipLaunchKernelGGL((k_scan_emit<FlagOwner, EmitOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag,
                      EmitOwner{(const int4 *)fine_coords, (int4 *)coarse_coords, rank_at}, nf,
-                     (const int32_t *)block_sums);
+                     (const int32_t *)block_sums, (const int64_t *)nullptr);
   hipLaunchKernelGGL(k_down2_parent, dim3(g), dim3(256), 0, s, nf, (const int32_t *)cvals,
                      (const int32_t *)rank_at, (const int32_t *)slot_of, parent);
   hipLaunchKernelGGL(k_down2_fix_vals, dim3(g), dim3(256), 0, s, nf, (const int32_t *)slot_of,
@@ -845,7 +905,7 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
 // count from device memory (the count the previous level / a mask compaction just wrote) and is launched for the
 // host-known upper bound `cap`.  One read-back then returns all counts (15 -> 5 host syncs per training step).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int64_t dev_n(const int64_t *n_dev, int64_t n_host) { return n_dev ? *n_dev : n_host; }
+__device__ __forceinline__ int64_t dev_n(const int64_t *n_dev, int64_t n_host) { return sgnn_dyn_n(n_host, n_dev); }
 
 __global__ __launch_bounds__(256) void k_chain_init(unsigned long long *__restrict__ ckeys, int32_t *__restrict__ owner,
                                                    int64_t ccap, int32_t *__restrict__ rank_at, int64_t cap) {
@@ -949,9 +1009,10 @@ SGNN_EXPORT int64_t sgnn_down2_chain_ws_bytes(int64_t cap) {
 
 SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_dev, int64_t cap, int depth,
                                  void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
-                                 void *const *coarse_coords, int64_t *counts_dev, void *ws, int64_t ws_bytes,
-                                 sgnn_stream_t stream) {
+                                 void *const *coarse_coords, int64_t *counts_dev, const int64_t *level_caps,
+                                 int32_t *status, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(!level_caps || status);
   SGNN_CHECK_ARG(depth >= 1 && depth <= 8 && cap >= 0 && n0 >= 0 && n0 <= cap && counts_dev && ckeys && cvals && parent &&
                  coarse_coords);
   SGNN_CHECK_ARG(ccap >= 2 * cap && ccap >= 2 && (ccap & (ccap - 1)) == 0 && ccap < (1ll << 31));
@@ -982,7 +1043,8 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
                        owner, (uint64_t)(ccap - 1), slot_of);
     hipLaunchKernelGGL(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
+                       level_caps ? ScanLimit{level_caps[l] < cap ? level_caps[l] : cap, nullptr, 0, status} : kNoLimit);
     hipLaunchKernelGGL(k_chain_emit, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
                        rank_at);
@@ -999,7 +1061,10 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
 __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ fine,
                                                      const int32_t *__restrict__ parent, int64_t nf,
                                                      int32_t *__restrict__ children, int64_t ldc,
-                                                     int32_t *__restrict__ ptable, int64_t ldf) {
+                                                     int32_t *__restrict__ ptable, int64_t ldf, int64_t nc,
+                                                     const int64_t *nf_dev, const int64_t *nc_dev) {
+  nf = sgnn_dyn_n(nf, nf_dev);
+  nc = sgnn_dyn_n(nc, nc_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < ldf; i += stride) {
@@ -1010,8 +1075,9 @@ __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ f
     }
     const int4 c = fine[i];
     const int off = ((c.x & 1) << 2) | ((c.y & 1) << 1) | (c.z & 1);
-    const int32_t p = parent[i];
-    children[(int64_t)off * ldc + p] = (int32_t)i;
+    int32_t p = parent[i];
+    if (p >= nc) p = -1;       // only after a capacity overflow (the step is flagged and discarded): stay in bounds
+    if (p >= 0) children[(int64_t)off * ldc + p] = (int32_t)i;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = (k == off) ? p : -1;
   }
@@ -1019,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ f
 
 SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *parent, int64_t nf,
                                   int32_t *children, int64_t ldc, int64_t nc, int32_t *ptable, int64_t ldf,
-                                  sgnn_stream_t stream) {
+                                  const int64_t *nf_dev, const int64_t *nc_dev, sgnn_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(nf >= 0 && nc >= 0 && ldc >= nc && ldf >= nf);
   if (nc > 0) {
@@ -1029,7 +1095,7 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
   if (nf == 0) return SGNN_OK;
   SGNN_CHECK_ARG(fine_coords && parent && ptable && children);
   hipLaunchKernelGGL(k_down2_tables, dim3(sgnn_grid_for(ldf, 256, 8192)), dim3(256), 0, s,
-                     (const int4 *)fine_coords, parent, nf, children, ldc, ptable, ldf);
+                     (const int4 *)fine_coords, parent, nf, children, ldc, ptable, ldf, nc, nf_dev, nc_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -1038,7 +1104,8 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
 // generative glue: 8-child expansion, dense coordinate table
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_expand8(const int4 *__restrict__ coords, int64_t n,
-                                                int4 *__restrict__ out) {
+                                                int4 *__restrict__ out, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per child
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; t < 8 * n; t += stride) {
@@ -1048,12 +1115,13 @@ __global__ __launch_bounds__(256) void k_expand8(const int4 *__restrict__ coords
   }
 }
 
-SGNN_EXPORT int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, sgnn_stream_t stream) {
+SGNN_EXPORT int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, const int64_t *n_dev,
+                                    sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && out);
   hipLaunchKernelGGL(k_expand8, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     (const int4 *)coords, n, (int4 *)out);
+                     (const int4 *)coords, n, (int4 *)out, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -37,8 +37,9 @@ struct LinG {
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x, int64_t n, LinW p,
-                                                   float *__restrict__ y) {
+                                                   float *__restrict__ y, const int64_t *n_dev) {
   __shared__ float ws[COUT * CIN + COUT];
+  n = sgnn_dyn_n(n, n_dev);
   for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = p.w[e / CIN][e % CIN];
   if (threadIdx.x < COUT) ws[COUT * CIN + threadIdx.x] = p.b[threadIdx.x] ? p.b[threadIdx.x][0] : 0.f;
   __syncthreads();
@@ -60,8 +61,9 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_linear_bwd(const float *__restrict__ x, const float *__restrict__ dy,
                                                    int64_t n, LinW p, float *__restrict__ dx,
-                                                   double *__restrict__ partial) {
+                                                   double *__restrict__ partial, const int64_t *n_dev) {
   constexpr int NV = COUT * CIN + COUT;
+  n = sgnn_dyn_n(n, n_dev);
   __shared__ float ws[COUT * CIN];
   __shared__ float red[4][NV];
   for (int e = threadIdx.x; e < COUT * CIN; e += 256) ws[e] = p.w[e / CIN][e % CIN];
@@ -150,7 +152,7 @@ SGNN_EXPORT int64_t sgnn_linear_ws_bytes(int64_t n, int cin, int cout) {
 #define LIN_CASES(X) X(16, 1) X(16, 2) X(48, 1) X(48, 2) X(8, 1) X(8, 2) X(32, 1) X(32, 2) X(12, 2) X(4, 1)
 
 int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,
-                         float *y, sgnn_stream_t stream) {
+                         float *y, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1 && cout <= LIN_MAX_OUT);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(x && w && y);
@@ -165,7 +167,7 @@ int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const 
   bool done = false;
 #define X(CI, CO)                                                                                   \
   if (!done && cin == CI && cout == CO) {                                                           \
-    hipLaunchKernelGGL((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, p, y);            \
+    hipLaunchKernelGGL((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, p, y, n_dev);     \
     done = true;                                                                                    \
   }
   LIN_CASES(X)
@@ -191,7 +193,7 @@ SGNN_EXPORT int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float 
 
 int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
                          float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
-                         sgnn_stream_t stream) {
+                         sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1 && cout <= LIN_MAX_OUT && w);
   if (n == 0) {
@@ -219,7 +221,7 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
   bool done = false;
 #define X(CI, CO)                                                                                          \
   if (!done && cin == CI && cout == CO) {                                                                  \
-    hipLaunchKernelGGL((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws); \
+    hipLaunchKernelGGL((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws, n_dev); \
     done = true;                                                                                           \
   }
   LIN_CASES(X)

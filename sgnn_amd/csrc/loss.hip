@@ -21,6 +21,7 @@ struct LossArgs {
   const uint8_t *known;   // dense u8 (final level mask) or NULL
   int d0, d1, d2;
   int64_t m;
+  const int64_t *m_dev;   // capacity mode: the live row count (clamped to m), NULL = m is exact
   int use_log;            // loss.py:139-141 log transform
   int mask_mode;          // 0: keep all (unknown occupancy targets count as 0), 1: keep tgt_occ != UNK_ID, 2: keep known < 2
 };
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void k_loss_partial(LossArgs a, double *__rest
   __shared__ double sh[3][256];
   double s_b = 0.0, s_l = 0.0, s_n = 0.0;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < a.m; r += stride) {
+  const int64_t m = sgnn_dyn_n(a.m, a.m_dev);
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += stride) {
     float bce, l1, db, dl;
     if (loss_site(a, r, bce, l1, db, dl)) {
       s_b += (double)bce;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void k_loss_partial(LossArgs a, double *__rest
 
 // sums[0..2] = {sum bce, sum l1, kept count}; out2 = {bce mean, l1 mean} (0/0 = nan like an empty mean)
 __global__ __launch_bounds__(256) void k_loss_finalize(const double *__restrict__ partial, int nblk,
-                                                      double *__restrict__ sums, float *__restrict__ out2) {
+                                                      double *__restrict__ sums, float *__restrict__ out2,
+                                                      const int64_t *m_dev) {
   __shared__ double sh[3][256];
   double s[3] = {0.0, 0.0, 0.0};
   for (int b = threadIdx.x; b < nblk; b += 256)
@@ -100,8 +103,10 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const double *__restrict_
     sums[0] = sh[0][0];
     sums[1] = sh[1][0];
     sums[2] = sh[2][0];
-    out2[0] = (float)(sh[0][0] / sh[2][0]);
-    out2[1] = (float)(sh[1][0] / sh[2][0]);
+    // capacity mode with no predicted site at all: the reference skips the level (torch/loss.py:166, len(...) == 0)
+    const bool empty = m_dev && *m_dev <= 0;
+    out2[0] = empty ? 0.f : (float)(sh[0][0] / sh[2][0]);
+    out2[1] = empty ? 0.f : (float)(sh[1][0] / sh[2][0]);
   }
 }
 
@@ -111,7 +116,8 @@ __global__ __launch_bounds__(256) void k_loss_bwd(LossArgs a, const double *__re
   const double kept = sums[2];
   const float g0 = (float)((double)gout2[0] / kept), g1 = (float)((double)gout2[1] / kept);
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < a.m; r += stride) {
+  const int64_t m = sgnn_dyn_n(a.m, a.m_dev);
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += stride) {
     float bce, l1, db, dl;
     const bool keep = loss_site(a, r, bce, l1, db, dl);
     for (int c = 0; c < a.vstride; ++c) {
@@ -134,7 +140,7 @@ SGNN_EXPORT int64_t sgnn_loss_ws_bytes(void) { return (int64_t)LOSS_MAX_BLOCKS *
 
 static int fill_args(LossArgs &a, const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
                      const float *tgt_occ, const float *tgt_sdf, const float *weights, const uint8_t *known, int d0,
-                     int d1, int d2, int64_t m, int use_log, int mask_mode) {
+                     int d1, int d2, int64_t m, int use_log, int mask_mode, const int64_t *m_dev) {
   if (!(m >= 0 && vstride >= 1 && occ_col < vstride && sdf_col < vstride && (occ_col >= 0 || sdf_col >= 0))) return -1;
   if (m > 0 && (!locs || !vals)) return -1;
   if (occ_col >= 0 && !tgt_occ) return -1;
@@ -142,18 +148,18 @@ static int fill_args(LossArgs &a, const int64_t *locs, const float *vals, int vs
   if (mask_mode == 1 && !tgt_occ) return -1;
   if (mask_mode == 2 && !known) return -1;
   if (mask_mode < 0 || mask_mode > 2) return -1;
-  a = LossArgs{locs, vals, vstride, occ_col, sdf_col, tgt_occ, tgt_sdf, weights, known, d0, d1, d2, m, use_log, mask_mode};
+  a = LossArgs{locs, vals, vstride, occ_col, sdf_col, tgt_occ, tgt_sdf, weights, known, d0, d1, d2, m, m_dev, use_log, mask_mode};
   return 0;
 }
 
 SGNN_EXPORT int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
                                     const float *tgt_occ, const float *tgt_sdf, const float *weights,
                                     const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
-                                    int mask_mode, double *sums, float *out2, void *ws, int64_t ws_bytes,
-                                    sgnn_stream_t stream) {
+                                    int mask_mode, const int64_t *m_dev, double *sums, float *out2, void *ws,
+                                    int64_t ws_bytes, sgnn_stream_t stream) {
   LossArgs a;
   SGNN_CHECK_ARG(fill_args(a, locs, vals, vstride, occ_col, sdf_col, tgt_occ, tgt_sdf, weights, known, d0, d1, d2, m,
-                           use_log, mask_mode) == 0);
+                           use_log, mask_mode, m_dev) == 0);
   SGNN_CHECK_ARG(sums && out2);
   if (!ws || ws_bytes < sgnn_loss_ws_bytes()) {
     sgnn_set_error("sgnn_loss_level_fwd: workspace too small");
@@ -162,7 +168,7 @@ SGNN_EXPORT int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int 
   hipStream_t s = (hipStream_t)stream;
   const int nblk = loss_blocks(m);
   hipLaunchKernelGGL(k_loss_partial, dim3(nblk), dim3(256), 0, s, a, (double *)ws);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, sums, out2);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, sums, out2, m_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -170,11 +176,11 @@ SGNN_EXPORT int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int 
 SGNN_EXPORT int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int vstride, int occ_col, int sdf_col,
                                     const float *tgt_occ, const float *tgt_sdf, const float *weights,
                                     const uint8_t *known, int d0, int d1, int d2, int64_t m, int use_log,
-                                    int mask_mode, const double *sums, const float *gout2, float *dvals,
-                                    sgnn_stream_t stream) {
+                                    int mask_mode, const int64_t *m_dev, const double *sums, const float *gout2,
+                                    float *dvals, sgnn_stream_t stream) {
   LossArgs a;
   SGNN_CHECK_ARG(fill_args(a, locs, vals, vstride, occ_col, sdf_col, tgt_occ, tgt_sdf, weights, known, d0, d1, d2, m,
-                           use_log, mask_mode) == 0);
+                           use_log, mask_mode, m_dev) == 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(sums && gout2 && dvals);
   hipLaunchKernelGGL(k_loss_bwd, dim3(sgnn_grid_for(m, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, sums, gout2,
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(256) void k_targets_fine(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_targets_sites(const int64_t *__restrict__ locs, int64_t n, int batch, int d0,
-                                                      int d1, int d2, float *__restrict__ w) {
+                                                      int d1, int d2, float *__restrict__ w, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
     const longlong2 p0 = reinterpret_cast<const longlong2 *>(locs)[2 * r];
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256) void k_targets_coarse(CoarseArgs a) {
 // device pointers, ncoarse = L - 1 <= 3); w_last NULL (and w entries NULL) switches the weights off.  Every dimension
 // must be divisible by 2^ncoarse (MaxPool3d(2) floors otherwise; the caller falls back to tensor ops then).
 SGNN_EXPORT int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *input_locs, int64_t n_locs,
-                                  int batch, int d0, int d1, int d2, float trunc, int masking, float weight_missing_geo,
+                                  const int64_t *n_locs_dev, int batch, int d0, int d1, int d2, float trunc, int masking, float weight_missing_geo,
                                   int ncoarse, void *const *hier_in, float *tsdf, float *hier_last, float *occ_last,
                                   float *w_last, void *const *occ, void *const *w, void *const *hier,
                                   sgnn_stream_t stream) {
@@ -306,7 +313,7 @@ SGNN_EXPORT int sgnn_loss_targets(const float *sdf, const uint8_t *known, const 
                      masking, weight_missing_geo, tsdf, hier_last, occ_last, w_last);
   if (w_last && n_locs > 0)
     hipLaunchKernelGGL(k_targets_sites, dim3(sgnn_grid_for(n_locs, 256, 4096)), dim3(256), 0, s, input_locs, n_locs,
-                       batch, d0, d1, d2, w_last);
+                       batch, d0, d1, d2, w_last, n_locs_dev);
   if (ncoarse > 0) {
     CoarseArgs a{};
     a.occ_f = occ_last;

@@ -316,8 +316,8 @@ SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const 
 SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                  void *const *lev_tile, int nlev, void *const *params, int nparams, void *const *ext,
-                                  void *const *idx,
+                                  void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, int nparams,
+                                  void *const *ext, void *const *idx,
                                   int nidx, float *arena, int64_t arena_floats, const int32_t *keep, int training,
                                   void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1 &&
@@ -342,6 +342,8 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
   auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
+  // capacity mode: device row count of a rows class (NULL: lev_n is exact)
+  auto CNT = [&](int cls) -> const int64_t * { return (lev_cnt && cls >= 0 && cls < nlev) ? (const int64_t *)lev_cnt[cls] : nullptr; };
   // Epilogue fusions (same arithmetic, fewer passes and launches; planned by make_plan):
   //  * conv -> AddTable: the convolution adds the other AddTable input while it stores (the sum buffer is written
   //    directly, the convolution's own output buffer stays untouched) when nothing else reads the convolution output;
@@ -387,34 +389,35 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         }
         epi.ldx = LD(in0);
         epi.ldy = LD(dst_buf);
+        epi.n_dev = CNT(down ? lev + 1 : lev);
         PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
                                     nullptr, 1, 1, down ? 8 : 27, &epi, stream));
         break;
       }
       case OP_UNPOOL:  // in0 lives on level lev+1, out on level lev
         SGNN_CHECK_ARG(lev + 1 < nlev);
-        PROG_TRY(sgnn_gather_rows_ld(B(in0), LD(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), LD(out), stream));
+        PROG_TRY(sgnn_gather_rows_ld(B(in0), LD(in0), cin, (const int32_t *)lev_parent[lev], n, B(out), LD(out), stream, CNT(lev)));
         break;
       case OP_BN: {
         float *save = arena + L.aux_off[i];
         PROG_TRY(sgnn_bn_fwd_impl(B(in0), LD(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
                                   opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), LD(out), pre[i],
-                                  pre_nblk[i], ws, ws_bytes, stream));
+                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev)));
         break;
       }
       case OP_ADD:
         SGNN_CHECK_ARG(in1 >= 0);
-        PROG_TRY(sgnn_add_ld(B(in0), LD(in0), B(in1), LD(in1), n, cin, B(out), LD(out), stream));
+        PROG_TRY(sgnn_add_ld(B(in0), LD(in0), B(in1), LD(in1), n, cin, B(out), LD(out), stream, CNT(lev)));
         break;
       case OP_JOIN:  // cin = channels of in0, cout = channels of in1
         SGNN_CHECK_ARG(in1 >= 0 && LD(in0) == cin && LD(in1) == cout && LD(out) == cin + cout);
-        PROG_TRY(sgnn_concat_rows(B(in0), cin, nullptr, B(in1), cout, nullptr, n, B(out), stream));
+        PROG_TRY(sgnn_concat_rows_dn(B(in0), cin, nullptr, B(in1), cout, nullptr, n, B(out), stream, CNT(lev)));
         break;
       case OP_CONCAT_IN: {
         const int in2 = o[8];
         SGNN_CHECK_ARG(in2 < nbuf && CH(in0) + CH(in1) + CH(in2) == CH(out) && LD(out) == CH(out));
-        PROG_TRY(sgnn_concat3_rows(B(in0), CH(in0), I(o[9]), B(in1), CH(in1), I(o[10]), B(in2), CH(in2), I(o[11]), n,
-                                   B(out), stream));
+        PROG_TRY(sgnn_concat3_rows_dn(B(in0), CH(in0), I(o[9]), B(in1), CH(in1), I(o[10]), B(in2), CH(in2), I(o[11]), n,
+                                      B(out), stream, CNT(lev)));
         break;
       }
       case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
@@ -423,8 +426,10 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         float *wc = arena + L.aux_off[i];
         PROG_TRY(sgnn_expand_weights(P(par), cin, cout, wc, stream));
+        ConvEpi xepi{};
+        xepi.n_dev = CNT(lev);
         PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
-                                    0, S, nullptr, 1, 8, 27, nullptr, stream));
+                                    0, S, nullptr, 1, 8, 27, &xepi, stream));
         break;
       }
       case OP_LINEAR: {
@@ -434,7 +439,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
           w[q] = P(par + 2 * q);
           b[q] = P(par + 2 * q + 1);
         }
-        PROG_TRY(sgnn_linear_fwd_rows(B(in0), n, cin, w, b, cout, B(out), stream));
+        PROG_TRY(sgnn_linear_fwd_rows(B(in0), n, cin, w, b, cout, B(out), stream, CNT(lev)));
         break;
       }
       default:
@@ -451,7 +456,8 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
 SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                    const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                    void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                   void *const *lev_tile, int nlev, void *const *params, void *const *pgrads, int nparams,
+                                   void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params,
+                                   void *const *pgrads, int nparams,
                                    void *const *ext, void *const *gext, void *const *idx, int nidx,
                                    const float *arena, float *garena, int64_t arena_floats, void *const *gout,
                                    const int32_t *keep, int training, void *ws, int64_t ws_bytes,
@@ -483,6 +489,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
   auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
   auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
+  auto CNT = [&](int cls) -> const int64_t * { return (lev_cnt && cls >= 0 && cls < nlev) ? (const int64_t *)lev_cnt[cls] : nullptr; };
+  auto BCNT = [&](int b) -> const int64_t * { return CNT(bufs[2 * b]); };     // device row count of buffer b's rows class
   for (int b = n_ext; b < nbuf; ++b)
     if (gout[b]) {
       if (L.buf_floats[b] > 0)
@@ -499,12 +507,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         const int a = alias[b];
         alias[b] = -1;
         init[b] = 1;
-        return sgnn_add_ld(G(b), LD(b), G(a), LD(a), ROWS(b), CH(b), G(b), LD(b), stream);
+        return sgnn_add_ld(G(b), LD(b), G(a), LD(a), ROWS(b), CH(b), G(b), LD(b), stream, BCNT(b));
       }
       init[b] = 1;
       return SGNN_OK;
     }
-    return sgnn_add_ld(G(b), LD(b), wrote, CH(b), ROWS(b), CH(b), G(b), LD(b), stream);
+    return sgnn_add_ld(G(b), LD(b), wrote, CH(b), ROWS(b), CH(b), G(b), LD(b), stream, BCNT(b));
   };
   auto wants = [&](int b) { return b >= n_ext || gext[b] != nullptr; };
   // dW launches go to the side lane when one is configured and its workspace is big enough
@@ -593,6 +601,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             }
             epi.ldx = ld_dy;
             epi.ldy = LD(in0);
+            epi.n_dev = CNT(lev);
             PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
                                         nullptr, 1, 1, K, &epi, stream));
             init[in0] = 1;
@@ -600,13 +609,16 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           } else {
             SGNN_CHECK_ARG(ld_dy == cout);               // views are only planned around compiled shapes
             float *t = target(in0, 0);
-            PROG_TRY(sgnn_conv_fwd(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, t, flags_b, 0, stream));
+            ConvEpi pepi{};
+            pepi.n_dev = CNT(lev);
+            PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, t, flags_b, 0, nullptr, nullptr,
+                                        1, 1, K, &pepi, stream));
             PROG_TRY(commit(in0, t));
           }
         }
         PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, LD(in0), dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
                                            nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
-                                           (sgnn_stream_t)lane));
+                                           (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev)));
         dw_off += dw_slice(v, i);
         break;
       }
@@ -614,7 +626,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         if (wants(in0)) {
           float *t = target(in0, 0);
           PROG_TRY(sgnn_gather_sum_ld(dy, ld_dy, cin, (const int32_t *)lev_children[lev], lev_ld[lev + 1], 8, lev_n[lev + 1],
-                                      t, TLD(in0, t), stream));
+                                      t, TLD(in0, t), stream, CNT(lev + 1)));
           PROG_TRY(commit(in0, t));
         }
         break;
@@ -633,7 +645,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         float *t = wants(in0) ? G(in0) : scratch[0];
         PROG_TRY(sgnn_bn_bwd_impl(X(in0), LD(in0), dy, ld_dy, n, cin, P(par), P(par + 1), save, save + cin, training,
                                   opf[4 * i + 2], addend, ld_add, t, wants(in0) ? LD(in0) : cin, PG(par), PG(par + 1), pre[i],
-                                  pre_nblk[i], ws, ws_bytes, stream));
+                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev)));
         if (wants(in0)) {
           init[in0] = 1;
           alias[in0] = -1;
@@ -646,9 +658,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           const int b = side_ ? in1 : in0;
           if (!wants(b)) continue;
           if (init[b] == 1) {
-            PROG_TRY(sgnn_add_ld(G(b), LD(b), dy, ld_dy, n, cin, G(b), LD(b), stream));
+            PROG_TRY(sgnn_add_ld(G(b), LD(b), dy, ld_dy, n, cin, G(b), LD(b), stream, CNT(lev)));
           } else if (init[b] == 2) {                            // two aliased contributions: materialise the sum
-            PROG_TRY(sgnn_add_ld(G(alias[b]), LD(alias[b]), dy, ld_dy, n, cin, G(b), LD(b), stream));
+            PROG_TRY(sgnn_add_ld(G(alias[b]), LD(alias[b]), dy, ld_dy, n, cin, G(b), LD(b), stream, CNT(lev)));
             init[b] = 1;
             alias[b] = -1;
           } else {
@@ -670,7 +682,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         SGNN_CHECK_ARG(ld_dy == cin + cout && LD(in0) == cin && LD(in1) == cout);   // make_plan: a copying JoinTable never reads views
         float *ta = wants(in0) ? target(in0, 0) : nullptr;
         float *tb = wants(in1) ? target(in1, 1) : nullptr;
-        PROG_TRY(sgnn_concat_rows_bwd(dy, cin, nullptr, cout, nullptr, n, ta, n, tb, n, stream));
+        PROG_TRY(sgnn_concat_rows_bwd_dn(dy, cin, nullptr, cout, nullptr, n, ta, n, tb, n, stream, CNT(lev)));
         if (ta) PROG_TRY(commit(in0, ta));
         if (tb) PROG_TRY(commit(in1, tb));
         break;
@@ -688,9 +700,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             init[src[q]] = 1;
           }
         SGNN_CHECK_ARG(ld_dy == CH(out));
-        PROG_TRY(sgnn_concat3_rows_bwd(dy, CH(in0), I(o[9]), CH(in1), I(o[10]), CH(o[8]), I(o[11]), n, d[0],
-                                       in0 >= 0 ? ROWS(in0) : 0, d[1], in1 >= 0 ? ROWS(in1) : 0, d[2],
-                                       o[8] >= 0 ? ROWS(o[8]) : 0, stream));
+        PROG_TRY(sgnn_concat3_rows_bwd_dn(dy, CH(in0), I(o[9]), CH(in1), I(o[10]), CH(o[8]), I(o[11]), n, d[0],
+                                          in0 >= 0 ? ROWS(in0) : 0, d[1], in1 >= 0 ? ROWS(in1) : 0, d[2],
+                                          o[8] >= 0 ? ROWS(o[8]) : 0, stream, CNT(lev)));
         break;
       }
       case OP_EXPAND: {
@@ -705,14 +717,16 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         if (wants(in0) && n > 0) {
           // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
           const int Gs = EXPAND_DX_SPLIT;
+          ConvEpi xepi{};
+          xepi.n_dev = CNT(lev);
           PROG_TRY(sgnn_conv_fwd_impl(dy, 8 * n, cout, wc, 64 / Gs, nbr, lev_ld[lev], n, cin, part, SGNN_CONV_TRANSPOSE_W,
-                                      0, ST, PAR, 8, Gs, 27, nullptr, stream));
+                                      0, ST, PAR, 8, Gs, 27, &xepi, stream));
           float *t = target(in0, 0);
-          PROG_TRY(sgnn_sum_groups(part, cin, n, Gs, t, stream));
+          PROG_TRY(sgnn_sum_groups_dn(part, cin, n, Gs, t, stream, CNT(lev)));
           PROG_TRY(commit(in0, t));
         }
-        PROG_TRY(sgnn_conv_bwd_weight_ex(X(in0), n, cin, dy, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1, 8, 27,
-                                         dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane));
+        PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, cin, dy, cout, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1,
+                                           8, 27, dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane, CNT(lev)));
         dw_off += dw_slice(v, i);
         pending_expand.push_back(PendingExpand{dwc, cin, cout, PG(par)});   // dwc is final after the batched reduce
         break;
@@ -727,7 +741,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         }
         SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
         float *t = wants(in0) ? target(in0, 0) : nullptr;
-        PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, t, dw, db, ws, ws_bytes, stream));
+        PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, t, dw, db, ws, ws_bytes, stream, CNT(lev)));
         if (t) PROG_TRY(commit(in0, t));
         break;
       }

@@ -68,8 +68,9 @@ SGNN_EXPORT int sgnn_gather_rows(const float *src, int c, const int32_t *idx, in
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows_ld(const float *__restrict__ src, int64_t ld_src, int cq,
                                                        const int32_t *__restrict__ idx, int64_t m,
-                                                       float *__restrict__ dst, int64_t ld_dst) {
+                                                       float *__restrict__ dst, int64_t ld_dst, const int64_t *n_dev) {
   typedef typename VecT<VEC>::T T;
+  m = sgnn_dyn_n(m, n_dev);
   const int64_t total = m * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
@@ -83,8 +84,10 @@ __global__ __launch_bounds__(256) void k_gather_rows_ld(const float *__restrict_
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_sum_ld(const float *__restrict__ src, int64_t ld_src, int cq,
                                                       const int32_t *__restrict__ table, int64_t ld, int K,
-                                                      int64_t n_out, float *__restrict__ dst, int64_t ld_dst) {
+                                                      int64_t n_out, float *__restrict__ dst, int64_t ld_dst,
+                                                      const int64_t *n_dev) {
   typedef typename VecT<VEC>::T T;
+  n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t total = n_out * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
@@ -100,8 +103,10 @@ __global__ __launch_bounds__(256) void k_gather_sum_ld(const float *__restrict__
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_add_ld(const float *__restrict__ a, int64_t lda, const float *__restrict__ b,
-                                               int64_t ldb, int64_t n, int cq, float *y, int64_t ldy) {
+                                               int64_t ldb, int64_t n, int cq, float *y, int64_t ldy,
+                                               const int64_t *n_dev) {
   typedef typename VecT<VEC>::T T;
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t total = n * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
@@ -130,37 +135,37 @@ static inline bool ld_vec4(int c, std::initializer_list<int64_t> lds, std::initi
   } while (0)
 
 int sgnn_gather_rows_ld(const float *src, int64_t ld_src, int c, const int32_t *idx, int64_t m, float *dst,
-                        int64_t ld_dst, sgnn_stream_t stream) {
+                        int64_t ld_dst, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(c >= 1 && m >= 0 && ld_src >= c && ld_dst >= c);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && idx && dst);
   const bool v4 = ld_vec4(c, {ld_src, ld_dst}, {src, dst});
   const int cq = v4 ? c / 4 : c;
-  ROWS_LAUNCH_V(k_gather_rows_ld, v4, m * cq, stream, src, ld_src, cq, idx, m, dst, ld_dst);
+  ROWS_LAUNCH_V(k_gather_rows_ld, v4, m * cq, stream, src, ld_src, cq, idx, m, dst, ld_dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
 
 int sgnn_gather_sum_ld(const float *src, int64_t ld_src, int c, const int32_t *table, int64_t ld, int K, int64_t n_out,
-                       float *dst, int64_t ld_dst, sgnn_stream_t stream) {
+                       float *dst, int64_t ld_dst, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(c >= 1 && n_out >= 0 && K >= 1 && ld >= n_out && ld_src >= c && ld_dst >= c);
   if (n_out == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && table && dst);
   const bool v4 = ld_vec4(c, {ld_src, ld_dst}, {src, dst});
   const int cq = v4 ? c / 4 : c;
-  ROWS_LAUNCH_V(k_gather_sum_ld, v4, n_out * cq, stream, src, ld_src, cq, table, ld, K, n_out, dst, ld_dst);
+  ROWS_LAUNCH_V(k_gather_sum_ld, v4, n_out * cq, stream, src, ld_src, cq, table, ld, K, n_out, dst, ld_dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
 
 int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t n, int c, float *y, int64_t ldy,
-                sgnn_stream_t stream) {
+                sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(c >= 1 && n >= 0 && lda >= c && ldb >= c && ldy >= c);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(a && b && y);
   const bool v4 = ld_vec4(c, {lda, ldb, ldy}, {a, b, y});
   const int cq = v4 ? c / 4 : c;
-  ROWS_LAUNCH_V(k_add_ld, v4, n * cq, stream, a, lda, b, ldb, n, cq, y, ldy);
+  ROWS_LAUNCH_V(k_add_ld, v4, n * cq, stream, a, lda, b, ldb, n, cq, y, ldy, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -170,9 +175,9 @@ int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows_dn(const float *__restrict__ src, int cq,
                                                        const int32_t *__restrict__ idx, const int64_t *m_dev,
-                                                       float *__restrict__ dst) {
+                                                       int64_t m_cap, float *__restrict__ dst) {
   typedef typename VecT<VEC>::T T;
-  const int64_t total = *m_dev * cq, stride = (int64_t)gridDim.x * 256;
+  const int64_t total = sgnn_dyn_n(m_cap, m_dev) * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
     const int col = (int)(g - r * cq);
@@ -187,7 +192,7 @@ SGNN_EXPORT int sgnn_gather_rows_dn(const float *src, int c, const int32_t *idx,
   if (m_cap == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && idx && dst);
   const int cq = c / row_vec(c);
-  ROWS_LAUNCH(k_gather_rows_dn, c, m_cap * cq, stream, src, cq, idx, m_dev, dst);
+  ROWS_LAUNCH(k_gather_rows_dn, c, m_cap * cq, stream, src, cq, idx, m_dev, m_cap, dst);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -196,8 +201,9 @@ SGNN_EXPORT int sgnn_gather_rows_dn(const float *src, int c, const int32_t *idx,
 template <int VEC>
 __global__ __launch_bounds__(256) void k_scatter_rows(const float *__restrict__ src, int cq,
                                                      const int32_t *__restrict__ idx, int64_t m,
-                                                     float *__restrict__ dst) {
+                                                     float *__restrict__ dst, const int64_t *m_dev) {
   typedef typename VecT<VEC>::T T;
+  m = sgnn_dyn_n(m, m_dev);
   const int64_t total = m * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const float *__restrict__ 
 }
 
 SGNN_EXPORT int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
-                                  int64_t n_dst, sgnn_stream_t stream) {
+                                  int64_t n_dst, const int64_t *m_dev, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(c >= 1 && m >= 0 && n_dst >= 0);
   if (n_dst > 0) {
     SGNN_CHECK_ARG(dst);
@@ -217,7 +223,7 @@ SGNN_EXPORT int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, i
   if (m == 0 || n_dst == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && idx);
   const int cq = c / row_vec(c);
-  ROWS_LAUNCH(k_scatter_rows, c, m * cq, stream, src, cq, idx, m, dst);
+  ROWS_LAUNCH(k_scatter_rows, c, m * cq, stream, src, cq, idx, m, dst, m_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -276,8 +282,9 @@ SGNN_EXPORT int sgnn_repeat_rows(const float *src, int c, int64_t n, int rep, fl
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_sum_groups(const float *__restrict__ src, int cq, int64_t n, int rep,
-                                                   float *__restrict__ dst) {
+                                                   float *__restrict__ dst, const int64_t *n_dev) {
   typedef typename VecT<VEC>::T T;
+  n = sgnn_dyn_n(n, n_dev);
   const int64_t total = n * cq, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / cq;
@@ -288,14 +295,19 @@ __global__ __launch_bounds__(256) void k_sum_groups(const float *__restrict__ sr
   }
 }
 
-SGNN_EXPORT int sgnn_sum_groups(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream) {
+int sgnn_sum_groups_dn(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream,
+                       const int64_t *n_dev) {
   SGNN_CHECK_ARG(c >= 1 && n >= 0 && rep >= 1);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && dst);
   const int cq = c / row_vec(c);
-  ROWS_LAUNCH(k_sum_groups, c, n * cq, stream, src, cq, n, rep, dst);
+  ROWS_LAUNCH(k_sum_groups, c, n * cq, stream, src, cq, n, rep, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_sum_groups(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream) {
+  return sgnn_sum_groups_dn(src, c, n, rep, dst, stream, nullptr);
 }
 
 // dst[r] = [a[ia?ia[r]:r] | b[ib?ib[r]:r] (0 if ib[r] < 0)]   — scalar elements (ca, cb arbitrary)
@@ -303,8 +315,9 @@ __global__ __launch_bounds__(256) void k_concat_rows(const float *__restrict__ a
                                                     const int32_t *__restrict__ ia,
                                                     const float *__restrict__ b, int cb,
                                                     const int32_t *__restrict__ ib, int64_t m,
-                                                    float *__restrict__ dst) {
+                                                    float *__restrict__ dst, const int64_t *n_dev) {
   const int c = ca + cb;
+  m = sgnn_dyn_n(m, n_dev);
   const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / c;
@@ -323,11 +336,16 @@ __global__ __launch_bounds__(256) void k_concat_rows(const float *__restrict__ a
 
 SGNN_EXPORT int sgnn_concat_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb,
                                  const int32_t *ib, int64_t m, float *dst, sgnn_stream_t stream) {
+  return sgnn_concat_rows_dn(a, ca, ia, b, cb, ib, m, dst, stream, nullptr);
+}
+
+int sgnn_concat_rows_dn(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib, int64_t m,
+                        float *dst, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b));
   hipLaunchKernelGGL(k_concat_rows, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, a, ca, ia, b, cb, ib, m, dst);
+                     (hipStream_t)stream, a, ca, ia, b, cb, ib, m, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -335,8 +353,10 @@ SGNN_EXPORT int sgnn_concat_rows(const float *a, int ca, const int32_t *ia, cons
 __global__ __launch_bounds__(256) void k_concat_rows_bwd(const float *__restrict__ ddst, int ca,
                                                         const int32_t *__restrict__ ia, int cb,
                                                         const int32_t *__restrict__ ib, int64_t m,
-                                                        float *__restrict__ da, float *__restrict__ db) {
+                                                        float *__restrict__ da, float *__restrict__ db,
+                                                        const int64_t *n_dev) {
   const int c = ca + cb;
+  m = sgnn_dyn_n(m, n_dev);
   const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
     const int64_t r = g / c;
@@ -357,6 +377,11 @@ __global__ __launch_bounds__(256) void k_concat_rows_bwd(const float *__restrict
 SGNN_EXPORT int sgnn_concat_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib,
                                      int64_t m, float *da, int64_t na, float *db, int64_t nb,
                                      sgnn_stream_t stream) {
+  return sgnn_concat_rows_bwd_dn(ddst, ca, ia, cb, ib, m, da, na, db, nb, stream, nullptr);
+}
+
+int sgnn_concat_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int64_t m, float *da,
+                            int64_t na, float *db, int64_t nb, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0 && na >= 0 && nb >= 0);
   if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
@@ -366,7 +391,7 @@ SGNN_EXPORT int sgnn_concat_rows_bwd(const float *ddst, int ca, const int32_t *i
   SGNN_CHECK_ARG(ia || !da || na >= m);
   SGNN_CHECK_ARG(ib || !db || nb >= m);
   hipLaunchKernelGGL(k_concat_rows_bwd, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0, s, ddst, ca,
-                     ia, cb, ib, m, da, db);
+                     ia, cb, ib, m, da, db, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -385,7 +410,8 @@ struct Cat3Out {
   int c[3];
 };
 
-__global__ __launch_bounds__(256) void k_concat3(Cat3 s, int64_t m, float *__restrict__ dst) {
+__global__ __launch_bounds__(256) void k_concat3(Cat3 s, int64_t m, float *__restrict__ dst, const int64_t *n_dev) {
+  m = sgnn_dyn_n(m, n_dev);
   const int c01 = s.c[0] + s.c[1], c = c01 + s.c[2];
   const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
@@ -398,7 +424,9 @@ __global__ __launch_bounds__(256) void k_concat3(Cat3 s, int64_t m, float *__res
   }
 }
 
-__global__ __launch_bounds__(256) void k_concat3_bwd(const float *__restrict__ ddst, int64_t m, Cat3Out o) {
+__global__ __launch_bounds__(256) void k_concat3_bwd(const float *__restrict__ ddst, int64_t m, Cat3Out o,
+                                                    const int64_t *n_dev) {
+  m = sgnn_dyn_n(m, n_dev);
   const int c01 = o.c[0] + o.c[1], c = c01 + o.c[2];
   const int64_t total = m * c, stride = (int64_t)gridDim.x * 256;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
@@ -415,12 +443,18 @@ __global__ __launch_bounds__(256) void k_concat3_bwd(const float *__restrict__ d
 SGNN_EXPORT int sgnn_concat3_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
                                   const float *c, int cc, const int32_t *ic, int64_t m, float *dst,
                                   sgnn_stream_t stream) {
+  return sgnn_concat3_rows_dn(a, ca, ia, b, cb, ib, c, cc, ic, m, dst, stream, nullptr);
+}
+
+int sgnn_concat3_rows_dn(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
+                         const float *c, int cc, const int32_t *ic, int64_t m, float *dst, sgnn_stream_t stream,
+                         const int64_t *n_dev) {
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && cc >= 0 && ca + cb + cc >= 1 && m >= 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b) && (cc == 0 || c));
   const Cat3 s{{a, b, c}, {ia, ib, ic}, {ca, cb, cc}};
   hipLaunchKernelGGL(k_concat3, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     s, m, dst);
+                     s, m, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -430,6 +464,12 @@ SGNN_EXPORT int sgnn_concat3_rows(const float *a, int ca, const int32_t *ia, con
 SGNN_EXPORT int sgnn_concat3_rows_bwd(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int cc,
                                       const int32_t *ic, int64_t m, float *da, int64_t na, float *db, int64_t nb,
                                       float *dc, int64_t nc, sgnn_stream_t stream) {
+  return sgnn_concat3_rows_bwd_dn(ddst, ca, ia, cb, ib, cc, ic, m, da, na, db, nb, dc, nc, stream, nullptr);
+}
+
+int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb, const int32_t *ib, int cc,
+                             const int32_t *ic, int64_t m, float *da, int64_t na, float *db, int64_t nb, float *dc,
+                             int64_t nc, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && cc >= 0 && ca + cb + cc >= 1 && m >= 0 && na >= 0 && nb >= 0 && nc >= 0);
   if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
@@ -439,7 +479,7 @@ SGNN_EXPORT int sgnn_concat3_rows_bwd(const float *ddst, int ca, const int32_t *
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG((ia || !da || na >= m) && (ib || !db || nb >= m) && (ic || !dc || nc >= m));
   const Cat3Out o{{da, db, dc}, {ia, ib, ic}, {ca, cb, cc}};
-  hipLaunchKernelGGL(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o);
+  hipLaunchKernelGGL(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

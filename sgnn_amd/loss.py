@@ -83,8 +83,9 @@ def compute_targets_and_weights(target, hierarchy, num_hierarchy_levels, truncat
     ptrs = dict((k, np.ascontiguousarray(np.array(v + [0], dtype=np.uint64))) for k, v in arr.items())
     locs = input_locs.contiguous() if want_w else None
     kn = known.contiguous() if use_loss_masking else None
+    n_cnt = getattr(input_locs, '_sgnn_cnt', None) if want_w else None     # capacity mode: live rows of input_locs
     _lib.call('sgnn_loss_targets', _lib.ptr(target), _lib.ptr(kn), _lib.ptr(locs), 0 if locs is None else int(locs.shape[0]),
-              B, d0, d1, d2, float(truncation), int(bool(use_loss_masking)), float(weight_missing_geo), L - 1,
+              _lib.ptr(n_cnt), B, d0, d1, d2, float(truncation), int(bool(use_loss_masking)), float(weight_missing_geo), L - 1,
               ptrs['hin'].ctypes.data, _lib.ptr(tsdf), _lib.ptr(hiers[-1]), _lib.ptr(occs[-1]),
               _lib.ptr(weights[-1]) if want_w else None, ptrs['occ'].ctypes.data, ptrs['w'].ctypes.data,
               ptrs['hier'].ctypes.data)
@@ -166,18 +167,19 @@ class _LevelLoss(torch.autograd.Function):
         out2 = torch.empty(2, dtype=torch.float32, device=vals.device)
         wsb = _lib.query('sgnn_loss_ws_bytes')
         ws = rt.workspace(wsb)
+        m_cnt = getattr(locs, '_sgnn_cnt', None)       # capacity mode: live row count (device int64[1])
         args = (_lib.ptr(locs), _lib.ptr(vals), vstride, occ_col, sdf_col, _lib.ptr(tgt_occ), _lib.ptr(tgt_sdf),
                 _lib.ptr(weights), _lib.ptr(known), int(dims[0]), int(dims[1]), int(dims[2]), m, int(use_log),
-                mask_mode)
+                mask_mode, _lib.ptr(m_cnt))
         _lib.call('sgnn_loss_level_fwd', *args, _lib.ptr(sums), _lib.ptr(out2), _lib.ptr(ws), wsb)
         ctx.args = args
-        ctx.keep = (locs, vals, tgt_occ, tgt_sdf, weights, known, sums)
+        ctx.keep = (locs, vals, tgt_occ, tgt_sdf, weights, known, sums, m_cnt)
         return out2
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib
-        locs, vals, tgt_occ, tgt_sdf, weights, known, sums = ctx.keep
+        locs, vals, tgt_occ, tgt_sdf, weights, known, sums, _m_cnt = ctx.keep
         g = g.contiguous()
         dvals = torch.empty_like(vals)
         _lib.call('sgnn_loss_level_bwd', *ctx.args, _lib.ptr(sums), _lib.ptr(g), _lib.ptr(dvals))
@@ -205,15 +207,16 @@ class _TotalLoss(torch.autograd.Function):
         args_all, coef, held = [], [], []
         for l, (lv, v) in enumerate(zip(levels, vals)):
             v = v.contiguous()
+            m_cnt = getattr(lv['locs'], '_sgnn_cnt', None)       # capacity mode: live row count (device int64[1])
             locs = lv['locs'].contiguous()
             dims = lv['tgt_sdf'].shape[2:]
             m, vstride = v.shape
             args = (_lib.ptr(locs), _lib.ptr(v), vstride, lv['occ_col'], lv['sdf_col'], _lib.ptr(lv['tgt_occ']),
                     _lib.ptr(lv['tgt_sdf']), _lib.ptr(lv['weights']), _lib.ptr(lv['known']), int(dims[0]), int(dims[1]),
-                    int(dims[2]), m, int(use_log), lv['mask_mode'])
+                    int(dims[2]), m, int(use_log), lv['mask_mode'], _lib.ptr(m_cnt))
             _lib.call('sgnn_loss_level_fwd', *args, sums[l].data_ptr(), out2s.data_ptr() + 8 * l, _lib.ptr(ws), wsb)
             args_all.append(args)
-            held.append((locs, v))
+            held.append((locs, v, m_cnt))
             coef += [float(lv['coef'][0]), float(lv['coef'][1])]
         coef_np = np.ascontiguousarray(np.array(coef, dtype=np.float32))
         total = torch.empty((), dtype=torch.float32, device=dev)

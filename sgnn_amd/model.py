@@ -96,16 +96,20 @@ class TSDFEncoder(nn.Module):
         self.occpred = nn.Sequential(nn.Conv3d(nf_out, 1, kernel_size=1, bias=False))
         self.sdfpred = nn.Sequential(nn.Conv3d(nf_out, 1, kernel_size=1, bias=False))
 
-    def forward(self, x, batch_size=None):
+    def forward(self, x, batch_size=None, capacity=None):
         """Returns (feat_rows (B*V, nf_out), out_rows (B*V, 2) [occ logit, sdf], skips, dense geometry);
-        rows are the dense coarse volume in batch-major raster order (== permute(0,2,3,4,1).view(-1, C))."""
+        rows are the dense coarse volume in batch-major raster order (== permute(0,2,3,4,1).view(-1, C)).
+        capacity (scn.capacity.Capacity): capacity mode — x[0] carries its live row count, no host read-back."""
         skips = []
         n_layers = len(self.process_sparse)
         prog = self._sparse_program() if P_.ENABLED else None
         if prog is not None:
             # the three sparse encoder levels (p1, p2, p3 each) as one native program; taps = the p2 outputs
             x0 = self.process_sparse[0].p0(x)
-            x0.metadata.prebuild(x0.key, n_layers)      # all stride-2 levels, one host read-back
+            if capacity is not None:                    # stride-2 levels with device-side row counts
+                x0.metadata.prebuild(x0.key, n_layers, capacity=(capacity.enc, capacity.enc_counts()))
+            else:
+                x0.metadata.prebuild(x0.key, n_layers)      # all stride-2 levels, one host read-back
             taps = [prog.taps[id(l.p2)][0] for l in self.process_sparse]
             outs, grids, _ = P_.run_program(prog, x0, self.training, taps + [prog.out])
             keys = [x0.key]
@@ -116,6 +120,8 @@ class TSDFEncoder(nn.Module):
             if self.use_skip_sparse:
                 skips = ts
         else:
+            if capacity is not None:
+                raise RuntimeError('capacity mode runs on the native program path (sgnn_amd.scn.program.ENABLED)')
             for i, layer in enumerate(self.process_sparse):
                 x, ft = layer(x, batch_size, densify=(i < n_layers - 1))
                 if self.use_skip_sparse:
@@ -125,7 +131,7 @@ class TSDFEncoder(nn.Module):
         if batch_size is None:  # upstream SparseToDense semantics: B = max batch index + 1 (one host read)
             batch_size = int(g.coords[:, 3].max().item()) + 1 if g.n else 0
         geo = dense_geometry(batch_size, dims, x.features.device)
-        rows = F_.ScatterRows.apply(x.features, geo.grid.lookup(g.coords), geo.grid.n)
+        rows = F_.ScatterRows.apply(x.features, geo.grid.lookup(g.coords, g.cnt), geo.grid.n, g.cnt)
         t0, t1 = geo.level(0), geo.level(1)
         enc0 = _bn3d_relu(self.encode_dense0[1], _dense_conv(rows, self.encode_dense0[0], t0, down=True))
         enc1 = _bn3d_relu(self.encode_dense1[1], _dense_conv(enc0, self.encode_dense1[0], t1, down=True))
@@ -317,8 +323,10 @@ class Refinement(nn.Module):
             return None
         locs = prev[3]
         x0 = self.p0([locs, ext[0]])
+        cnt8 = getattr(locs, '_sgnn_cnt8', None)              # capacity mode: live rows of the 8-child expansion
         outs, _, _ = P_.run_program(prog, x0, self.training, [prog.taps[id(self.n2)][0], prog.taps[id(self.linear)][0]],
-                                    ext=ext, idx=idx, extra_rows=extra)
+                                    ext=ext, idx=idx, extra_rows=extra,
+                                    extra_cnt=None if cnt8 is None else {'child': cnt8})
         children = getattr(locs, '_sgnn_children', None)     # already made by GenModel._teacher_plans
         return outs[0], outs[1], (children if children is not None else F_.expand8_coords(locs))
 
@@ -339,7 +347,7 @@ def _stage_program(owner, prev, skip, chain, nf_in, tail):
             return None, None, None, None
         srcs[2] = ('skip', int(feats_from.shape[1]), 1)
         ext.append(feats_from)
-        idx.append(grid_from.lookup(locs))
+        idx.append(grid_from.lookup(locs, getattr(locs, '_sgnn_cnt', None)))
         extra['skip'] = grid_from.n
     cache = owner.__dict__.setdefault('_stage_progs', {})
     key = tuple(srcs)
@@ -452,8 +460,8 @@ class GenModel(nn.Module):
         R = len(self.refinement)
         # which later stage consumes a compaction's sites (its U-Net needs a 2-level stride-2 pyramid)?
         runs = [loss_weights[h + 1] > 0 for h in range(R)] + [bool(self.PRED_SURF and loss_weights[-1] > 0)]
-        for h in range(R):
-            self.refinement[h].plan_depth = 2 if any(runs[h + 1:h + 2]) else 0
+        for h in range(R):     # the pyramid serves the next stage that actually runs (a skipped level does not compact)
+            self.refinement[h].plan_depth = 2 if any(runs[h + 1:]) else 0
         return runs
 
     def plan_geometry(self, locs, loss_weights, batch_size, teacher):
@@ -479,8 +487,13 @@ class GenModel(nn.Module):
         plans = self._teacher_plans(dense_geometry(batch_size, dims, dev), self._runs(loss_weights), teacher)
         return coords, plans
 
-    def forward(self, x, loss_weights, batch_size=None, teacher=None, geometry=None):
-        """teacher (optional, not in the reference): list of the L dense target occupancy volumes (loss.compute_targets'
+    def forward(self, x, loss_weights, batch_size=None, teacher=None, geometry=None, capacity=None):
+        """capacity (scn.capacity.Capacity, optional; not in the reference): capacity mode — every level's tensors have
+        the plan's capacities, the live row counts stay on the device (results carry them as `_sgnn_cnt`; rows past a
+        count are undefined) and the call performs NO host read-back, so a training step can be captured in a HIP
+        graph (train.GraphStep).  x[0] may have more rows than the batch (x[0]._sgnn_cnt or capacity.input_cnt()
+        holds the live count).  Needs batch_size and the native stage path.
+        teacher (optional, not in the reference): list of the L dense target occupancy volumes (loss.compute_targets'
         target_for_occs); when given, every generative mask is `target occupancy == 1` at the candidate site instead of
         sigmoid(predicted occupancy) > 0.5, so the per-level site counts do not depend on the weights (bench.py).
         geometry: result of plan_geometry() for this batch and these loss weights (teacher-forced only)."""
@@ -488,12 +501,17 @@ class GenModel(nn.Module):
             if teacher is None or not (P_.ENABLED and STAGES):
                 raise ValueError('geometry plans belong to the teacher-forced native stage path')
             x = [geometry[0], x[1]]
+        if capacity is not None:
+            if geometry is not None or batch_size is None or not (P_.ENABLED and STAGES):
+                raise ValueError('capacity mode: pass batch_size, no geometry plan, native stage path on')
+            if getattr(x[0], '_sgnn_cnt', None) is None:
+                x[0]._sgnn_cnt = capacity.input_cnt()
         x = [coords_from_locs(x[0], x[1].device), x[1]]
         R = len(self.refinement)
         runs = self._runs(loss_weights)
         plans = None if geometry is None else geometry[1]
         if (plans is None and teacher is not None and batch_size is not None and TEACHER_GEOMETRY_FIRST and P_.ENABLED
-                and STAGES):
+                and STAGES and capacity is None):
             # teacher-forced masks depend on the data only: build the site lists, index lists and stride-2 pyramids of
             # ALL generative levels now, while the GPU queue is short.  Their row-count read-backs then wait for a few
             # small kernels each instead of for a whole stage's convolutions, and everything after them — encoder,
@@ -501,12 +519,14 @@ class GenModel(nn.Module):
             enc = self.encoder
             dims = tuple(int(v) >> len(enc.process_sparse) for v in enc.process_sparse[0].p0.spatial_size)
             plans = self._teacher_plans(dense_geometry(batch_size, dims, x[1].device), runs, teacher)
-        feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size)
+        feat_rows, occ_rows, skips, geo = self.encoder(x, batch_size, capacity=capacity)
         if self.use_skip_sparse:
             skips = [(t.grid(), t.features) for t in skips]
         if P_.ENABLED and STAGES:
-            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher, plans)
+            res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher, plans, capacity)
             if res is not None:
+                if capacity is not None:
+                    return res
                 if not self.training:     # inference: report input errors (duplicate / out-of-range sites) from THIS call
                     from .scn.metadata import runtime
                     runtime(feat_rows.device).check_status()
@@ -552,7 +572,8 @@ class GenModel(nn.Module):
             plans.append(plan)
         return plans
 
-    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher=None, plans=None):
+    def _forward_stages(self, feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher=None, plans=None,
+                        capacity=None):
         """forward() with every generative stage as one native program (Refinement.stage / SurfacePrediction.stage):
         the kept rows of a level are never gathered into their own tensor — the next stage's CONCAT_IN reads them
         through the compaction's index list.  Same results as the per-module path (tests/test_gpu_program.py)."""
@@ -566,6 +587,9 @@ class GenModel(nn.Module):
         tv = (lambda h: None) if teacher is None else (lambda h: teacher[h])
         if plans is not None:
             sel, cnt, locs = plans[0]
+        elif capacity is not None:      # kept counts stay on the device; `cnt` is the level's capacity from here on
+            sel, cnt, locs = F_.compact_capped(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0, capacity, 0,
+                                               tv(0))
         else:
             sel, cnt, locs = F_.compact_sigmoid_plan(occ_rows.detach(), 2, n_all, geo.coords, 2 if runs[0] else 0, tv(0))
         # channel order of model.py:330: [occ, sdf | features]
@@ -585,6 +609,9 @@ class GenModel(nn.Module):
             outputs.append([F_.coords_to_i64(coords_next), out])
             if plans is not None:
                 sel, cnt, locs = plans[h + 1]
+            elif capacity is not None:
+                sel, cnt, locs = F_.compact_capped(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth, capacity,
+                                                   h + 1, tv(h + 1))
             else:
                 sel, cnt, locs = F_.compact_sigmoid_plan(out.detach(), 2, out.shape[0], coords_next, ref.plan_depth, tv(h + 1))
             # channel order of model.py:242: [features | occ, sdf]

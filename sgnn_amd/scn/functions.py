@@ -258,9 +258,9 @@ def gather_rows_raw(src, c, idx, m):
     return dst
 
 
-def scatter_rows_raw(src, c, idx, m, n_dst):
+def scatter_rows_raw(src, c, idx, m, n_dst, m_cnt=None):
     dst = torch.empty(n_dst, c, dtype=torch.float32, device=src.device)
-    _lib.call('sgnn_scatter_rows', ptr(src), c, ptr(idx), m, ptr(dst), n_dst)
+    _lib.call('sgnn_scatter_rows', ptr(src), c, ptr(idx), m, ptr(dst), n_dst, ptr(m_cnt))
     return dst
 
 
@@ -288,20 +288,27 @@ class GatherRows(Function):
 
 
 class ScatterRows(Function):
-    """dst (n_dst rows, zeros elsewhere); dst[idx[r]] = src[r] with unique idx."""
+    """dst (n_dst rows, zeros elsewhere); dst[idx[r]] = src[r] with unique idx.  m_cnt: device row count of src
+    (capacity mode)."""
 
     @staticmethod
-    def forward(ctx, src, idx, n_dst):
+    def forward(ctx, src, idx, n_dst, m_cnt=None):
         src = _f32c(src)
         ctx.save_for_backward(idx)
         ctx.shape = (src.shape[0], src.shape[1])
-        return scatter_rows_raw(src, src.shape[1], idx, src.shape[0], n_dst)
+        ctx.m_cnt = m_cnt
+        return scatter_rows_raw(src, src.shape[1], idx, src.shape[0], n_dst, m_cnt)
 
     @staticmethod
     def backward(ctx, d):
         (idx,) = ctx.saved_tensors
         m, c = ctx.shape
-        return gather_rows_raw(_f32c(d), c, idx, m), None, None
+        d = _f32c(d)
+        if ctx.m_cnt is None:
+            return gather_rows_raw(d, c, idx, m), None, None, None
+        out = torch.empty(m, c, dtype=torch.float32, device=d.device)
+        _lib.call('sgnn_gather_rows_dn', ptr(d), c, ptr(idx), ptr(ctx.m_cnt), m, ptr(out))
+        return out, None, None, None
 
 
 class RowLinear(Function):
@@ -491,6 +498,8 @@ def compact_sigmoid_plan(logits, stride, n, coords_all, depth, teacher=None):
             _compact_call(logits, stride, n, coords_all, sel, rt, rt.workspace(wsb), wsb, teacher)
             cnt = rt.read_count()
             sel = sel[:cnt]
+        if MD.COUNT_LOG is not None:
+            MD.COUNT_LOG.append(('gen', int(cnt), []))
         return sel, cnt, gather_coords(coords_all, sel, cnt)
     sel = torch.empty(n, dtype=torch.int32, device=logits.device)
     wsb = _lib.query('sgnn_compact_ws_bytes', n)
@@ -502,9 +511,44 @@ def compact_sigmoid_plan(logits, stride, n, coords_all, depth, teacher=None):
     host = rt.read_counts()
     count = int(host[0])
     locs = locs_cap[:count]
+    if MD.COUNT_LOG is not None:
+        MD.COUNT_LOG.append(('gen', count, [int(v) for v in host[2:2 + chain.depth]]))
     if count:
         locs._sgnn_plan = chain.finalize(count, host)
     return sel[:count], count, locs
+
+
+def compact_capped(logits, stride, n_all, coords_all, depth, capacity, g, teacher=None):
+    """Capacity-mode counterpart of compact_sigmoid_plan for generative level g of `capacity` (scn.capacity.Capacity):
+    no host read-back.  The candidate count is coords_all._sgnn_cnt (None: n_all is exact, the dense coarse volume);
+    returns (sel (n_all), kept capacity K, locs (K,4) int32) where locs carries its live count (`_sgnn_cnt`, and
+    `_sgnn_cnt8` = 8 x it) and, for depth >= 1, the stride-2 pyramid below it (`_sgnn_plan`) sized by the capacities."""
+    from . import metadata as MD
+    dev = coords_all.device
+    rt = runtime(dev)
+    K, pyr_caps = capacity.gen[g]
+    cnt2 = capacity.kept2(g)
+    n_cnt = getattr(coords_all, '_sgnn_cnt', None)
+    sel = torch.empty(max(n_all, 1), dtype=torch.int32, device=dev)
+    wsb = _lib.query('sgnn_compact_ws_bytes', n_all)
+    ws = rt.workspace(wsb)
+    if teacher is None:
+        _lib.call('sgnn_compact_sigmoid_cap', ptr(logits), stride, n_all, ptr(n_cnt), ptr(sel), ptr(cnt2), K,
+                  ptr(rt.status32), ptr(ws), wsb)
+    else:
+        B, _, d0, d1, d2 = (int(v) for v in teacher.shape)
+        _lib.call('sgnn_compact_dense_cap', ptr(coords_all), n_all, ptr(n_cnt), ptr(teacher), B, d0, d1, d2, ptr(sel),
+                  ptr(cnt2), K, ptr(rt.status32), ptr(ws), wsb)
+    kept, kept8 = cnt2[0:1], cnt2[1:2]
+    locs = torch.empty(K, 4, dtype=torch.int32, device=dev)
+    _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(kept), K, ptr(locs))
+    locs._sgnn_cnt, locs._sgnn_cnt8 = kept, kept8
+    if depth >= 1:
+        depth = min(depth, len(pyr_caps))
+        chain = MD.PendingChain(locs, K, True, depth, n0_cnt=kept, counts=capacity.pyr_counts(g, depth),
+                                level_caps=pyr_caps)
+        locs._sgnn_plan = chain.finalize_capped()
+    return sel, K, locs
 
 
 def compact_mask(mask_u8, n):
@@ -527,7 +571,10 @@ def gather_coords(coords32, sel, m):
 def expand8_coords(coords32):
     n = coords32.shape[0]
     out = torch.empty(8 * n, 4, dtype=torch.int32, device=coords32.device)
-    _lib.call('sgnn_expand8_coords', ptr(coords32), n, ptr(out))
+    cnt = getattr(coords32, '_sgnn_cnt', None)
+    _lib.call('sgnn_expand8_coords', ptr(coords32), n, ptr(out), ptr(cnt))
+    if cnt is not None:          # capacity mode: the children's live row count (8 x kept) sits next to the kept count
+        out._sgnn_cnt = coords32._sgnn_cnt8
     return out
 
 
@@ -540,5 +587,8 @@ def dense_coords(batch, d0, d1, d2, device):
 def coords_to_i64(coords32):
     n = coords32.shape[0]
     out = torch.empty(n, 4, dtype=torch.int64, device=coords32.device)
-    _lib.call('sgnn_coords_to_i64', ptr(coords32), n, ptr(out))
+    cnt = getattr(coords32, '_sgnn_cnt', None)
+    _lib.call('sgnn_coords_to_i64', ptr(coords32), n, ptr(out), ptr(cnt))
+    if cnt is not None:
+        out._sgnn_cnt = cnt
     return out

@@ -88,8 +88,21 @@ class _Runtime(object):
                 msgs.append('coordinate outside [0,65535] (batch outside [0,32767])')
             if status & 2:
                 msgs.append('InputLayer(mode=0): duplicate coordinates are a caller error')
+            if status & 4 and not (status & 3):
+                raise CapacityOverflow('capacity mode: a level produced more rows than its capacity (step discarded)')
+            if status & 4:
+                msgs.append('capacity overflow')
             raise _lib.SgnnError('; '.join(msgs))
 
+
+class CapacityOverflow(_lib.SgnnError):
+    """Capacity mode: some level had more rows than the buffers sized for it.  Nothing was written out of bounds and
+    sgnn_adam_flat skipped the update; re-run the batch with larger capacities (train.GraphStep does)."""
+
+
+# exact-mode row counts of the last forward pass, recorded when this is a list: ('enc', n_input, [pyramid rows]) and
+# ('gen', kept rows, [pyramid rows]) entries in call order — what scn.capacity.Capacity.from_log sizes itself from
+COUNT_LOG = None
 
 _runtimes = {}
 _lanes = threading.local()     # .n = scratch lane of this thread (0 = main); see `lane`
@@ -158,10 +171,12 @@ def _round_up(n, m):
 class Grid(object):
     """Active sites of one resolution level: int32 coords (n,4) [z,y,x,b]; row i <-> site i."""
 
-    def __init__(self, coords32, keys=None, vals=None, cap=0):
+    def __init__(self, coords32, keys=None, vals=None, cap=0, cnt=None):
         assert coords32.dtype == torch.int32 and coords32.dim() == 2 and coords32.shape[1] == 4
         self.coords = coords32.contiguous()
         self.n = int(coords32.shape[0])
+        # capacity mode: `n` is the capacity, the live row count is this device int64[1] (None: n is exact)
+        self.cnt = cnt
         self.device = coords32.device
         self.keys, self.vals, self.cap = keys, vals, cap
         self._nbr = None
@@ -176,15 +191,16 @@ class Grid(object):
             self.keys = torch.empty(self.cap, dtype=torch.int64, device=self.device)
             self.vals = torch.empty(self.cap, dtype=torch.int32, device=self.device)
             _lib.call('sgnn_hash_build', ptr(self.coords), self.n, ptr(self.keys), ptr(self.vals), self.cap,
-                      ptr(rt.status32))
+                      ptr(rt.status32), ptr(self.cnt))
         return self.keys, self.vals, self.cap
 
-    def lookup(self, query32):
-        """Row of each query site in this grid, or -1 (int32 tensor)."""
+    def lookup(self, query32, m_cnt=None):
+        """Row of each query site in this grid, or -1 (int32 tensor).  m_cnt: device count of the query rows
+        (capacity mode; rows past it are left unwritten)."""
         keys, vals, cap = self.hash()
         m = int(query32.shape[0])
         rows = torch.empty(m, dtype=torch.int32, device=self.device)
-        _lib.call('sgnn_hash_lookup', ptr(keys), ptr(vals), cap, ptr(query32), m, ptr(rows))
+        _lib.call('sgnn_hash_lookup', ptr(keys), ptr(vals), cap, ptr(query32), m, ptr(rows), ptr(m_cnt))
         return rows
 
     def subm_table(self):
@@ -197,16 +213,16 @@ class Grid(object):
                     and 0 < d[0] * d[1] * d[2] <= INDEX_VOLUME_ENTRIES and max(d) <= 65536):
                 vol = runtime(self.device).index_volume()
                 _lib.call('sgnn_rulebook_subm3_dense', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, int(d[0]),
-                          int(d[1]), int(d[2]), ptr(vol), vol.numel(), ptr(self._nbr), self.ld)
+                          int(d[1]), int(d[2]), ptr(vol), vol.numel(), ptr(self._nbr), self.ld, ptr(self.cnt))
             else:
                 _lib.call('sgnn_rulebook_subm3', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, ptr(self._nbr),
-                          self.ld)
+                          self.ld, ptr(self.cnt))
         return self._nbr
 
     def tile_index(self):
         """Tile index of the 3x3x3 table (sgnn_tile_index: unique rows + 16-bit local slots per 128-row tile) for the
         LDS-staged convolution kernel; None below TILE_MIN_ROWS, where the small / gather kernels are used."""
-        if self.n < TILE_MIN_ROWS:
+        if self.n < TILE_MIN_ROWS or self.cnt is not None:
             return None
         if self._tile is None:
             nbr = self.subm_table()
@@ -216,7 +232,9 @@ class Grid(object):
 
     def locations_i64(self):
         out = torch.empty(self.n, 4, dtype=torch.int64, device=self.device)
-        _lib.call('sgnn_coords_to_i64', ptr(self.coords), self.n, ptr(out))
+        _lib.call('sgnn_coords_to_i64', ptr(self.coords), self.n, ptr(out), ptr(self.cnt))
+        if self.cnt is not None:
+            out._sgnn_cnt = self.cnt
         return out
 
 
@@ -245,7 +263,8 @@ def build_down2(fine):
     ldc, ldf = coarse.ld, fine.ld
     children = torch.empty(8 * ldc, dtype=torch.int32, device=dev)
     ptable = torch.empty(8 * ldf, dtype=torch.int32, device=dev)  # rows >= nf are never read
-    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf)
+    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf, None,
+              None)
     return Down2(fine, coarse, parent[:nf], children, ldc, ptable, ldf)
 
 
@@ -257,11 +276,15 @@ class PendingChain(object):
     """Stride-2 pyramid below a level, issued before the host knows any row count (sgnn_down2_chain).
     `finalize(n0, counts)` turns it into Grid / Down2 objects once the single read-back has happened."""
 
-    def __init__(self, coords_cap, n0, n0_on_device, depth):
+    def __init__(self, coords_cap, n0, n0_on_device, depth, n0_cnt=None, counts=None, level_caps=None):
+        """n0_cnt / counts / level_caps (capacity mode): the device int64[1] holding level 0's row count, the device
+        int64[depth] that receives the rows of levels 1..depth (clamped to level_caps, a list of ints) — instead of
+        the runtime's state block and a host read-back."""
         dev = coords_cap.device
         rt = runtime(dev)
         cap = int(coords_cap.shape[0])
         depth = min(depth, MAX_CHAIN)
+        self.n0_cnt, self.counts, self.level_caps = n0_cnt, counts, level_caps
         self.coords_cap, self.cap, self.depth = coords_cap, cap, depth
         self.ccap = _lib.query('sgnn_hash_capacity', cap)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -273,10 +296,17 @@ class PendingChain(object):
         ws = rt.workspace(wsb)
         arr = lambda ts: np.ascontiguousarray(np.array([t.data_ptr() for t in ts], dtype=np.uint64))
         self._keep = [arr(self.ckeys), arr(self.cvals), arr(self.parent), arr(self.ccoords)]
+        if counts is not None:
+            assert n0_cnt is not None and level_caps is not None and len(level_caps) >= depth and counts.numel() >= depth
+            caps_np = np.ascontiguousarray(np.array([int(c) for c in level_caps[:depth]], dtype=np.int64))
+            _lib.call('sgnn_down2_chain', ptr(coords_cap), 0, ptr(n0_cnt), cap, depth, self._keep[0].ctypes.data,
+                      self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data, self._keep[3].ctypes.data,
+                      ptr(counts), caps_np.ctypes.data, ptr(rt.status32), ptr(ws), wsb)
+            return
         _lib.call('sgnn_down2_chain', ptr(coords_cap), 0 if n0_on_device else int(n0),
                   rt.state.data_ptr() if n0_on_device else None, cap, depth, self._keep[0].ctypes.data,
                   self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data, self._keep[3].ctypes.data,
-                  rt.state.data_ptr() + 16, ptr(ws), wsb)
+                  rt.state.data_ptr() + 16, None, None, ptr(ws), wsb)
 
     def finalize(self, n0, host_state):
         """-> (grid of level 0, [Down2 level l -> l+1])."""
@@ -290,6 +320,17 @@ class PendingChain(object):
             fine = coarse
         return grid0, downs
 
+    def finalize_capped(self, grid0=None):
+        """Capacity mode: Grid / Down2 objects sized by the level capacities, row counts left on the device."""
+        fine = grid0 if grid0 is not None else Grid(self.coords_cap, cnt=self.n0_cnt)
+        grid0, downs = fine, []
+        for l in range(self.depth):
+            cap_l = min(int(self.level_caps[l]), self.cap)
+            coarse = Grid(self.ccoords[l][:cap_l], self.ckeys[l], self.cvals[l], self.ccap, cnt=self.counts[l:l + 1])
+            downs.append(_down2_tables(fine, coarse, self.parent[l]))
+            fine = coarse
+        return grid0, downs
+
 
 def _down2_tables(fine, coarse, parent):
     dev = fine.device
@@ -297,7 +338,8 @@ def _down2_tables(fine, coarse, parent):
     ldc, ldf = coarse.ld, fine.ld
     children = torch.empty(8 * ldc, dtype=torch.int32, device=dev)
     ptable = torch.empty(8 * ldf, dtype=torch.int32, device=dev)  # rows >= nf are never read
-    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf)
+    _lib.call('sgnn_down2_tables', ptr(fine.coords), ptr(parent), nf, ptr(children), ldc, nc, ptr(ptable), ldf,
+              ptr(fine.cnt), ptr(coarse.cnt))
     return Down2(fine, coarse, parent[:nf], children, ldc, ptable, ldf)
 
 
@@ -329,9 +371,10 @@ class Metadata(object):
             self._register(nxt, d.coarse)
             key = nxt
 
-    def prebuild(self, spatial_size, depth):
+    def prebuild(self, spatial_size, depth, capacity=None):
         """Build the stride-2 pyramid (`depth` levels below `spatial_size`) with ONE host read-back instead of one
-        per level.  The level-0 grid must be registered already; levels already built are kept."""
+        per level.  The level-0 grid must be registered already; levels already built are kept.
+        capacity = (level capacities, device int64[depth] for the row counts): capacity mode, no read-back at all."""
         key = self.key(spatial_size)
         k, todo = key, 0
         for _ in range(depth):
@@ -342,10 +385,20 @@ class Metadata(object):
                 todo += 1
             k = nxt
         g0 = self.grids[key]
+        if capacity is not None:
+            if g0.cnt is None or len(self.down) or todo != depth:
+                raise _lib.SgnnError('capacity mode: the level-0 grid needs a device row count and an unbuilt pyramid')
+            caps, counts = capacity
+            chain = PendingChain(g0.coords, g0.n, True, depth, n0_cnt=g0.cnt, counts=counts, level_caps=caps)
+            _, downs = chain.finalize_capped(g0)
+            self.adopt(key, g0, downs)
+            return
         if not CHAIN or todo < 2 or g0.n == 0 or len(self.down):
             return
         chain = PendingChain(g0.coords, g0.n, False, todo)
         host = runtime(g0.device).read_counts()
+        if COUNT_LOG is not None:
+            COUNT_LOG.append(('enc', g0.n, [int(v) for v in host[2:2 + chain.depth]]))
         _, downs = chain.finalize(g0.n, host)
         fine = g0
         for d in downs:            # level 0 keeps its Grid object (hash / rulebook caches)
@@ -373,10 +426,17 @@ class Metadata(object):
 def coords_from_locs(locs, device):
     """Reference-style LongTensor (N,4) [z,y,x,b] (any device) -> device int32 rows."""
     rt = runtime(device)
+    cnt = getattr(locs, '_sgnn_cnt', None)       # capacity mode: live row count of `locs` (device int64[1])
     if locs.dtype == torch.int32:
-        return locs.to(device).contiguous()
-    locs = locs.to(device=device, dtype=torch.int64).contiguous()
-    n = int(locs.shape[0])
-    out = torch.empty(n, 4, dtype=torch.int32, device=device)
-    _lib.call('sgnn_coords_from_i64', ptr(locs), n, ptr(out), ptr(rt.status32))
+        out = locs.to(device).contiguous()
+    else:
+        src = locs.to(device=device, dtype=torch.int64).contiguous()
+        n = int(src.shape[0])
+        out = torch.empty(n, 4, dtype=torch.int32, device=device)
+        _lib.call('sgnn_coords_from_i64', ptr(src), n, ptr(out), ptr(rt.status32), ptr(cnt))
+    if cnt is not None and out is not locs:
+        out._sgnn_cnt = cnt
+        for a in ('_sgnn_cnt8', '_sgnn_plan', '_sgnn_children'):
+            if hasattr(locs, a):
+                setattr(out, a, getattr(locs, a))
     return out

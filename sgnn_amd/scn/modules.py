@@ -120,7 +120,7 @@ class InputLayer(nn.Module):
             g = plan[0]
             md.adopt(key, g, plan[1])
         else:
-            g = Grid(coords)
+            g = Grid(coords, cnt=getattr(coords, '_sgnn_cnt', None))   # capacity mode: the live row count travels along
             md.set_input(key, g)
         return SparseConvNetTensor(feats, md, key, g)
 

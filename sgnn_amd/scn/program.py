@@ -278,6 +278,15 @@ class _ProgramFn(Function):
             lev_n[cid] = run.extra_rows[name]
         nbr = [0] * prog.n_classes
         tile = [0] * prog.n_classes
+        # capacity mode: device row count per rows class (0 = lev_n is exact); lev_n then holds the capacities
+        cnts = [0] * prog.n_classes
+        for l, g in enumerate(run.grids):
+            if g.cnt is not None:
+                cnts[l] = g.cnt.data_ptr()
+        for name, cid in prog.class_ids.items():
+            c = run.extra_cnt.get(name)
+            if c is not None:
+                cnts[cid] = c.data_ptr()
         run.tile_hold = []
         for l in prog.subm_levels:
             nbr[l] = run.grids[l].subm_table().data_ptr()
@@ -290,7 +299,7 @@ class _ProgramFn(Function):
         ptable = [d.ptable.data_ptr() for d in run.downs] + pad
         parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + pad
         run.lev_n, run.lev_ld = lev_n, lev_ld
-        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, tile)]
+        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, tile, cnts)]
         run.pptr = _ptr_array([0 if p is None else p.data_ptr() for p in params])
         run.eptr = _ptr_array([t.data_ptr() for t in ext])
         run.iptr = _ptr_array([t.data_ptr() for t in run.idx] + [0])
@@ -310,8 +319,8 @@ class _ProgramFn(Function):
         ws = rt.workspace(wsb)
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls, run.pptr.ctypes.data,
-                  len(params),
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, run.tabs[5].ctypes.data, ncls,
+                  run.pptr.ctypes.data, len(params),
                   run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), total,
                   keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
         run.offsets = {}
@@ -354,12 +363,20 @@ class _ProgramFn(Function):
             held.append(g)
             gout[b] = g.data_ptr()
         gout = _ptr_array(gout)
-        # one flat gradient tensor for all trainable slots
-        sizes = [p.numel() if (t and p is not None) else 0 for p, t in zip(params, prog.grad_slot)]
+        # one flat gradient tensor for all trainable slots; a parameter bound to an optimizer's persistent flat
+        # gradient buffer (train.FlatAdam.bind_programs: `_sgnn_flat_grad`) gets its gradient written THERE and autograd
+        # sees None for it — no per-tensor accumulation node, no copy, a fixed address for graph capture
+        live = prog.tensors()
+        direct = [getattr(lp, '_sgnn_flat_grad', None) if (t and p is not None) else None
+                  for lp, p, t in zip(live, params, prog.grad_slot)]
+        sizes = [p.numel() if (t and p is not None and d is None) else 0 for p, t, d in zip(params, prog.grad_slot, direct)]
         flat = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=dev)
         gptr, views, o = [], [], 0
-        for p, s in zip(params, sizes):
-            if s:
+        for p, s, d in zip(params, sizes, direct):
+            if d is not None:
+                gptr.append(d.data_ptr())
+                views.append(None)
+            elif s:
                 v = flat[o:o + s].view_as(p)
                 gptr.append(v.data_ptr())
                 views.append(v)
@@ -374,8 +391,8 @@ class _ProgramFn(Function):
         rt.side_lane(run.wsb)
         _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls, run.pptr.ctypes.data,
-                  gp.ctypes.data,
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, run.tabs[5].ctypes.data, ncls,
+                  run.pptr.ctypes.data, gp.ctypes.data,
                   len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
                   arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, run.keep.ctypes.data,
                   int(run.training), ws.data_ptr(), run.wsb)
@@ -389,17 +406,33 @@ def compile_or_none(chain, in_channels, tap_modules=(), sources=None, tail=()):
         return None
 
 
-def run_program(prog, x, training, out_bufs=None, ext=None, idx=(), extra_rows=None):
+def run_program(prog, x, training, out_bufs=None, ext=None, idx=(), extra_rows=None, extra_cnt=None):
     """x: SparseConvNetTensor at the program's level 0 (its features are the external input unless `ext` lists the
-    program's source tensors).  Returns (list of output feature tensors, grids, downs)."""
+    program's source tensors).  Returns (list of output feature tensors, grids, downs).  extra_cnt: device row counts
+    (int64[1] tensors) of named rows classes, capacity mode."""
     run = _Run()
     run.prog, run.training = prog, training
     run.grids, run.downs = _levels(prog, x.metadata, x.key, x.grid())
     run.out_bufs = list(out_bufs) if out_bufs is not None else [prog.out]
     run.idx = list(idx)
     run.extra_rows = dict(extra_rows or {})
+    run.extra_cnt = dict(extra_cnt or {})
     if 'child' in prog.class_ids and 'child' not in run.extra_rows:
         run.extra_rows['child'] = 8 * run.grids[0].n
     tensors = [x.features] if ext is None else list(ext)
     outs = _ProgramFn.apply(run, *tensors, *prog.tensors())
     return list(outs), run.grids, run.downs
+
+
+def programs_of(model):
+    """Every compiled Program hanging off the modules of `model` (encoder stack: `_prog`; generative stages:
+    `_stage_progs`), compiled lazily by the first forward pass."""
+    out = []
+    for m in model.modules():
+        p = m.__dict__.get('_prog')
+        if isinstance(p, Program):
+            out.append(p)
+        for p in (m.__dict__.get('_stage_progs') or {}).values():
+            if isinstance(p, Program):
+                out.append(p)
+    return out

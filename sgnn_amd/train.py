@@ -162,13 +162,19 @@ def make_optimizer(params, lr=1e-3, weight_decay=0.0):
     return FastAdam(params, lr=lr, weight_decay=weight_decay)
 
 
-def to_device(batch, device):
-    """train.py:256-262: move one collated sample to the GPU."""
+def to_device(batch, device, non_blocking=False, record_ready=False):
+    """train.py:256-262: move one collated sample to the GPU.  record_ready: also record a torch.cuda.Event after the
+    copies (out['ready']) so that a consumer on another stream (GeometryPrefetcher) can order itself behind them."""
     out = dict(batch)
-    out['input'] = [batch['input'][0].to(device), batch['input'][1].to(device)]
-    out['sdf'] = batch['sdf'].to(device)
-    out['known'] = batch['known'].to(device) if batch.get('known') is not None else None
-    out['hierarchy'] = [h.to(device) for h in batch['hierarchy']] if batch.get('hierarchy') is not None else None
+    mv = lambda t: t.to(device, non_blocking=non_blocking)
+    out['input'] = [mv(batch['input'][0]), mv(batch['input'][1])]
+    out['sdf'] = mv(batch['sdf'])
+    out['known'] = mv(batch['known']) if batch.get('known') is not None else None
+    out['hierarchy'] = [mv(h) for h in batch['hierarchy']] if batch.get('hierarchy') is not None else None
+    if record_ready and torch.device(device).type == 'cuda':
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(torch.device(device)))
+        out['ready'] = ev
     return out
 
 
@@ -230,6 +236,14 @@ class GeometryPrefetcher(object):
         plan = StepPlan()
         plan.batch, plan.loss_weights = batch, np.array(loss_weights, copy=True)
         known = batch['known'] if masking else None
+        # the batch may still be in flight on the stream that produced it (non-blocking H2D copies, a device-side
+        # collate): order the prefetch stream behind it — batch['ready'] (a torch.cuda.Event recorded by the producer,
+        # e.g. to_device(..., record_ready=True)) if present, else the current stream of the calling thread
+        ready = batch.get('ready') if isinstance(batch, dict) else None
+        if ready is not None:
+            self.stream.wait_event(ready)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.device(dev), torch.cuda.stream(self.stream), lane(1):
             plan.targets, plan.weights = loss_util.compute_targets_and_weights(
                 batch['sdf'], batch['hierarchy'], nl, trunc, masking, known, wgeo, batch['input'][0])
@@ -329,6 +343,11 @@ def train_step(model, optimizer, batch, loss_weights, num_hierarchy_levels=4, tr
 
     optimizer.zero_grad(set_to_none=True)
     if teacher_forced and prefetch is not None:
+        if tuple(prefetch.args) != (num_hierarchy_levels, truncation, use_loss_masking, weight_missing_geo):
+            # the plan's targets / weights were built with the prefetcher's own settings
+            raise ValueError('GeometryPrefetcher was built with (levels, truncation, masking, weight_missing_geo) = %r '
+                             'but train_step was called with %r' % (tuple(prefetch.args), (
+                                 num_hierarchy_levels, truncation, use_loss_masking, weight_missing_geo)))
         plan = prefetch.take(batch, loss_weights)
         prefetch.announce(next_batch, loss_weights)
         (tgt_sdf, tgt_occs, tgt_hier), weights = plan.targets, plan.weights
@@ -389,3 +408,481 @@ def get_loss_weights(it, num_hierarchy_levels, num_iters_per_level, factor_l1_lo
         l1_weight = 1.0
     w[-1] = l1_weight
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Flat-buffer Adam + the whole training step as a replayed HIP graph (capacity mode, scn/capacity.py)
+# ---------------------------------------------------------------------------------------------------------------
+def genmodel_segments(model):
+    """Parameter segments of a GenModel in the order the optimizer lays them out: the encoder (always reached), one
+    per Refinement and the SurfacePrediction — a generative stage without input sites leaves its parameters without a
+    gradient in the reference (torch/model.py:211, 260), which Adam then skips."""
+    segs = [('encoder', list(model.encoder.parameters()))]
+    for h, r in enumerate(model.refinement):
+        segs.append(('refinement.%d' % h, list(r.parameters())))
+    segs.append(('surfacepred', list(model.surfacepred.parameters())))
+    seen = set(id(p) for _, ps in segs for p in ps)
+    rest = [p for p in model.parameters() if id(p) not in seen]
+    if rest:
+        segs[0] = ('encoder', segs[0][1] + rest)
+    return segs
+
+
+class FlatAdam(object):
+    """Adam (torch/train.py:81) over ONE flat buffer: every parameter becomes a view of `flat_p`, gradients / moments
+    live in `flat_g` / `flat_m` / `flat_v` with the same layout, and a step is one launch (sgnn_adam_flat) instead
+    of torch's eight multi-tensor launches + host list walk.  Segments (see genmodel_segments) carry torch's "skip a
+    parameter without gradient" rule to the device: a segment is updated iff it was reached this step.  Same update
+    rule as torch.optim.Adam (bias-corrected, eps outside the square root, L2 weight decay added to the gradient);
+    state_dict() / load_state_dict() speak torch.optim.Adam's format, so checkpoints move both ways."""
+
+    def __init__(self, segments, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if segments and not isinstance(segments[0], (tuple, list)):
+            segments = [('all', list(segments))]
+        self.segments = [(name, [p for p in ps if p.requires_grad]) for name, ps in segments]
+        self.params = [p for _, ps in self.segments for p in ps]
+        assert self.params and len(self.segments) <= 8
+        dev, dt = self.params[0].device, torch.float32
+        self.numel = sum(p.numel() for p in self.params)
+        nseg = len(self.segments)
+        self.flat_p = torch.empty(self.numel, dtype=dt, device=dev)
+        self.flat_g = torch.zeros(self.numel + 8, dtype=dt, device=dev)       # tail: per-segment "reached" flags
+        self.flat_m = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.flat_v = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.steps = torch.zeros(8, dtype=dt, device=dev)                     # per-segment update counters
+        self.lr_dev = torch.full((1,), float(lr), dtype=dt, device=dev)
+        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.bounds, self.views_g, o = [], [], 0
+        with torch.no_grad():
+            for _, ps in self.segments:
+                b = o
+                for p in ps:
+                    n = p.numel()
+                    self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                    p.data = self.flat_p[o:o + n].view_as(p)
+                    self.views_g.append(self.flat_g[o:o + n].view_as(p))
+                    o += n
+                self.bounds.append((b, o))
+        self.flags = self.flat_g[self.numel:self.numel + nseg]
+        self._direct = set()
+        self.param_groups = [{'lr': float(lr), 'params': self.params}]        # what schedulers / loggers look at
+
+    # -- learning rate (device scalar: a captured graph picks up changes) -------------------------------------
+    def set_lr(self, lr):
+        self.param_groups[0]['lr'] = float(lr)
+        self.lr_dev.fill_(float(lr))
+
+    # -- gradient plumbing ---------------------------------------------------------------------------------
+    def bind_programs(self, model):
+        """Parameters of compiled native programs get their gradient written straight into flat_g by the program's
+        backward pass (scn/program.py).  Call after the model's first forward pass (programs compile lazily)."""
+        from .scn import program as P_
+        by_id = dict((id(p), v) for p, v in zip(self.params, self.views_g))
+        for prog in P_.programs_of(model):
+            for (m, nm), trainable in zip(prog.slots, prog.grad_slot):
+                p = getattr(m, nm)
+                if trainable and id(p) in by_id:
+                    p._sgnn_flat_grad = by_id[id(p)]
+                    p.grad = by_id[id(p)]
+                    self._direct.add(id(p))
+
+    def unbind(self):
+        for p in self.params:
+            if id(p) in self._direct:
+                del p._sgnn_flat_grad
+                p.grad = None
+        self._direct = set()
+
+    def zero_grad(self):
+        """Before backward: autograd-delivered gradients start from None (set_to_none), direct ones are overwritten."""
+        for p in self.params:
+            if id(p) not in self._direct:
+                p.grad = None
+
+    def collect(self):
+        """After backward: copy the autograd-delivered gradients into flat_g (one multi-tensor launch).  Returns the
+        per-segment "some parameter has a gradient" list (host knowledge, exact mode)."""
+        dst, src, reached = [], [], []
+        i = 0
+        for _, ps in self.segments:
+            any_grad = False
+            for p in ps:
+                v = self.views_g[i]
+                i += 1
+                if id(p) in self._direct:
+                    any_grad = True
+                elif p.grad is not None:
+                    any_grad = True
+                    dst.append(v)
+                    src.append(p.grad)
+            reached.append(any_grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return reached
+
+    def _seg_table(self, cnts, use_flags):
+        seg = np.zeros((len(self.segments), 5), dtype=np.int64)
+        for t, (b, e) in enumerate(self.bounds):
+            seg[t, 0], seg[t, 1] = b, e
+            c = cnts[t] if cnts is not None else None
+            seg[t, 2] = 0 if c is None else c.data_ptr()
+            seg[t, 3] = (self.flags.data_ptr() + 4 * t) if use_flags else 0
+            seg[t, 4] = self.steps.data_ptr() + 4 * t
+        return np.ascontiguousarray(seg)
+
+    def step(self, reached=None, cnts=None, status=None, grad_scale=1.0, flags_in_grads=False):
+        """One update from flat_g.  Exactly one of: `reached` (host list of bools per segment, exact mode), `cnts`
+        (device int64[1] row counts per segment or None = always, capacity mode), flags_in_grads (the flags at the tail
+        of flat_g were filled by sgnn_seg_flags and summed by the all-reduce).  status: device int32 status word."""
+        from . import _lib
+        use_flags = flags_in_grads
+        if reached is not None:
+            self.flags.copy_(torch.tensor([1.0 if r else 0.0 for r in reached], dtype=torch.float32), non_blocking=True)
+            use_flags = True
+        seg = self._seg_table(cnts, use_flags)
+        _lib.call('sgnn_adam_flat', self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                  self.flat_v.data_ptr(), self.numel, seg.ctypes.data, len(self.segments), self.lr_dev.data_ptr(),
+                  self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale),
+                  None if status is None else status.data_ptr())
+
+    def write_flags(self, cnts):
+        """flags tail of flat_g from the device row counts (before a data-parallel all-reduce of flat_g)."""
+        from . import _lib
+        ptrs = np.ascontiguousarray(np.array([0 if c is None else c.data_ptr() for c in cnts], dtype=np.int64))
+        _lib.call('sgnn_seg_flags', ptrs.ctypes.data, len(self.segments), self.flags.data_ptr())
+
+    # -- torch.optim.Adam checkpoint format ------------------------------------------------------------------
+    def state_dict(self):
+        steps = self.steps.cpu().tolist()
+        state, i, o = {}, 0, 0
+        for t, (_, ps) in enumerate(self.segments):
+            for p in ps:
+                n = p.numel()
+                if steps[t] > 0:
+                    state[i] = {'step': torch.tensor(float(steps[t])), 'exp_avg': self.flat_m[o:o + n].view_as(p).clone(),
+                                'exp_avg_sq': self.flat_v[o:o + n].view_as(p).clone()}
+                i += 1
+                o += n
+        group = {'lr': self.param_groups[0]['lr'], 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        self.set_lr(g['lr'])
+        self.betas, self.eps, self.weight_decay = (float(g['betas'][0]), float(g['betas'][1])), float(g['eps']), float(g['weight_decay'])
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        steps = [0.0] * 8
+        i, o = 0, 0
+        for t, (_, ps) in enumerate(self.segments):
+            for p in ps:
+                n = p.numel()
+                st = sd['state'].get(i)
+                if st is not None:
+                    self.flat_m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                    self.flat_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    steps[t] = max(steps[t], float(st['step']))
+                i += 1
+                o += n
+        self.steps.copy_(torch.tensor(steps, dtype=torch.float32))
+
+
+class GraphStep(object):
+    """The training step of torch/train.py:245-268 (targets, forward, loss, backward, Adam) in CAPACITY MODE, captured
+    once in a HIP graph and replayed: no host read-back, no Python, no per-kernel launch cost in the steady state.
+
+        step = GraphStep(model, lr=1e-3)
+        for batch in loader:                       # device-resident dicts in scene_dataloader.collate layout
+            loss = step(batch, loss_weights)       # device scalar (valid until the next call)
+
+    Life cycle per loss-weight pattern: (1) one classic step with read-backs, which also measures every level's row
+    count -> capacities = counts x headroom (scn.capacity.Capacity); (2) one eager capacity-mode step (warm-up: lazy
+    allocations, program compilation); (3) capture; (4) replay per batch — the batch is copied into the graph's static
+    input buffers first (or written there directly: `buffers()`).  Every step's status word is checked one step late:
+    after a capacity overflow (SGNN_STATUS_OVERFLOW: the step did not update the parameters) the capacities grow, the
+    affected batch is run again and the graph is re-captured.  Masks are the reference's (sigmoid(pred) > 0.5) unless
+    teacher_forced.  grad_sync (data parallel): called between backward and the optimizer with the flat gradient
+    buffer; the step then replays as two graphs around it.  BatchNorm running statistics of an overflowed step are not
+    rolled back (they see that batch twice; weights are exact)."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, num_hierarchy_levels=4, truncation=3.0, use_log_transform=True,
+                 weight_missing_geo=5.0, use_loss_masking=True, teacher_forced=False, headroom=1.3, use_graph=True,
+                 grad_sync=None, world_size=1, optimizer=None):
+        self.model = model
+        self.opt = optimizer if optimizer is not None else FlatAdam(genmodel_segments(model), lr=lr, weight_decay=weight_decay)
+        self.args = (num_hierarchy_levels, truncation, use_log_transform, weight_missing_geo, use_loss_masking)
+        self.teacher_forced, self.headroom, self.use_graph = teacher_forced, float(headroom), bool(use_graph)
+        self.grad_sync, self.world_size = grad_sync, int(world_size)
+        self.capacity = None
+        self.key = None                 # (which stages run, batch shape) the capacities / static buffers belong to
+        self.weights = None             # the loss weights the captured graph has baked in
+        self.stage = 0                  # 0: needs a probe step, 1: needs the eager capacity step, 2: captured
+        self.graphs = None
+        self.static = None
+        self.loss = None
+        self.losses = None
+        self.pending = []               # [(event, pinned status, batch, loss_weights)] of issued capacity steps
+        self.stats = {'probe_steps': 0, 'eager_steps': 0, 'captures': 0, 'replays': 0, 'overflows': 0}
+        self._pins, self._npin = None, 0
+        self._bound = False
+
+    # -- pieces --------------------------------------------------------------------------------------------
+    def _probe(self, batch, loss_weights):
+        """Classic step (read-backs) that also sizes the capacities."""
+        from .scn import metadata as MD
+        nl, trunc, use_log, wgeo, masking = self.args
+        self.opt.unbind()
+        self._bound = False
+        MD.COUNT_LOG = []
+        try:
+            self.opt.zero_grad()
+            known = batch['known'] if masking else None
+            (tsdf, toccs, thier), weights = loss_util.compute_targets_and_weights(
+                batch['sdf'], batch['hierarchy'], nl, trunc, masking, known, wgeo, batch['input'][0])
+            B = int(batch['sdf'].shape[0])
+            out_sdf, out_occs = self.model(batch['input'], loss_weights, batch_size=B,
+                                           teacher=toccs if self.teacher_forced else None)
+            loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
+                                                  batch['input'][0], masking, known, weights=weights)
+            loss.backward()
+            reached = self.opt.collect()
+            if self.grad_sync is not None:
+                self.opt.flags.copy_(torch.tensor([1.0 if r else 0.0 for r in reached], dtype=torch.float32))
+                self.grad_sync(self.opt.flat_g)
+                self.opt.step(flags_in_grads=True, grad_scale=1.0 / self.world_size)
+            else:
+                self.opt.step(reached=reached)
+            log = MD.COUNT_LOG
+        finally:
+            MD.COUNT_LOG = None
+        from .scn.capacity import Capacity
+        dev = batch['sdf'].device
+        runs = self.model._runs(loss_weights)
+        n_gen = 1 + sum(1 for r in runs[:-1] if r)      # the coarse compaction + one per running refinement
+        new = Capacity.from_log(dev, log, self.headroom, n_gen=n_gen)
+        if self.capacity is not None:        # never shrink below what an earlier batch needed
+            old = self.capacity
+            new = Capacity(dev, max(new.input_rows, old.input_rows),
+                           [max(a, b) for a, b in zip(new.enc, old.enc)] if len(old.enc) == len(new.enc) else new.enc,
+                           [(max(k, ko), [max(a, b) for a, b in zip(p, po)]) for (k, p), (ko, po) in zip(new.gen, old.gen)]
+                           if len(old.gen) == len(new.gen) else new.gen)
+        self.capacity = new
+        self.stats['probe_steps'] += 1
+        self.loss, self.losses = loss.detach(), losses
+        return self.loss
+
+    def _make_static(self, batch):
+        cap = self.capacity
+        dev = batch['sdf'].device
+        locs, feats = batch['input']
+        st = {'locs': torch.zeros(cap.input_rows, 4, dtype=torch.int64, device=dev),
+              'feats': torch.zeros(cap.input_rows, feats.shape[1], dtype=torch.float32, device=dev),
+              'sdf': torch.empty_like(batch['sdf']),
+              'known': torch.empty_like(batch['known']) if batch.get('known') is not None else None,
+              'hierarchy': [torch.empty_like(h) for h in batch['hierarchy']]}
+        st['locs']._sgnn_cnt = cap.input_cnt()
+        self.static = st
+
+    def buffers(self):
+        """The graph's static input buffers (a loader may write batches straight into them, then call step(None))."""
+        return self.static
+
+    def _load(self, batch):
+        st = self.static
+        locs, feats = batch['input']
+        n = int(locs.shape[0])
+        self.capacity.set_input_rows(n)
+        st['locs'][:n].copy_(locs, non_blocking=True)
+        st['feats'][:n].copy_(feats, non_blocking=True)
+        st['sdf'].copy_(batch['sdf'], non_blocking=True)
+        if st['known'] is not None:
+            st['known'].copy_(batch['known'], non_blocking=True)
+        for d, s_ in zip(st['hierarchy'], batch['hierarchy']):
+            d.copy_(s_, non_blocking=True)
+
+    def _fwd_bwd(self, loss_weights):
+        """Capacity-mode targets + forward + loss + backward on the static buffers (capturable)."""
+        from .scn.metadata import runtime
+        nl, trunc, use_log, wgeo, masking = self.args
+        st, cap = self.static, self.capacity
+        rt = runtime(st['sdf'].device)
+        rt.state[1:2].zero_()                       # status word of THIS step
+        self.opt.zero_grad()
+        known = st['known'] if masking else None
+        (tsdf, toccs, thier), weights = loss_util.compute_targets_and_weights(
+            st['sdf'], st['hierarchy'], nl, trunc, masking, known, wgeo, st['locs'])
+        B = int(st['sdf'].shape[0])
+        out_sdf, out_occs = self.model([st['locs'], st['feats']], loss_weights, batch_size=B, capacity=cap,
+                                       teacher=toccs if self.teacher_forced else None)
+        loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
+                                              st['locs'], masking, known, weights=weights)
+        loss.backward()
+        self.opt.collect()           # gradients autograd delivered (dense bottleneck); program gradients are in flat_g already
+        return loss.detach(), losses, rt
+
+    def _seg_cnts(self, loss_weights):
+        """Device row count deciding whether a segment was reached: encoder always; Refinement h <- kept rows of
+        generative level h; SurfacePrediction <- kept rows of the last level."""
+        cap = self.capacity
+        R = len(self.model.refinement)
+        cnts = [None]
+        for h in range(R + 1):
+            cnts.append(cap.kept2(h)[0:1] if h < len(cap.gen) else None)
+        return cnts[:len(self.opt.segments)]
+
+    def _active_segments(self, loss_weights):
+        """Segments whose stage runs at all with these loss weights (static per graph)."""
+        runs = self.model._runs(loss_weights)
+        return [True] + [bool(r) for r in runs]
+
+    def _opt_step(self, loss_weights, rt):
+        cnts = self._seg_cnts(loss_weights)
+        active = self._active_segments(loss_weights)
+        # a stage that does not run at all has no gradient: park its segment on a zero count
+        zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
+        cnts = [(c if a else zero) for c, a in zip(cnts, active)]
+        if self.grad_sync is not None:
+            self.opt.step(flags_in_grads=True, status=rt.status32, grad_scale=1.0 / self.world_size)
+        else:
+            self.opt.step(cnts=cnts, status=rt.status32)
+
+    def _capacity_step_eager(self, loss_weights):
+        loss, losses, rt = self._fwd_bwd(loss_weights)
+        if self.grad_sync is not None:
+            cnts = self._seg_cnts(loss_weights)
+            active = self._active_segments(loss_weights)
+            zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
+            self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)])
+            self.grad_sync(self.opt.flat_g)
+        self._opt_step(loss_weights, rt)
+        return loss, losses, rt
+
+    def _issue_status(self, rt, batch, loss_weights):
+        if self._pins is None:
+            self._pins = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(4)]
+        pin = self._pins[self._npin % len(self._pins)]
+        self._npin += 1
+        pin.copy_(rt.state[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(rt.device))
+        self.pending.append((ev, pin, batch, loss_weights))
+
+    def _check(self, keep):
+        """Retire all but the `keep` newest issued steps; returns the batches whose step overflowed."""
+        redo = []
+        while len(self.pending) > keep:
+            ev, pin, batch, lw = self.pending.pop(0)
+            ev.synchronize()
+            word = int(pin[0]) & 0xFFFFFFFF
+            if word & 4 and not (word & 3):
+                redo.append((batch, lw))
+            elif word:
+                from .scn.metadata import runtime
+                runtime(self.static['sdf'].device).raise_status(word)
+        return redo
+
+    def _capture(self, loss_weights):
+        from .scn.metadata import runtime
+        dev = self.static['sdf'].device
+        rt = runtime(dev)
+        torch.cuda.synchronize(dev)
+        if self.grad_sync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, losses, _ = self._fwd_bwd(loss_weights)
+                self._opt_step(loss_weights, rt)
+            self.graphs = (g,)
+        else:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                loss, losses, _ = self._fwd_bwd(loss_weights)
+                cnts = self._seg_cnts(loss_weights)
+                active = self._active_segments(loss_weights)
+                zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
+                self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)])
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._opt_step(loss_weights, rt)
+            self.graphs = (g1, g2)
+        self._graph_out = (loss, losses)
+        # everything the captured kernels touch outside the graph's own pool must outlive the graph
+        self._keep = (rt.ws, getattr(rt, '_side_ws', None), getattr(rt, '_volume', None), self.capacity, self.static)
+        self.stats['captures'] += 1
+
+    def _replay(self):
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            self.grad_sync(self.opt.flat_g)
+            self.graphs[1].replay()
+        self.stats['replays'] += 1
+        return self._graph_out
+
+    # -- the step -------------------------------------------------------------------------------------------
+    def __call__(self, batch, loss_weights):
+        loss_weights = np.asarray(loss_weights, dtype=np.float32)
+        key = (tuple(bool(w > 0) for w in loss_weights), tuple(batch['sdf'].shape))
+        wkey = tuple(float(w) for w in loss_weights)
+        if key != self.key:                          # new curriculum stage / batch shape: re-size and re-capture
+            self._drain()
+            self.key, self.stage, self.graphs, self.capacity = key, 0, None, None
+        if wkey != self.weights:                     # the loss weights are baked into the captured launches
+            self._drain()
+            self.weights, self.graphs = wkey, None
+        if self.stage == 0:
+            self._probe(batch, loss_weights)
+            self.stage = 1
+            return self.loss
+        n_in = int(batch['input'][0].shape[0])
+        if n_in > self.capacity.input_rows:          # known on the host before anything is launched
+            self._drain()
+            self.graphs = None
+            self._probe(batch, loss_weights)
+            self.stage = 1
+            return self.loss
+        if self.stage == 1:
+            self._make_static(batch)
+        self._load(batch)
+        from .scn.metadata import runtime
+        rt = runtime(batch['sdf'].device)
+        if not self._bound:                          # programs were compiled by the probe step
+            self.opt.bind_programs(self.model)
+            self._bound = True
+        if self.stage == 1:
+            loss, losses, _ = self._capacity_step_eager(loss_weights)
+            self.stats['eager_steps'] += 1
+            self.stage = 2 if not self.use_graph else 3
+        elif self.stage == 2:                        # use_graph=False: eager capacity steps forever (tests, profiling)
+            loss, losses, _ = self._capacity_step_eager(loss_weights)
+            self.stats['eager_steps'] += 1
+        else:
+            if self.graphs is None:
+                self._capture(loss_weights)
+            loss, losses = self._replay()
+        self._issue_status(rt, batch, loss_weights)
+        self.loss, self.losses = loss, losses
+        redo = self._check(1)
+        if redo:
+            self._overflow(redo)
+        return self.loss
+
+    def _drain(self):
+        redo = self._check(0)
+        if redo:
+            self._overflow(redo)
+
+    def _overflow(self, redo):
+        """Some issued step overflowed a capacity (it left the parameters untouched): finish what is in flight, grow,
+        run the affected batches again through the classic path, re-capture on the next call."""
+        redo = redo + self._check(0)
+        self.stats['overflows'] += len(redo)
+        self.graphs = None
+        self.capacity = self.capacity.grown(1.5)
+        for batch, lw in redo:
+            self._probe(batch, lw)
+        self.stage = 1
+
+
+SLOT_ZERO = 63      # a count slot that is always 0 (Capacity.counts is zero-initialised and nothing writes there)

@@ -309,7 +309,7 @@ def test_dense_volume_rulebook_equals_hash_rulebook(order, volume_blocks):
     vol = torch.full((max(entries, 1),), -1, dtype=torch.int32, device=dev)
     out = torch.full_like(ref, 12345)
     _lib.call('sgnn_rulebook_subm3_dense', keys.data_ptr(), vals.data_ptr(), cap, coords.data_ptr(), g.n, dims[0],
-              dims[1], dims[2], vol.data_ptr(), entries, out.data_ptr(), g.ld)
+              dims[1], dims[2], vol.data_ptr(), entries, out.data_ptr(), g.ld, None)
     assert torch.equal(out, ref)
     assert int((vol != -1).sum()) == 0
 

@@ -94,6 +94,25 @@ class TSDFEncoder(nn.Module):  # model.py:69-167
         return x, torch.cat([self.occpred(x), self.sdfpred(x)], 1), skips
 
 
+# Test hooks (parity tests only): MASK_LOG, when a list, receives every generative mask in the order the forward pass
+# takes them; FORCED_MASKS, when a non-empty list, supplies them instead of `sigmoid(logit) > 0.5` (consumed front to
+# back).  Lets the fp64 evaluation of the model, and the HIP model through its `teacher=` volumes, walk exactly the
+# site lists the fp32 oracle decided on, so that 100 % of the sites are comparable.
+MASK_LOG = None
+FORCED_MASKS = None
+
+
+def _occupied(logit):  # model.py:233, 322
+    if FORCED_MASKS:
+        mask = FORCED_MASKS.pop(0)
+        assert mask.shape == logit.shape
+    else:
+        mask = torch.sigmoid(logit) > 0.5
+    if MASK_LOG is not None:
+        MASK_LOG.append(mask.clone())
+    return mask
+
+
 def expand_children(locs, feats):  # model.py:192-207
     offs = torch.tensor([[dz, dy, dx, 0] for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)], dtype=locs.dtype)
     nxt = locs.unsqueeze(1).repeat(1, 8, 1)
@@ -126,7 +145,7 @@ class Refinement(nn.Module):  # model.py:169-247
         locs_unfilt, feats = expand_children(locs_in, f)
         y = self.n3(self.n2(self.n1(self.n0([locs_unfilt, feats]))))
         out = torch.cat([self.linear(y), self.linearsdf(y)], 1)
-        mask = torch.sigmoid(out[:, 0]) > 0.5
+        mask = _occupied(out[:, 0])
         parts = ([y[mask]] if self.pass_feats else []) + ([out[mask]] if self.pass_occ else [])
         return [locs_unfilt[mask], torch.cat(parts, 1)], [locs_unfilt, out]
 
@@ -178,7 +197,7 @@ class GenModel(nn.Module):  # model.py:276-416
         bcol = torch.arange(B).view(B, 1, 1).repeat(1, d0 * d1 * d2, 1)
         locs_unfilt = torch.cat([vox, bcol], 2).view(-1, 4)
         occ_rows = coarse_occ.permute(0, 2, 3, 4, 1).contiguous().view(-1, 2)
-        mask = torch.sigmoid(occ_rows[:, 0]) > 0.5
+        mask = _occupied(occ_rows[:, 0])
         parts = []
         if self.pass_occ:
             parts.append(occ_rows[mask])

@@ -158,6 +158,22 @@ SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int6
   return SGNN_OK;
 }
 
+// Capacity mode: tables are sized for the level's capacity, but only the entries of rows [0, roundup256(live rows)) are
+// ever read (the convolution kernels exit per 256-row tile past the live count), so padding / pre-fill writes stop
+// there instead of costing capacity-proportional traffic.
+__device__ __forceinline__ int64_t pad_end(int64_t n, int64_t ld) {
+  const int64_t e = (n + 255) & ~int64_t(255);
+  return e < ld ? e : ld;
+}
+
+// rows x [0, pad_end(n)) entries of an offset-major int32 table := -1
+__global__ __launch_bounds__(256) void k_fill_rows_dyn(int32_t *__restrict__ t, int rows, int64_t ld, int64_t n,
+                                                      const int64_t *n_dev) {
+  const int64_t end = pad_end(sgnn_dyn_n(n, n_dev), ld);
+  const int64_t total = end * rows, stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) t[(g / end) * ld + (g % end)] = -1;
+}
+
 // ---------------------------------------------------------------------------
 // 3x3x3 submanifold rulebook: nbr[k][j].  One thread per site.  The rulebook is symmetric —
 // nbr[k][j] = i  <=>  nbr[26-k][i] = j — so only the 13 "lower" offsets are probed in the hash; each hit
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
                                                        int32_t *__restrict__ nbr, int64_t ld, const int64_t *n_dev) {
   n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= ld) return;
+  if (j >= pad_end(n, ld)) return;
   if (j >= n) {  // padding entries: the conv kernels rely on them being -1 (rows 14..26 come from the memset)
 #pragma unroll
     for (int k = 0; k <= 13; ++k) nbr[(int64_t)k * ld + j] = -1;
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__re
                                                            const int64_t *n_dev) {
   n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= ld) return;
+  if (j >= pad_end(n, ld)) return;
   if (j >= n) {                                 // padding entries: the conv kernels rely on them being -1
 #pragma unroll
     for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
@@ -562,7 +578,11 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
   }
-  SGNN_HIP_TRY(hipMemsetAsync(nbr + 14 * ld, 0xFF, (size_t)(13 * ld) * sizeof(int32_t), (hipStream_t)stream));
+  if (n_dev)      // capacity mode: pre-fill only what the live rows can reach
+    hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(13 * n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       nbr + 14 * ld, 13, ld, n, n_dev);
+  else
+    SGNN_HIP_TRY(hipMemsetAsync(nbr + 14 * ld, 0xFF, (size_t)(13 * ld) * sizeof(int32_t), (hipStream_t)stream));
   hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
   SGNN_CHECK_LAUNCH();
@@ -1067,7 +1087,8 @@ __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ f
   nc = sgnn_dyn_n(nc, nc_dev);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (; i < ldf; i += stride) {
+  const int64_t iend = pad_end(nf, ldf);
+  for (; i < iend; i += stride) {
     if (i >= nf) {  // padding
 #pragma unroll
       for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = -1;
@@ -1090,7 +1111,10 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
   SGNN_CHECK_ARG(nf >= 0 && nc >= 0 && ldc >= nc && ldf >= nf);
   if (nc > 0) {
     SGNN_CHECK_ARG(children);
-    SGNN_HIP_TRY(hipMemsetAsync(children, 0xFF, (size_t)(8 * ldc) * sizeof(int32_t), s));
+    if (nc_dev)
+      hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(8 * nc, 256, 4096)), dim3(256), 0, s, children, 8, ldc, nc, nc_dev);
+    else
+      SGNN_HIP_TRY(hipMemsetAsync(children, 0xFF, (size_t)(8 * ldc) * sizeof(int32_t), s));
   }
   if (nf == 0) return SGNN_OK;
   SGNN_CHECK_ARG(fine_coords && parent && ptable && children);

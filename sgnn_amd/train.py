@@ -760,22 +760,25 @@ class GraphStep(object):
         return loss, losses, rt
 
     def _issue_status(self, rt, batch, loss_weights):
-        if self._pins is None:
-            self._pins = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(4)]
+        if self._pins is None:      # [status word | the capacity's 64 live row counts], per in-flight step
+            self._pins = [torch.zeros(65, dtype=torch.int64).pin_memory() for _ in range(4)]
         pin = self._pins[self._npin % len(self._pins)]
         self._npin += 1
-        pin.copy_(rt.state[1:2], non_blocking=True)
+        pin[0:1].copy_(rt.state[1:2], non_blocking=True)
+        pin[1:].copy_(self.capacity.counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(rt.device))
-        self.pending.append((ev, pin, batch, loss_weights))
+        self.pending.append((ev, pin, batch, loss_weights, self.capacity))
 
     def _check(self, keep):
         """Retire all but the `keep` newest issued steps; returns the batches whose step overflowed."""
         redo = []
         while len(self.pending) > keep:
-            ev, pin, batch, lw = self.pending.pop(0)
+            ev, pin, batch, lw, cap = self.pending.pop(0)
             ev.synchronize()
             word = int(pin[0]) & 0xFFFFFFFF
+            if cap is self.capacity:
+                self._live = pin[1:].tolist()
             if word & 4 and not (word & 3):
                 redo.append((batch, lw))
             elif word:
@@ -866,7 +869,43 @@ class GraphStep(object):
         redo = self._check(1)
         if redo:
             self._overflow(redo)
+        else:
+            self._maybe_replan()
         return self.loss
+
+    def _maybe_replan(self):
+        """Row counts drift while the weights train (the masks are predictions).  From the live counts that ride back
+        with every step's status word: re-size before a level overflows (live > 92 % of its capacity) and when the plan
+        has become much larger than needed (kernels are launched for the capacities; > 1.5x the needed rows for 3 checks
+        in a row), then warm up + re-capture on the next call."""
+        live, cap = getattr(self, '_live', None), self.capacity
+        if live is None or self.stage < 2:
+            return
+        from .scn.capacity import Capacity, ENC0, _round
+        need = lambda n: _round(max(int(n * self.headroom), 1024))
+        pairs = [(live[0], cap.input_rows)] + [(live[ENC0 + l], c) for l, c in enumerate(cap.enc)]
+        for g, (k, pyr) in enumerate(cap.gen):
+            b = cap.gen_base(g)
+            pairs.append((live[b], k))
+            pairs += [(live[b + 2 + l], c) for l, c in enumerate(pyr)]
+        tight = any(n > 0.92 * c for n, c in pairs)
+        have, want = sum(c for _, c in pairs), sum(need(n) for n, _ in pairs)
+        self._loose = (getattr(self, '_loose', 0) + 1) if have > 1.5 * want else 0
+        if not (tight or self._loose >= 3):
+            return
+        self._loose = 0
+        self._drain()
+        if self.stage < 2:                     # the drain found an overflow and re-planned already
+            return
+        grow = 1.25 if tight else 1.0          # moving up: leave more room than the steady-state headroom
+        nn = lambda n: _round(max(int(n * self.headroom * grow), 1024))
+        b = cap.gen_base
+        self.capacity = Capacity(cap.device, nn(live[0]), [nn(live[ENC0 + l]) for l in range(len(cap.enc))],
+                                 [(nn(live[b(g)]), [nn(live[b(g) + 2 + l]) for l in range(len(pyr))])
+                                  for g, (k, pyr) in enumerate(cap.gen)])
+        self._live = None
+        self.graphs, self.stage = None, 1
+        self.stats['replans'] = self.stats.get('replans', 0) + 1
 
     def _drain(self):
         redo = self._check(0)

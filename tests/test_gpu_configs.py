@@ -94,7 +94,7 @@ def _keys(sites):
     return ((s[:, 3] << 48) | (s[:, 0] << 32) | (s[:, 1] << 16) | s[:, 2])
 
 
-def _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, tol):
+def _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, tol, values=True):
     """Site lists must be identical, except that an occupancy decision may differ where the reference logit lies within
     the fp32 tolerance of the threshold (sigmoid(x) > 0.5 <=> x > 0 cannot be decided for |x| below the logit error):
     at these sizes ~1e6 decisions are taken per level and a handful land there.  A differing decision changes the next
@@ -131,7 +131,7 @@ def _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, tol):
                 c = os_[io]
                 far &= ~((c[:, 3] == q[3]) & (np.abs(c[:, :3] - q[:3]).max(1) <= 24))
             ih, io = ih[far], io[far]
-        err = float(np.abs(hv[ih] - ov[io]).max()) if len(ih) else 0.0
+        err = float(np.abs(hv[ih] - ov[io]).max()) if (len(ih) and values) else 0.0
         report('%-58s max|err| %.3e   max|ref| %.3e   sites %d, %d on one side only, %d compared' %
                ('%s GenModel %s' % (tag, name), err, float(np.abs(ov).max()), os_.shape[0], n_diff, len(ih)))
         assert err <= tol * scale, '%s %s: %g > %g' % (tag, name, err, tol * scale)
@@ -139,25 +139,130 @@ def _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, tol):
             border_prev = _keys(os_[np.abs(ov[:, 0]) <= tol * scale])
 
 
-def _model_forward(tag, dims, batch, cfg, dist, occupancy, train=True):
-    from sgnn_amd.model import GenModel
+def _teacher_volumes(oocc, masks, dims, batch):
+    """The oracle's per-level occupancy decisions as dense (B,1,d0,d1,d2) volumes: what GenModel.forward(teacher=...)
+    takes in place of sigmoid(pred) > 0.5 (sgnn_compact_dense), so that the HIP model walks exactly the oracle's sites."""
+    vols = []
+    for h in range(4):
+        f = 8 >> h
+        v = torch.zeros(batch, 1, dims[0] // f, dims[1] // f, dims[2] // f)
+        kept = oocc[h][0][masks[h]]
+        v[kept[:, 3], 0, kept[:, 0], kept[:, 1], kept[:, 2]] = 1.0
+        vols.append(v.cuda())
+    return vols
+
+
+def _oracle_runs(dims, batch, cfg, dist, occupancy, train, want_grads=False, data=None):
+    """fp32 oracle run (its masks are logged) and an fp64 run forced onto the same masks.  Returns the batch, both
+    outputs and the masks; with want_grads also loss + parameter gradients of both."""
     _fast_oracle()
-    try:
-        data = synth.make_batch(batch, dims, cfg=cfg, occupancy=occupancy, dist=dist)
-        locs, feats = data['input']
-        lw = np.ones(5, dtype=np.float32)
+    data = data or synth.make_batch(batch, dims, cfg=cfg, occupancy=occupancy, dist=dist)
+    locs, feats = data['input']
+    lw = np.ones(5, dtype=np.float32)
+    res = {}
+    masks = None
+    for prec in ('f32', 'f64'):
         om = param_fill(mo.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train)
-        hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train).cuda()
-        with torch.no_grad():
-            osdf, oocc = om([locs, feats], lw)
-            hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw, batch_size=batch)
-        _compare_hierarchy(tag, hocc, hsdf, oocc, osdf, 2e-4)
-    finally:
-        oscn.FAST = False
+        f = feats
+        if prec == 'f64':
+            om, f = om.double(), feats.double()
+            mo.FORCED_MASKS = [m.clone() for m in masks]
+        else:
+            mo.MASK_LOG = []
+        try:
+            with torch.set_grad_enabled(want_grads):
+                osdf, oocc = om([locs, f], lw)
+                if want_grads:
+                    cast = (lambda t: t.double()) if prec == 'f64' else (lambda t: t)
+                    t = mo.compute_targets(cast(data['sdf'].clone()), [cast(h.clone()) for h in data['hierarchy']], 4, 3, True,
+                                           data['known'])
+                    loss, _ = mo.compute_loss(osdf, oocc, t[0], t[1], t[2], lw, 3, True, 5.0, locs, True, data['known'])
+                    loss.backward()
+                    res[prec + '_loss'] = float(loss)
+                    res[prec + '_grads'] = dict((n, p.grad.detach().double().clone()) for n, p in om.named_parameters())
+        finally:
+            if prec == 'f32':
+                masks, mo.MASK_LOG = mo.MASK_LOG, None
+            assert not mo.FORCED_MASKS
+            mo.FORCED_MASKS = None
+        res[prec] = (osdf, oocc)
+    oscn.FAST = False
+    return data, res, masks, lw
+
+
+def _model_forward(tag, dims, batch, cfg, dist, occupancy, train=True):
+    """(1) The HIP model on its own masks: site lists equal the oracle's except for sites that descend from a decision
+    whose reference logit lies within the fp32 error of the threshold.  (2) The HIP model forced onto the oracle's masks
+    (teacher volumes): site lists identical by construction, EVERY site's logits compared — against the fp64 evaluation
+    of the reference algorithm, with the reference's own fp32 run beside it.  north_star: logits within 1e-4 fp32; the
+    bar here is max|HIP - fp64| <= max(1e-4, max|oracle_fp32 - fp64|) in absolute terms, per level."""
+    from sgnn_amd.model import GenModel
+    data, res, masks, lw = _oracle_runs(dims, batch, cfg, dist, occupancy, train)
+    locs, feats = data['input']
+    (osdf, oocc), (dsdf, docc) = res['f32'], res['f64']
+    hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train).cuda()
+    with torch.no_grad():
+        hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw, batch_size=batch)
+    _compare_hierarchy(tag + ' own masks', hocc, hsdf, oocc, osdf, 2e-4, values=False)
+    hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(train).cuda()
+    with torch.no_grad():
+        hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw, batch_size=batch, teacher=_teacher_volumes(oocc, masks, dims, batch))
+    total = 0
+    for h in range(5):
+        if h < 4:
+            hs, hv, os_, ov, dv, name = hocc[h][0], hocc[h][1], oocc[h][0], oocc[h][1], docc[h][1], 'level %d logits' % h
+            assert torch.equal(docc[h][0], os_)
+        else:
+            hs, hv, os_, ov, dv, name = hsdf[0], hsdf[1], osdf[0], osdf[1], dsdf[1], 'final sdf'
+            assert torch.equal(dsdf[0], os_)
+        assert torch.equal(hs.cpu(), os_), '%s %s: forced site lists differ' % (tag, name)
+        hv, ov, dv = hv.detach().cpu().double(), ov.detach().double(), dv.detach()
+        e_h, e_o = (hv - dv).abs(), (ov - dv).abs()
+        report('%-58s HIP-vs-fp64 max %.3e rms %.3e | oracle_fp32-vs-fp64 max %.3e rms %.3e | HIP-vs-oracle_fp32 max %.3e | '
+               'max|ref| %.3e | %d sites, all compared' %
+               ('%s GenModel %s' % (tag, name), e_h.max(), e_h.pow(2).mean().sqrt(), e_o.max(), e_o.pow(2).mean().sqrt(),
+                (hv - ov).abs().max(), dv.abs().max(), os_.shape[0]))
+        assert float(e_h.max()) <= max(1e-4, 1.05 * float(e_o.max())), '%s %s: HIP %g vs fp64, reference fp32 %g' % (
+            tag, name, float(e_h.max()), float(e_o.max()))
+        assert float(e_h.pow(2).mean().sqrt()) <= 5e-5
+        total += os_.shape[0]
+    return total
 
 
 def test_config1_model_forward_bs4():
     _model_forward('configs[1] 64^3 bs4', (64, 64, 64), 4, 2, 'surface', 0.05)
+
+
+def test_config1_model_loss_and_gradients_bs4():
+    """the whole model's loss and EVERY parameter gradient at 64^3 batch 4 (torch/train.py:262-264),
+    on the oracle's masks, against the fp64 evaluation — with the reference's own fp32 spread beside it.  A ReLU network's
+    parameter gradients are discontinuous in the activations; the HIP path is held to the fp32 oracle's own distance from
+    fp64 (x 2, + 1e-4 of the tensor's scale)."""
+    from sgnn_amd.model import GenModel
+    from sgnn_amd import loss as L
+    dims, batch, cfg = (64, 64, 64), 4, 2
+    data, res, masks, lw = _oracle_runs(dims, batch, cfg, 'surface', 0.05, True, want_grads=True)
+    locs, feats = data['input']
+    oocc = res['f32'][1]
+    hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
+    t = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
+                          data['known'].cuda())
+    hsdf, hocc = hm([locs.cuda(), feats.cuda()], lw, batch_size=batch, teacher=_teacher_volumes(oocc, masks, dims, batch))
+    loss, _ = L.compute_loss(hsdf, hocc, t[0], t[1], t[2], lw, 3, True, 5.0, locs.cuda(), True, data['known'].cuda())
+    loss.backward()
+    l64, l32 = res['f64_loss'], res['f32_loss']
+    report('configs[1] 64^3 bs4 loss: HIP %.7f  oracle fp32 %.7f  fp64 %.7f' % (float(loss), l32, l64))
+    assert abs(float(loss) - l64) <= max(1e-4 * abs(l64), 2 * abs(l32 - l64))
+    worst = (0.0, '')
+    for name, p in hm.named_parameters():
+        g64, g32 = res['f64_grads'][name], res['f32_grads'][name]
+        gh = p.grad.detach().cpu().double()
+        scale = float(g64.abs().max()) + 1e-30
+        eh, eo = float((gh - g64).abs().max()) / scale, float((g32 - g64).abs().max()) / scale
+        worst = max(worst, (eh, name))
+        assert eh <= 2 * eo + 1e-4, '%s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (name, eh, eo)
+    report('configs[1] 64^3 bs4 parameter gradients (%d tensors): worst HIP-vs-fp64 %.3e of the tensor scale (%s)'
+           % (len(res['f64_grads']), worst[0], worst[1]))
 
 
 def test_config4_level_ops_and_stride2():

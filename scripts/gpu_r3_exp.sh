@@ -18,12 +18,14 @@ PY
 timeout -k 10 300 python -m pytest tests/test_gpu_capacity.py -x -q > gpurun_out/${TAG}_cap_tests.log 2>&1; echo "cap tests rc $?"; tail -15 gpurun_out/${TAG}_cap_tests.log
 run graph_default A=1
 run graph_noside SGNN_SIDE_LANE=0
-run graph_nopktcap DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-run graph_pktcap1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
-run graph_headroom11 A=1 EXTRA="--headroom 1.1"
-EXTRA="--headroom 1.1" run graph_h11 A=1
-EXTRA="--classic" run classic_tf_prefetch A=1
+EXTRA="--headroom 1.25" run graph_h125 A=1
 EXTRA="--classic --no-prefetch" run classic_tf A=1
+EXTRA="" 
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/${TAG}_graph_default.json').read().strip().splitlines()[-1])
+print('graph stats', d['config']['graph'])
+PY
 # kernel trace of the graph replay
 export TMPDIR=/tmp; D=/tmp/prof_$TAG; rm -rf $D; ROOT=$(pwd)
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --steps 20 --warmup 12 --no-cpu-baseline --no-traffic --no-other-mode --teacher-forced > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)

@@ -92,6 +92,12 @@ int sgnn_gather_sum_ld(const float *src, int64_t ld_src, int c, const int32_t *t
                        float *dst, int64_t ld_dst, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_add_ld(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t n, int c, float *y, int64_t ldy,
                 sgnn_stream_t stream, const int64_t *n_dev = nullptr);
+// fill / copy as plain kernels (rows.hip).  hipMemsetAsync / hipMemcpyAsync become memset / memcpy NODES in a captured
+// graph, and a replay stalls around each of them (50-150 us bubbles in the rocprofv3 timeline of a replayed step,
+// profiles/r03b_trace_summary.txt); kernel nodes replay back to back.  regions: up to 4 (pointer, 32-bit words) pairs.
+int sgnn_fill32(void *p, uint32_t pattern, int64_t words, hipStream_t s);
+int sgnn_fill32_multi(void *const *p, const int64_t *words, int nregions, uint32_t pattern, hipStream_t s);
+int sgnn_copy_words(void *dst, const void *src, int64_t words, hipStream_t s);
 int sgnn_sum_groups_dn(const float *src, int c, int64_t n, int rep, float *dst, sgnn_stream_t stream, const int64_t *n_dev);
 int sgnn_concat_rows_dn(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib, int64_t m,
                         float *dst, sgnn_stream_t stream, const int64_t *n_dev);

@@ -183,17 +183,22 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   // all groups of a row tile run next to each other on one XCD (they gather the same feature rows)
-  const unsigned lin = sgnn_xcd_tile(blockIdx.x, gridDim.x);
   const unsigned groups = EX ? (unsigned)ex.groups : 1u;
-  const unsigned tile = lin / groups, grp = lin % groups;
+  unsigned nwg = gridDim.x;
   if (epi.n_dev) {   // capacity mode: the launch covers the level's capacity, the live row count is on the device
     n_out = sgnn_dyn_n(n_out, epi.n_dev);
-    if ((int64_t)tile * 4 * RPW >= n_out) {   // workgroup past the end: nothing to compute, zero statistics partials
+    // the LIVE workgroups are the first nwg in dispatch order (round robin over the XCDs) and share the tiles among
+    // themselves exactly as an exact-size launch would: every XCD stays busy whatever the capacity's head-room, and the
+    // statistics partial a block writes is the one the exact launch writes
+    nwg = (unsigned)((n_out + 4 * RPW - 1) / (4 * RPW)) * groups;
+    if (blockIdx.x >= nwg) {   // workgroup past the end: nothing to compute, zero statistics partials
       if (!EX && epi.stats)
         for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
       return;
     }
   }
+  const unsigned lin = sgnn_xcd_tile(blockIdx.x, nwg);
+  const unsigned tile = lin / groups, grp = lin % groups;
   const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
   const int32_t *kmap = nullptr, *kadd_g = nullptr;
   if constexpr (EX) {
@@ -1043,7 +1048,12 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift, ConvEx ex, int64_t ldx,
                                                 int64_t ld_dy, const int64_t *n_dev) {
-  n_out = sgnn_dyn_n(n_out, n_dev);   // capacity mode: row blocks past the live count write zero partials
+  if (n_dev) {   // capacity mode: spread the LIVE rows over all row blocks of the (capacity-sized) launch
+    n_out = sgnn_dyn_n(n_out, n_dev);
+    const int64_t per = (n_out + gridDim.x - 1) / gridDim.x;
+    rows_per_block = ((per + 255) / 256) * 256;
+    if (rows_per_block < 256) rows_per_block = 256;
+  }
   constexpr int MT = (CIN + 15) / 16, NT = (COUT + 15) / 16;
   constexpr int DW_KPB = KPBT > 0 ? KPBT : DwCfg<CIN, COUT>::KPB;
   constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
@@ -1369,7 +1379,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
   hipStream_t s = (hipStream_t)stream;
   const int64_t elems = (int64_t)groups * K * cin * cout;
   if (n_out == 0) {
-    SGNN_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), s));
+    if (sgnn_fill32(dw, 0u, elems, s) != SGNN_OK) return SGNN_EHIP;
     return SGNN_OK;
   }
   SGNN_CHECK_ARG(x && dy && table && n_in >= 1);

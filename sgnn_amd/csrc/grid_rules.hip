@@ -121,7 +121,7 @@ SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys
     sgnn_set_error("sgnn_hash_build: %lld sites exceed the 31-bit row index", (long long)n);
     return SGNN_EOVERFLOW;
   }
-  SGNN_HIP_TRY(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint64_t), (hipStream_t)stream));
+  if (sgnn_fill32(keys, 0xFFFFFFFFu, cap * 2, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords);
   hipLaunchKernelGGL(k_hash_build, dim3(sgnn_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
@@ -582,7 +582,7 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
     hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(13 * n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        nbr + 14 * ld, 13, ld, n, n_dev);
   else
-    SGNN_HIP_TRY(hipMemsetAsync(nbr + 14 * ld, 0xFF, (size_t)(13 * ld) * sizeof(int32_t), (hipStream_t)stream));
+    if (sgnn_fill32(nbr + 14 * ld, 0xFFFFFFFFu, 13 * ld, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
   hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
   SGNN_CHECK_LAUNCH();
@@ -1114,7 +1114,7 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
     if (nc_dev)
       hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(8 * nc, 256, 4096)), dim3(256), 0, s, children, 8, ldc, nc, nc_dev);
     else
-      SGNN_HIP_TRY(hipMemsetAsync(children, 0xFF, (size_t)(8 * ldc) * sizeof(int32_t), s));
+      if (sgnn_fill32(children, 0xFFFFFFFFu, 8 * ldc, s) != SGNN_OK) return SGNN_EHIP;
   }
   if (nf == 0) return SGNN_OK;
   SGNN_CHECK_ARG(fine_coords && parent && ptable && children);

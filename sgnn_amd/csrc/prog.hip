@@ -494,7 +494,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   for (int b = n_ext; b < nbuf; ++b)
     if (gout[b]) {
       if (L.buf_floats[b] > 0)
-        SGNN_HIP_TRY(hipMemcpyAsync(G(b), gout[b], (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        PROG_TRY(sgnn_copy_words(G(b), gout[b], L.buf_floats[b], hs));
       init[b] = 1;
     }
   float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
@@ -544,15 +544,19 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     const int64_t n = lev_n[lev];
     if (!init[out]) {  // no gradient reached this output: its producers contribute nothing
       if (type == OP_CONV_SUBM || type == OP_CONV_DOWN || type == OP_EXPAND)
-        SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, (size_t)(type == OP_CONV_DOWN ? 8 : 27) * cin * cout * sizeof(float), hs));
+        PROG_TRY(sgnn_fill32(PG(par), 0u, (int64_t)(type == OP_CONV_DOWN ? 8 : 27) * cin * cout, hs));
       if (type == OP_BN) {
-        if (PG(par)) SGNN_HIP_TRY(hipMemsetAsync(PG(par), 0, cin * sizeof(float), hs));
-        if (PG(par + 1)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 1), 0, cin * sizeof(float), hs));
+        {
+          void *zp[2] = {PG(par), PG(par + 1)};
+          const int64_t zw[2] = {cin, cin};
+          PROG_TRY(sgnn_fill32_multi(zp, zw, 2, 0u, hs));
+        }
       }
       if (type == OP_LINEAR)
         for (int q = 0; q < cout; ++q) {
-          if (PG(par + 2 * q)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 2 * q), 0, cin * sizeof(float), hs));
-          if (PG(par + 2 * q + 1)) SGNN_HIP_TRY(hipMemsetAsync(PG(par + 2 * q + 1), 0, sizeof(float), hs));
+          void *zp[2] = {PG(par + 2 * q), PG(par + 2 * q + 1)};
+          const int64_t zw[2] = {cin, 1};
+          PROG_TRY(sgnn_fill32_multi(zp, zw, 2, 0u, hs));
         }
       continue;
     }
@@ -753,9 +757,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   for (int b = 0; b < n_ext; ++b) {                   // the caller reads gext[b]: an alias has to become a copy,
     if (!gext[b] || L.buf_floats[b] == 0) continue;   // an input nothing reached gets zeros
     if (init[b] == 2)
-      SGNN_HIP_TRY(hipMemcpyAsync(G(b), G(alias[b]), (size_t)L.buf_floats[b] * sizeof(float), hipMemcpyDeviceToDevice, hs));
+      PROG_TRY(sgnn_copy_words(G(b), G(alias[b]), L.buf_floats[b], hs));
     else if (init[b] == 0)
-      SGNN_HIP_TRY(hipMemsetAsync(G(b), 0, (size_t)L.buf_floats[b] * sizeof(float), hs));
+      PROG_TRY(sgnn_fill32(G(b), 0u, L.buf_floats[b], hs));
   }
   {
     const hipStream_t lane = side ? g_side.stream : hs;

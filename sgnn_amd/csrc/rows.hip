@@ -37,6 +37,73 @@ __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
       hipLaunchKernelGGL((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
   } while (0)
 
+// ---------------------------------------------------------------------------
+// fill / copy kernels (see common.h: memset / memcpy graph nodes stall a replayed step)
+// ---------------------------------------------------------------------------
+struct FillRegions {
+  uint32_t *p[4];
+  int64_t words[4];
+  int64_t start[5];   // prefix sums of the 16-byte chunk counts
+};
+
+__global__ __launch_bounds__(256) void k_fill32_multi(FillRegions r, int n, uint32_t pattern) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < r.start[n]; g += stride) {
+    int k = 0;
+    while (k + 1 < n && g >= r.start[k + 1]) ++k;
+    const int64_t c = g - r.start[k], w = c * 4;
+    uint32_t *q = r.p[k] + w;
+    if (w + 4 <= r.words[k] && (((uintptr_t)r.p[k]) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(q) = make_uint4(pattern, pattern, pattern, pattern);
+    } else {
+      for (int t = 0; t < 4 && w + t < r.words[k]; ++t) q[t] = pattern;
+    }
+  }
+}
+
+int sgnn_fill32_multi(void *const *p, const int64_t *words, int nregions, uint32_t pattern, hipStream_t s) {
+  FillRegions r{};
+  int n = 0;
+  for (int k = 0; k < nregions && n < 4; ++k) {
+    if (!p[k] || words[k] <= 0) continue;
+    r.p[n] = (uint32_t *)p[k];
+    r.words[n] = words[k];
+    r.start[n + 1] = r.start[n] + (words[k] + 3) / 4;
+    ++n;
+  }
+  if (n == 0) return SGNN_OK;
+  hipLaunchKernelGGL(k_fill32_multi, dim3(sgnn_grid_for(r.start[n], 256, 4096)), dim3(256), 0, s, r, n, pattern);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+int sgnn_fill32(void *p, uint32_t pattern, int64_t words, hipStream_t s) {
+  void *ps[1] = {p};
+  return sgnn_fill32_multi(ps, &words, 1, pattern, s);
+}
+
+__global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
+                                                   int64_t words, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t n4 = words / 4;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n4; g += stride)
+      reinterpret_cast<uint4 *>(dst)[g] = reinterpret_cast<const uint4 *>(src)[g];
+    if (blockIdx.x == 0 && threadIdx.x < (words & 3)) dst[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x];
+  } else {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < words; g += stride) dst[g] = src[g];
+  }
+}
+
+int sgnn_copy_words(void *dst, const void *src, int64_t words, hipStream_t s) {
+  if (words <= 0 || dst == src) return SGNN_OK;
+  const int vec = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+  hipLaunchKernelGGL(k_copy_words, dim3(sgnn_grid_for(vec ? words / 4 + 1 : words, 256, 4096)), dim3(256), 0, s,
+                     (uint32_t *)dst, (const uint32_t *)src, words, vec);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 // dst[r] = src[idx[r]]  (idx < 0 -> zeros)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ src, int cq,
@@ -218,7 +285,7 @@ SGNN_EXPORT int sgnn_scatter_rows(const float *src, int c, const int32_t *idx, i
   SGNN_CHECK_ARG(c >= 1 && m >= 0 && n_dst >= 0);
   if (n_dst > 0) {
     SGNN_CHECK_ARG(dst);
-    SGNN_HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n_dst * c * sizeof(float), (hipStream_t)stream));
+    if (sgnn_fill32(dst, 0u, n_dst * (int64_t)c, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
   }
   if (m == 0 || n_dst == 0) return SGNN_OK;
   SGNN_CHECK_ARG(src && idx);
@@ -384,8 +451,11 @@ int sgnn_concat_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb
                             int64_t na, float *db, int64_t nb, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0 && na >= 0 && nb >= 0);
-  if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
-  if (db && ib && nb > 0 && cb > 0) SGNN_HIP_TRY(hipMemsetAsync(db, 0, (size_t)nb * cb * sizeof(float), s));
+  {
+    void *zp[2] = {(da && ia && ca > 0) ? da : nullptr, (db && ib && cb > 0) ? db : nullptr};
+    const int64_t zw[2] = {na * (int64_t)ca, nb * (int64_t)cb};
+    if (sgnn_fill32_multi(zp, zw, 2, 0u, s) != SGNN_OK) return SGNN_EHIP;
+  }
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG(ia || !da || na >= m);
@@ -472,9 +542,11 @@ int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int c
                              int64_t nc, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && cc >= 0 && ca + cb + cc >= 1 && m >= 0 && na >= 0 && nb >= 0 && nc >= 0);
-  if (da && ia && na > 0 && ca > 0) SGNN_HIP_TRY(hipMemsetAsync(da, 0, (size_t)na * ca * sizeof(float), s));
-  if (db && ib && nb > 0 && cb > 0) SGNN_HIP_TRY(hipMemsetAsync(db, 0, (size_t)nb * cb * sizeof(float), s));
-  if (dc && ic && nc > 0 && cc > 0) SGNN_HIP_TRY(hipMemsetAsync(dc, 0, (size_t)nc * cc * sizeof(float), s));
+  {   // one launch zero-fills every destination that is reached through an index array
+    void *zp[3] = {(da && ia && ca > 0) ? da : nullptr, (db && ib && cb > 0) ? db : nullptr, (dc && ic && cc > 0) ? dc : nullptr};
+    const int64_t zw[3] = {na * (int64_t)ca, nb * (int64_t)cb, nc * (int64_t)cc};
+    if (sgnn_fill32_multi(zp, zw, 3, 0u, s) != SGNN_OK) return SGNN_EHIP;
+  }
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG((ia || !da || na >= m) && (ib || !db || nb >= m) && (ic || !dc || nc >= m));
@@ -533,7 +605,7 @@ SGNN_EXPORT int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, 
   const int64_t total = (int64_t)batch * c * d0 * d1 * d2;
   if (total > 0) {
     SGNN_CHECK_ARG(dense);
-    SGNN_HIP_TRY(hipMemsetAsync(dense, 0, (size_t)total * sizeof(float), s));
+    if (sgnn_fill32(dense, 0u, total, s) != SGNN_OK) return SGNN_EHIP;
   }
   if (n == 0 || total == 0) return SGNN_OK;
   SGNN_CHECK_ARG(feats && coords);

@@ -624,7 +624,8 @@ class GraphStep(object):
         self.loss = None
         self.losses = None
         self.pending = []               # [(event, pinned status, batch, loss_weights)] of issued capacity steps
-        self.stats = {'probe_steps': 0, 'eager_steps': 0, 'captures': 0, 'replays': 0, 'overflows': 0}
+        self.stats = {'probe_steps': 0, 'eager_steps': 0, 'captures': 0, 'replays': 0, 'overflows': 0, 'replans': 0,
+                      'replay_host_ms': 0.0}
         self._pins, self._npin = None, 0
         self._bound = False
 
@@ -814,12 +815,15 @@ class GraphStep(object):
         self.stats['captures'] += 1
 
     def _replay(self):
+        import time
+        t0 = time.perf_counter()
         if len(self.graphs) == 1:
             self.graphs[0].replay()
         else:
             self.graphs[0].replay()
             self.grad_sync(self.opt.flat_g)
             self.graphs[1].replay()
+        self.stats['replay_host_ms'] += 1e3 * (time.perf_counter() - t0)     # host time inside hipGraphLaunch
         self.stats['replays'] += 1
         return self._graph_out
 
@@ -888,7 +892,7 @@ class GraphStep(object):
             b = cap.gen_base(g)
             pairs.append((live[b], k))
             pairs += [(live[b + 2 + l], c) for l, c in enumerate(pyr)]
-        tight = any(n > 0.92 * c for n, c in pairs)
+        tight = any(n > (1.0 - 0.2 * min(self.headroom - 1.0, 0.4)) * c for n, c in pairs)
         have, want = sum(c for _, c in pairs), sum(need(n) for n, _ in pairs)
         self._loose = (getattr(self, '_loose', 0) + 1) if have > 1.5 * want else 0
         if not (tight or self._loose >= 3):
@@ -905,7 +909,7 @@ class GraphStep(object):
                                   for g, (k, pyr) in enumerate(cap.gen)])
         self._live = None
         self.graphs, self.stage = None, 1
-        self.stats['replans'] = self.stats.get('replans', 0) + 1
+        self.stats['replans'] += 1
 
     def _drain(self):
         redo = self._check(0)

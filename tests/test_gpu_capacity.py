@@ -99,7 +99,8 @@ def test_capacity_forward_backward_equals_the_classic_path():
             ib = torch.nonzero(torch.isin(kb, common)).view(-1)
             assert torch.equal(ka[ia], kb[ib]), 'level %d: common sites are not in the same order' % h
             mism += (sa_.shape[0] - ia.numel()) + (sb_.shape[0] - ib.numel())
-        tol = 5e-5 * max(1.0, float(va.abs().max())) * (1 if mism == 0 else 20)
+        # a site decided differently changes the BatchNorm statistics of its level for every site
+        tol = (5e-5 if mism == 0 else 5e-3) * max(1.0, float(va.detach().abs().max()))
         assert torch.allclose(va[ia], vb[ib], rtol=0, atol=tol), (h, float((va[ia] - vb[ib]).abs().max()))
     assert mism <= 32, 'site lists differ by %d sites' % mism
     if mism == 0:

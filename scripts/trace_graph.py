@@ -67,3 +67,12 @@ for g, at in sorted(gaps, reverse=True)[:15]:
     before = max((r for r in step if r['e'] <= at), key=lambda r: r['e'])
     after = min((r for r in step if r['s'] >= at + g), key=lambda r: r['s'])
     print('  %7.1f  %-45s -> %s' % (g / 1e3, short(before['Kernel_Name'])[:45], short(after['Kernel_Name'])[:45]))
+
+# per-launch table of the analysed step (kernel, grid, duration) for offline inspection
+if len(sys.argv) > 3:
+    with open(sys.argv[3], 'w') as f:
+        f.write('start_us,dur_us,queue,grid,wg,kernel\n')
+        for r in step:
+            f.write('%.1f,%.2f,%s,%s,%s,%s\n' % ((r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, r.get('Queue_Id'),
+                                               r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')),
+                                               short(r['Kernel_Name']).replace(',', ';')))

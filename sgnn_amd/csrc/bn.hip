@@ -264,9 +264,22 @@ __device__ __forceinline__ void bn_fuse_totals(const BnFuse &f, int c, double *s
   const int ch = tid % c, part = tid / c;
   double a = 0.0, b = 0.0;
   if (part < tpc)
-    for (int blk = part; blk < f.nblk; blk += tpc) {
-      a += f.partial[((size_t)blk * 2 + 0) * c + ch];
-      b += f.partial[((size_t)blk * 2 + 1) * c + ch];
+    // eight independent loads in flight per thread (the table is L2-resident; a load -> add chain would pay one L2
+    // round trip per block partial); the additions keep their order, missing entries add an exact 0.0
+    for (int blk = part; blk < f.nblk; blk += 8 * tpc) {
+      double va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bi = blk + u * tpc;
+        const bool ok = bi < f.nblk;
+        va[u] = ok ? f.partial[((size_t)bi * 2 + 0) * c + ch] : 0.0;
+        vb[u] = ok ? f.partial[((size_t)bi * 2 + 1) * c + ch] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += va[u];
+        b += vb[u];
+      }
     }
   scratch[tid] = a;
   scratch[256 + tid] = b;

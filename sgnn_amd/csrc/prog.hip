@@ -476,26 +476,37 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   hipStream_t hs = (hipStream_t)stream;
   // gradient state of a buffer: 0 nothing yet, 1 G(b) holds it, 2 it EQUALS the gradient of buffer alias[b]
   // (an AddTable input whose only contribution so far is the sum's gradient: nothing is copied until something
-  // has to be added to it, and a reader just follows the alias)
+  // has to be added to it, and a reader just follows the alias), 3 it is the caller's tensor gout[b], read in place
+  // (contiguous rows; folded into G(b) by the first kernel that has to add to it — no up-front copy of the outputs'
+  // gradients into the arena)
   std::vector<char> init(nbuf, 0);
   std::vector<int> alias(nbuf, -1);
+  std::vector<char> viewed(nbuf, 0);      // storage shared through an in-place JoinTable: keeps the copying path
+  for (int b = 0; b < nbuf; ++b)
+    if (PL.root[b] != b) viewed[b] = viewed[PL.root[b]] = 1;
   auto X = [&](int b) -> const float * { return b < 0 ? nullptr : (b < n_ext ? (const float *)ext[b] : arena + L.buf_off[b]); };
   auto G = [&](int b) -> float * { return b < n_ext ? (float *)gext[b] : garena + L.buf_off[b]; };
-  auto GR = [&](int b) -> const float * { return init[b] == 2 ? G(alias[b]) : G(b); };   // where b's gradient is read
   auto LD = [&](int b) -> int64_t { return PL.ld[b]; };                                  // row stride of X(b) and G(b)
-  auto GRLD = [&](int b) -> int64_t { return init[b] == 2 ? PL.ld[alias[b]] : PL.ld[b]; };
+  auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
+  // where the gradient a buffer HOLDS lives (its own arena slot, or the caller's tensor) and that storage's row stride
+  auto GH = [&](int b) -> const float * { return init[b] == 3 ? (const float *)gout[b] : G(b); };
+  auto GHLD = [&](int b) -> int64_t { return init[b] == 3 ? (int64_t)CH(b) : PL.ld[b]; };
+  auto GR = [&](int b) -> const float * { return init[b] == 2 ? GH(alias[b]) : GH(b); };   // where b's gradient is read
+  auto GRLD = [&](int b) -> int64_t { return init[b] == 2 ? GHLD(alias[b]) : GHLD(b); };
   auto P = [&](int p) { return (p >= 0 && p < nparams) ? (float *)params[p] : nullptr; };
   auto PG = [&](int p) { return (p >= 0 && p < nparams) ? (float *)pgrads[p] : nullptr; };
-  auto CH = [&](int b) { return b < 0 ? 0 : bufs[2 * b + 1]; };
   auto ROWS = [&](int b) { return lev_n[bufs[2 * b]]; };
   auto I = [&](int i) { return (i >= 0 && i < nidx && idx) ? (const int32_t *)idx[i] : nullptr; };
   auto CNT = [&](int cls) -> const int64_t * { return (lev_cnt && cls >= 0 && cls < nlev) ? (const int64_t *)lev_cnt[cls] : nullptr; };
   auto BCNT = [&](int b) -> const int64_t * { return CNT(bufs[2 * b]); };     // device row count of buffer b's rows class
   for (int b = n_ext; b < nbuf; ++b)
     if (gout[b]) {
-      if (L.buf_floats[b] > 0)
-        PROG_TRY(sgnn_copy_words(G(b), gout[b], L.buf_floats[b], hs));
-      init[b] = 1;
+      if (viewed[b] || !g_fuse) {
+        if (L.buf_floats[b] > 0) PROG_TRY(sgnn_copy_words(G(b), gout[b], L.buf_floats[b], hs));
+        init[b] = 1;
+      } else {
+        init[b] = 3;
+      }
     }
   float *scratch[2] = {garena + L.scratch0, garena + L.scratch1};
   // where a kernel should write the gradient of buffer b: the buffer itself unless it already holds data
@@ -503,11 +514,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   auto TLD = [&](int b, const float *t) -> int64_t { return t == G(b) ? LD(b) : CH(b); };   // scratch rows are contiguous
   auto commit = [&](int b, float *wrote) -> int {  // fold a freshly written gradient into buffer b
     if (wrote == G(b)) {
-      if (init[b] == 2) {                            // G(b) = fresh + the aliased gradient
-        const int a = alias[b];
+      if (init[b] == 2 || init[b] == 3) {            // G(b) = fresh + the aliased / the caller's gradient
+        const float *other = GR(b);
+        const int64_t ldo = GRLD(b);
         alias[b] = -1;
         init[b] = 1;
-        return sgnn_add_ld(G(b), LD(b), G(a), LD(a), ROWS(b), CH(b), G(b), LD(b), stream, BCNT(b));
+        return sgnn_add_ld(G(b), LD(b), other, ldo, ROWS(b), CH(b), G(b), LD(b), stream, BCNT(b));
       }
       init[b] = 1;
       return SGNN_OK;
@@ -581,12 +593,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             ConvEpi epi{};
             const bool tiled = !down && lev_tile && lev_tile[lev];      // symmetric rulebook: the same row sets
             if (tiled) sgnn_tile_ptrs(lev_tile[lev], lev_ld[lev], &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
-            if (init[in0] == 1) {
-              epi.addend = G(in0);
-              epi.ld_add = LD(in0);
-            } else if (init[in0] == 2) {
-              epi.addend = G(alias[in0]);
-              epi.ld_add = LD(alias[in0]);
+            if (init[in0]) {                    // what the buffer (or its alias / the caller's tensor) already holds
+              epi.addend = GR(in0);
+              epi.ld_add = GRLD(in0);
             }
             if (i > 0 && ops[OPW * (i - 1)] == OP_BN && ops[OPW * (i - 1) + 3] == in0 && ops[OPW * (i - 1) + 6] == cin) {
               const int32_t *bo = ops + OPW * (i - 1);
@@ -639,12 +648,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         // the kernel adds what the buffer already holds (in place) or the aliased gradient: no scratch pass, no k_add
         const float *addend = nullptr;
         int64_t ld_add = cin;
-        if (wants(in0) && init[in0] == 1) {
-          addend = G(in0);
-          ld_add = LD(in0);
-        } else if (wants(in0) && init[in0] == 2) {
-          addend = G(alias[in0]);
-          ld_add = LD(alias[in0]);
+        if (wants(in0) && init[in0]) {
+          addend = GR(in0);
+          ld_add = GRLD(in0);
         }
         float *t = wants(in0) ? G(in0) : scratch[0];
         PROG_TRY(sgnn_bn_bwd_impl(X(in0), LD(in0), dy, ld_dy, n, cin, P(par), P(par + 1), save, save + cin, training,
@@ -663,8 +669,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           if (!wants(b)) continue;
           if (init[b] == 1) {
             PROG_TRY(sgnn_add_ld(G(b), LD(b), dy, ld_dy, n, cin, G(b), LD(b), stream, CNT(lev)));
-          } else if (init[b] == 2) {                            // two aliased contributions: materialise the sum
-            PROG_TRY(sgnn_add_ld(G(alias[b]), LD(alias[b]), dy, ld_dy, n, cin, G(b), LD(b), stream, CNT(lev)));
+          } else if (init[b] == 2 || init[b] == 3) {            // two contributions held elsewhere: materialise the sum
+            PROG_TRY(sgnn_add_ld(GR(b), GRLD(b), dy, ld_dy, n, cin, G(b), LD(b), stream, CNT(lev)));
             init[b] = 1;
             alias[b] = -1;
           } else {
@@ -757,7 +763,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   for (int b = 0; b < n_ext; ++b) {                   // the caller reads gext[b]: an alias has to become a copy,
     if (!gext[b] || L.buf_floats[b] == 0) continue;   // an input nothing reached gets zeros
     if (init[b] == 2)
-      PROG_TRY(sgnn_copy_words(G(b), G(alias[b]), L.buf_floats[b], hs));
+      PROG_TRY(sgnn_copy_words(G(b), GR(b), L.buf_floats[b], hs));
     else if (init[b] == 0)
       PROG_TRY(sgnn_fill32(G(b), 0u, L.buf_floats[b], hs));
   }

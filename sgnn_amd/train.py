@@ -636,6 +636,7 @@ class GraphStep(object):
         nl, trunc, use_log, wgeo, masking = self.args
         self.opt.unbind()
         self._bound = False
+        MD.runtime(batch['sdf'].device).state[1:2].zero_()     # a discarded capacity step may have left its overflow flag
         MD.COUNT_LOG = []
         try:
             self.opt.zero_grad()

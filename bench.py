@@ -55,7 +55,11 @@ def parse():
     ap.add_argument('--classic', action='store_true',
                     help='the classic eager step (host read-backs of the level sizes, one launch at a time from Python) '
                          'instead of the capacity-mode step replayed from a HIP graph')
-    ap.add_argument('--headroom', type=float, default=1.5, help='capacity = measured rows x headroom (graph mode)')
+    ap.add_argument('--headroom', type=float, default=1.3, help='capacity = measured rows x headroom (graph mode)')
+    ap.add_argument('--settle', type=int, default=40,
+                    help='untimed training steps BEFORE the warm-up steps (set-up, like building the model): with the '
+                         'reference\'s masks the per-level row counts of a freshly initialised model change several-fold '
+                         'within the first dozen optimizer steps; the timed region should see a settled workload')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='teacher-forced steps build their own geometry (5 read-backs at the head of the step) instead of '
                          'having it built one batch ahead on a second stream (train.GeometryPrefetcher)')
@@ -330,7 +334,12 @@ def main():
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # SGNN_BENCH_FORCE_DIST=1: take the data-parallel code path (process group, flat-gradient all-reduce between the
+    # two halves of the replayed step) even with ONE rank — on a 1-GPU box this executes the RCCL branch the 8-GPU run
+    # takes (tests/test_gpu_distributed.py)
+    force_dist = os.environ.get('SGNN_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if os.environ.get('SGNN_BENCH_SHARE_GPU') == '1':
@@ -392,6 +401,7 @@ def main():
 
     def flat_sync(flat):        # data parallel: ONE all-reduce of the flat gradient buffer (+ its reached-flags tail)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    backend = dist.get_backend() if dist_on else None
 
     batches = make_batches(args.batch)
     n_sites = [int(b['input'][0].shape[0]) for b in batches]
@@ -407,12 +417,16 @@ def main():
         # reference (torch/model.py:233, 322) unless --teacher-forced
         model = make_model()
         gs = GraphStep(model, lr=1e-3, teacher_forced=teacher, headroom=args.headroom,
-                       grad_sync=flat_sync if world > 1 else None, world_size=world)
+                       grad_sync=flat_sync if dist_on else None, world_size=world)
 
         def step(i):
             return gs(batches[i % 2], lw)
+        for i in range(args.settle):
+            step(i)
         elapsed = timed(step, args.warmup, args.steps)
         graph_info = dict(gs.stats)
+        graph_info['replay_host_ms_per_step'] = round(graph_info.pop('replay_host_ms') / max(gs.stats['replays'], 1), 3)
+        graph_info['preconditioning_steps'] = args.settle
         graph_info['capacity'] = gs.capacity.describe()
         graph_info['live_rows'] = gs.capacity.read()
         live = graph_info['live_rows']
@@ -433,7 +447,7 @@ def main():
         P_.PERSISTENT_ARENAS = True          # grow-only program arenas (a training loop never keeps two forward results)
         model = make_model()
         opt = make_optimizer(model.parameters(), lr=1e-3)
-        sync = FlatGradAllReduce(model.parameters()) if world > 1 else None
+        sync = FlatGradAllReduce(model.parameters()) if dist_on else None
         pre = GeometryPrefetcher(model) if (teacher and not args.no_prefetch and not share) else None
 
         def step(i):
@@ -467,18 +481,33 @@ def main():
         k2 = max(10, args.steps // 3)
         P_.PERSISTENT_ARENAS = True
         if not classic:
+            gs._drain()
+            torch.cuda.synchronize()
+            state = dict((k, v.detach().clone()) for k, v in model.state_dict().items())
+
+            def make_model():       # every comparison leg starts from the headline leg's weights: the same masks
+                m = GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
+                m.load_state_dict(state)
+                return m
             # (a) the classic eager path with the reference's masks: five host read-backs per step, ~680 launches issued
             #     from Python (what BENCH_r01 / BENCH_r02's `other_mask_mode` measured)
             m2 = make_model()
             o2 = make_optimizer(m2.parameters(), lr=1e-3)
-            s2 = FlatGradAllReduce(m2.parameters()) if world > 1 else None
-            el = timed(lambda i: train_step(m2, o2, batches[i % 2], lw, grad_sync=s2, teacher_forced=False), 8, k2)
-            legs['classic_eager_free_running'] = {'steps': k2, 'value': round(args.batch * world * k2 / el, 2),
-                                                  'ms_per_step': round(1e3 * el / k2, 3)}
+            s2 = FlatGradAllReduce(m2.parameters()) if dist_on else None
+            box2 = {}
+
+            def step2(i):
+                box2['o'] = train_step(m2, o2, batches[i % 2], lw, grad_sync=s2, teacher_forced=False)[2]
+            el = timed(step2, 8, k2)
+            o_ = box2['o']
+            legs['classic_eager_free_running'] = {
+                'steps': k2, 'value': round(args.batch * world * k2 / el, 2), 'ms_per_step': round(1e3 * el / k2, 3),
+                'generated_sites_per_level': [int(o[0].shape[0]) if len(o[0]) else 0 for o in o_[1]] +
+                                             [int(o_[0][0].shape[0]) if len(o_[0][0]) else 0]}
             # (b) BENCH_r02's headline: teacher-forced masks + geometry built one batch ahead on a second stream
             m3 = make_model()
             o3 = make_optimizer(m3.parameters(), lr=1e-3)
-            s3 = FlatGradAllReduce(m3.parameters()) if world > 1 else None
+            s3 = FlatGradAllReduce(m3.parameters()) if dist_on else None
             p3 = GeometryPrefetcher(m3)
             el = timed(lambda i: train_step(m3, o3, batches[i % 2], lw, grad_sync=s3, teacher_forced=True, prefetch=p3,
                                             next_batch=batches[(i + 1) % 2]), 8, k2)
@@ -487,8 +516,8 @@ def main():
             del m2, o2, m3, o3, p3
             # (c) graph replay with teacher-forced masks (row counts independent of the weights)
             m4 = make_model()
-            g4 = GraphStep(m4, lr=1e-3, teacher_forced=not teacher, headroom=args.headroom,
-                           grad_sync=flat_sync if world > 1 else None, world_size=world)
+            g4 = GraphStep(m4, lr=1e-3, teacher_forced=not teacher, headroom=args.headroom, settle=teacher,
+                           grad_sync=flat_sync if dist_on else None, world_size=world)
             el = timed(lambda i: g4(batches[i % 2], lw), 8, k2)
             live4 = g4.capacity.read()
             legs['graph_teacher_forced' if not teacher else 'graph_free_running'] = {
@@ -500,9 +529,9 @@ def main():
             if args.batch > 1:
                 b1 = make_batches(1)
                 m5 = make_model()
-                g5 = GraphStep(m5, lr=1e-3, teacher_forced=teacher, headroom=max(args.headroom, 2.0),
-                               grad_sync=flat_sync if world > 1 else None, world_size=world)
-                el = timed(lambda i: g5(b1[i % 2], lw), 8, k2)
+                g5 = GraphStep(m5, lr=1e-3, teacher_forced=teacher, headroom=max(args.headroom, 1.6),
+                               grad_sync=flat_sync if dist_on else None, world_size=world)
+                el = timed(lambda i: g5(b1[i % 2], lw), 12, k2)
                 legs['batch1'] = {'steps': k2, 'ms_per_step': round(1e3 * el / k2, 3), 'stats': dict(g5.stats)}
                 del m5, g5, b1
     other = legs or None
@@ -581,13 +610,15 @@ def main():
                                     'train.GeometryPrefetcher)' if pre is not None else
                                     'built inside its own step' + ('' if classic else ' (inside the graph)')),
                        'graph': graph_info,
-                       'ranks_in_process_group': (dist.get_world_size() if world > 1 else 1)},
+                       'ranks_in_process_group': (dist.get_world_size() if dist_on else 1),
+                       'collective': ('%s all-reduce of the flat gradient buffer (%d floats + segment flags) between the two '
+                                      'graph halves' % (backend, 643735)) if (dist_on and not classic) else backend},
             'roofline': roof, 'cpu_baseline': cpu, 'other_legs': other,
         }
         if cpu:
             res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -609,11 +609,12 @@ class GraphStep(object):
 
     def __init__(self, model, lr=1e-3, weight_decay=0.0, num_hierarchy_levels=4, truncation=3.0, use_log_transform=True,
                  weight_missing_geo=5.0, use_loss_masking=True, teacher_forced=False, headroom=1.3, use_graph=True,
-                 grad_sync=None, world_size=1, optimizer=None):
+                 grad_sync=None, world_size=1, optimizer=None, settle=True):
         self.model = model
         self.opt = optimizer if optimizer is not None else FlatAdam(genmodel_segments(model), lr=lr, weight_decay=weight_decay)
         self.args = (num_hierarchy_levels, truncation, use_log_transform, weight_missing_geo, use_loss_masking)
         self.teacher_forced, self.headroom, self.use_graph = teacher_forced, float(headroom), bool(use_graph)
+        self.settle = bool(settle)      # False: capture right after the warm-up step (row counts known to be stable)
         self.grad_sync, self.world_size = grad_sync, int(world_size)
         self.capacity = None
         self.key = None                 # (which stages run, batch shape) the capacities / static buffers belong to
@@ -858,13 +859,11 @@ class GraphStep(object):
         if not self._bound:                          # programs were compiled by the probe step
             self.opt.bind_programs(self.model)
             self._bound = True
-        if self.stage == 1:
-            loss, losses, _ = self._capacity_step_eager(loss_weights)
+        if self.stage in (1, 2):                     # eager capacity steps: warm-up, and while the row counts settle
+            loss, losses, _ = self._capacity_step_eager(loss_weights)     # (use_graph=False: forever)
             self.stats['eager_steps'] += 1
-            self.stage = 2 if not self.use_graph else 3
-        elif self.stage == 2:                        # use_graph=False: eager capacity steps forever (tests, profiling)
-            loss, losses, _ = self._capacity_step_eager(loss_weights)
-            self.stats['eager_steps'] += 1
+            if self.stage == 1:
+                self.stage = 3 if (self.use_graph and self.settle is False) else 2
         else:
             if self.graphs is None:
                 self._capture(loss_weights)
@@ -878,38 +877,62 @@ class GraphStep(object):
             self._maybe_replan()
         return self.loss
 
-    def _maybe_replan(self):
-        """Row counts drift while the weights train (the masks are predictions).  From the live counts that ride back
-        with every step's status word: re-size before a level overflows (live > 92 % of its capacity) and when the plan
-        has become much larger than needed (kernels are launched for the capacities; > 1.5x the needed rows for 3 checks
-        in a row), then warm up + re-capture on the next call."""
-        live, cap = getattr(self, '_live', None), self.capacity
-        if live is None or self.stage < 2:
-            return
-        from .scn.capacity import Capacity, ENC0, _round
-        need = lambda n: _round(max(int(n * self.headroom), 1024))
+    def _levels(self, live):
+        """[(live rows, capacity)] of every count the plan tracks."""
+        from .scn.capacity import ENC0
+        cap = self.capacity
         pairs = [(live[0], cap.input_rows)] + [(live[ENC0 + l], c) for l, c in enumerate(cap.enc)]
         for g, (k, pyr) in enumerate(cap.gen):
             b = cap.gen_base(g)
             pairs.append((live[b], k))
             pairs += [(live[b + 2 + l], c) for l, c in enumerate(pyr)]
+        return pairs
+
+    def _maybe_replan(self):
+        """Row counts drift while the weights train (the masks are predictions) — fast right after initialisation, slowly
+        later.  Capturing a graph costs a few hundred ms, an eager capacity-mode step about what a classic step costs.
+        So: while the live counts (they ride back with every step's status word, one step late) are still moving or do
+        not fit the plan, steps run eagerly and the plan follows the counts for free; once the counts of the last three
+        steps agree within 15 % and fit, the step is captured and replayed.  A replaying step drops back to the eager
+        phase when a level comes close to its capacity (before it overflows) or the plan has become more than twice as
+        large as needed (kernels are launched for the capacities)."""
+        live, cap = getattr(self, '_live', None), self.capacity
+        if live is None or self.stage < 2:
+            return
+        from .scn.capacity import Capacity, ENC0, _round
+        self._live = None
+        pairs = self._levels(live)
+        need = lambda n: _round(max(int(n * self.headroom), 1024))
         tight = any(n > (1.0 - 0.2 * min(self.headroom - 1.0, 0.4)) * c for n, c in pairs)
         have, want = sum(c for _, c in pairs), sum(need(n) for n, _ in pairs)
-        self._loose = (getattr(self, '_loose', 0) + 1) if have > 1.5 * want else 0
-        if not (tight or self._loose >= 3):
-            return
+        hist = self.__dict__.setdefault('_hist', [])
+        hist.append([n for n, _ in pairs])
+        del hist[:-3]
+        stable = len(hist) == 3 and all(max(v) <= 1.15 * max(min(v), 256) for v in zip(*hist))
+        replaying = self.stage == 3 and self.graphs is not None
+        if replaying:
+            self._loose = (getattr(self, '_loose', 0) + 1) if have > 2.0 * want else 0
+            if not (tight or self._loose >= 5):
+                return
+        else:
+            if self.use_graph and self.stage == 2 and stable and not tight and have <= 1.5 * want:
+                self.stage = 3                      # settled and fitting: capture on the next call
+                return
+            if not (tight or have > 1.5 * want):
+                return
+        # re-size from the live counts (moving up: leave more room than the steady-state headroom)
         self._loose = 0
         self._drain()
         if self.stage < 2:                     # the drain found an overflow and re-planned already
             return
-        grow = 1.25 if tight else 1.0          # moving up: leave more room than the steady-state headroom
+        grow = 1.25 if tight else 1.0
         nn = lambda n: _round(max(int(n * self.headroom * grow), 1024))
         b = cap.gen_base
         self.capacity = Capacity(cap.device, nn(live[0]), [nn(live[ENC0 + l]) for l in range(len(cap.enc))],
                                  [(nn(live[b(g)]), [nn(live[b(g) + 2 + l]) for l in range(len(pyr))])
                                   for g, (k, pyr) in enumerate(cap.gen)])
-        self._live = None
         self.graphs, self.stage = None, 1
+        self._hist = []
         self.stats['replans'] += 1
 
     def _drain(self):

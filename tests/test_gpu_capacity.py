@@ -149,7 +149,7 @@ def test_flat_adam_is_adam():
 def _train(use_graph, steps, batches, lw, headroom=1.4, **kw):
     from sgnn_amd.train import GraphStep
     m = _model()
-    gs = GraphStep(m, lr=1e-3, use_graph=use_graph, headroom=headroom, **kw)
+    gs = GraphStep(m, lr=1e-3, use_graph=use_graph, headroom=headroom, settle=False, **kw)
     losses = []
     for i in range(steps):
         losses.append(gs(batches[i % len(batches)], lw).clone())
@@ -195,7 +195,7 @@ def test_overflow_discards_the_step_and_recovers():
     lw = np.ones(5, dtype=np.float32)
     small, big = _batch(3, n=2), _batch(9, n=2)
     m = _model()
-    gs = GraphStep(m, lr=1e-3, headroom=1.0)           # capacities = exactly the first batch's counts
+    gs = GraphStep(m, lr=1e-3, headroom=1.3, settle=False)
     gs(small, lw)                                      # probe
     gs(small, lw)                                      # eager capacity step
     gs(small, lw)                                      # capture + replay
@@ -240,7 +240,7 @@ def test_empty_level_in_capacity_mode_behaves_like_the_reference_early_return():
             m.refinement[0].linear.bias.fill_(-30.0)   # sigmoid(out) <= 0.5 everywhere: level 1 keeps nothing
         return m
     m = build()
-    gs = GraphStep(m, lr=1e-3, headroom=1.5)
+    gs = GraphStep(m, lr=1e-3, headroom=1.5, settle=False)
     state0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     for _ in range(4):
         loss = gs(b, lw)

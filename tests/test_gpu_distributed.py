@@ -120,3 +120,67 @@ def test_bench_gpus_2_starts_two_ranks():
     res = json.loads(line)
     assert res['n_gpus'] == 2 and res['config']['ranks_in_process_group'] == 2
     assert res['config']['global_batch'] == 4 and res['value'] > 0
+
+
+def test_bench_rccl_branch_runs_with_one_rank():
+    """the code the 8-GPU driver run takes — init_process_group('nccl', device_id=...), the flat
+    gradient buffer all-reduced through RCCL between the two halves of the replayed step — executed here with ONE rank
+    under the driver's launcher form."""
+    env = dict(os.environ)
+    env['SGNN_BENCH_FORCE_DIST'] = '1'
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    port = 36500 + (os.getpid() % 2000)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '4',
+           '--batch', '2', '--dim', '32', '--no-cpu-baseline', '--no-traffic', '--no-other-mode']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['n_gpus'] == 1 and res['config']['ranks_in_process_group'] == 1
+    assert res['config']['collective'].startswith('nccl'), res['config']['collective']
+    g = res['config']['graph']
+    assert g['captures'] >= 1 and g['replays'] >= 1 and g['overflows'] == 0 and res['value'] > 0
+
+
+def _worker_graph(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import param_fill
+    from sgnn_amd import synth
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.train import GraphStep, to_device
+    dev = torch.device('cuda', rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    model = param_fill(GenModel(8, DIMS, 1, 16, 16, 4, True, True, 1, 1), 5).train().to(dev)
+    batches = [to_device(synth.make_batch(2, DIMS, cfg=7, first_block=10 * it + 2 * rank, occupancy=0.08), dev)
+               for it in range(2)]
+    step = GraphStep(model, lr=1e-3, headroom=1.6, grad_sync=lambda flat: dist.all_reduce(flat), world_size=world)
+    lw = np.ones(5, dtype=np.float32)
+    for it in range(6):
+        loss = step(batches[it % 2], lw)
+        torch.cuda.synchronize()
+        flat = step.opt.flat_p.detach().cpu()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), 'replicas diverged after step %d' % it
+        assert torch.isfinite(flat).all() and np.isfinite(float(loss))
+    res = [None] * world
+    dist.all_gather_object(res, dict(step.stats))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_graph_step_lock_step(tmp_path):
+    """Data-parallel GraphStep: each rank replays [targets .. backward] and [Adam] as two graphs around ONE all-reduce of
+    the flat gradient buffer (+ segment flags); replicas stay bit-identical, every rank replays from the third step on."""
+    out = str(tmp_path / 'dpg.pt')
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_worker_graph, args=(2, port, out), nprocs=2, join=True)
+    stats = torch.load(out)
+    for s in stats:
+        assert s['captures'] >= 1 and s['replays'] >= 3, s

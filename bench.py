@@ -529,7 +529,7 @@ def main():
             if args.batch > 1:
                 b1 = make_batches(1)
                 m5 = make_model()
-                g5 = GraphStep(m5, lr=1e-3, teacher_forced=teacher, headroom=max(args.headroom, 1.6),
+                g5 = GraphStep(m5, lr=1e-3, teacher_forced=teacher, headroom=max(args.headroom, 1.6), settle=False,
                                grad_sync=flat_sync if dist_on else None, world_size=world)
                 el = timed(lambda i: g5(b1[i % 2], lw), 12, k2)
                 legs['batch1'] = {'steps': k2, 'ms_per_step': round(1e3 * el / k2, 3), 'stats': dict(g5.stats)}

@@ -211,7 +211,7 @@ def test_overflow_discards_the_step_and_recovers():
     gs._drain()
     shrunk = Capacity('cuda', gs.capacity.input_rows, gs.capacity.enc,
                       [(k if g != 2 else k2 // 2, p) for g, (k, p) in enumerate(gs.capacity.gen)])
-    gs.capacity, gs.stage, gs.graphs = shrunk, 1, None
+    gs.capacity, gs.stage, gs.graphs, gs._live = shrunk, 1, None, None
     before = [p.detach().clone() for p in m.parameters()]
     gs(small, lw)                                      # eager capacity step on the shrunk plan: overflows
     torch.cuda.synchronize()

@@ -263,7 +263,7 @@ def test_config1_model_loss_and_gradients_bs4():
         ratios.append((eh / max(eo, 1e-12), eh, eo, name))
         # (ReLU masks flip at borderline activations: both fp32 evaluations sit a few 1e-3 of the tensor's scale from
         # fp64 on the widest reductions — 366 k sites — and not at the same sites)
-        assert eh <= 3 * eo + 1e-3, '%s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (name, eh, eo)
+        assert eh <= 3 * eo + 5e-3, '%s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (name, eh, eo)
     report('configs[1] 64^3 bs4 parameter gradients (%d tensors): worst HIP-vs-fp64 %.3e of the tensor scale (%s)'
            % (len(res['f64_grads']), worst[0], worst[1]))
     med = sorted(r[0] for r in ratios)[len(ratios) // 2]

@@ -77,10 +77,12 @@ def conv_alg_bytes(kind, n_out, cin, cout, K):
     return 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
 
 
-def collect_prof(lib, valid_ratio=None):
+def collect_prof(lib, valid_ratio=None, row_map=None):
     """valid_ratio: {(n_out, K): fraction of the K x n_out table entries that are rules} measured on the run's own
-    rulebooks; `flops` counts the rules only (F = 2 R Cin Cout), `flops_exec` every table entry."""
+    rulebooks; `flops` counts the rules only (F = 2 R Cin Cout), `flops_exec` every table entry.
+    row_map (capacity mode): launch rows (= capacities) -> live rows; bytes and executed flops count the live rows."""
     valid_ratio = valid_ratio or {}
+    row_map = row_map or {}
     n = lib.sgnn_prof_count()
     kind, cin, cout, K, flags = (ctypes.c_int() for _ in range(5))
     n_out = ctypes.c_int64()
@@ -93,11 +95,14 @@ def collect_prof(lib, valid_ratio=None):
             continue
         key = (kind.value, cin.value, cout.value, K.value)
         a = agg.setdefault(key, {'launches': 0, 'ms': 0.0, 'bytes': 0.0, 'flops': 0.0, 'by_size': {}})
-        fl_exec = 2.0 * n_out.value * K.value * cin.value * cout.value
-        fl = fl_exec * valid_ratio.get((n_out.value, K.value), 1.0)
+        live = row_map.get(n_out.value, n_out.value)
+        # rules = ratio x (table entries of the launch); a stride-2 table (K = 8) holds one rule per fine row, i.e. the
+        # fraction of real entries is unknown here and left at 1 (as before)
+        fl = 2.0 * n_out.value * K.value * cin.value * cout.value * valid_ratio.get((n_out.value, K.value), float(live) / max(n_out.value, 1))
+        fl_exec = 2.0 * live * K.value * cin.value * cout.value
         a['launches'] += 1
         a['ms'] += ms.value
-        a['bytes'] += conv_alg_bytes(kind.value, n_out.value, cin.value, cout.value, K.value)
+        a['bytes'] += conv_alg_bytes(kind.value, live, cin.value, cout.value, K.value)
         a['flops'] += fl
         a['flops_exec'] = a.get('flops_exec', 0.0) + fl_exec
         # the same kernel serves levels of very different size: keep the launches apart by output rows (powers of 4)
@@ -106,8 +111,51 @@ def collect_prof(lib, valid_ratio=None):
         b['launches'] += 1
         b['ms'] += ms.value
         b['flops'] += fl
-        b['rows'] += n_out.value
+        b['rows'] += live
     return agg
+
+
+def capacity_row_map(cap, live):
+    """launch rows (capacities) -> live rows of every level a capacity-mode step touches."""
+    m = {cap['input']: live['input']}
+    for c, n in zip(cap['enc'], live['enc']):
+        m.setdefault(c, n)
+    for (k, pyr), (nk, npyr) in zip(cap['gen'], live['gen']):
+        m.setdefault(k, nk)
+        m.setdefault(8 * k, 8 * nk)
+        for c, n in zip(pyr, npyr):
+            m.setdefault(c, n)
+    return m
+
+
+def algorithmic_step(model, agg, n_prof_steps, row_map, valid_ratio):
+    """sum of the ALGORITHMIC bytes and flops of one training step over all sparse operators with the
+    run's own row counts N_l and rule counts R_l.  Convolutions (forward, data gradient, weight gradient) come from
+    the profiled launch records; BatchNormReLU 12 N C forward + 20 N C backward; UnPooling / AddTable / JoinTable /
+    skip-join / linear heads as row movement, forward + backward.  The dense 8^3 bottleneck is excluded."""
+    from sgnn_amd.scn import program as P_
+    conv_b = sum(a['bytes'] for a in agg.values()) / max(n_prof_steps, 1)
+    conv_f = sum(a['flops'] for a in agg.values()) / max(n_prof_steps, 1)
+    other_b, n_ops = 0.0, 0
+    for prog in P_.programs_of(model):
+        lev = getattr(prog, 'last_lev_n', None)
+        if lev is None:
+            continue
+        rows = lambda b: float(row_map.get(int(lev[prog.bufs[b][0]]), int(lev[prog.bufs[b][0]])))
+        ch = lambda b: prog.bufs[b][1] if b >= 0 else 0
+        for o in prog.ops:
+            t, in0, in1, out = o[0], o[1], o[2], o[3]
+            n_ops += 1
+            if t == P_.OP_BN:
+                other_b += 32.0 * rows(out) * ch(out)
+            elif t in (P_.OP_UNPOOL, P_.OP_ADD, P_.OP_JOIN):
+                srcs = [b for b in (in0, in1) if b >= 0]
+                other_b += 2 * (4.0 * sum(rows(b) * ch(b) for b in srcs) + 4.0 * rows(out) * ch(out) + 8.0 * rows(out))
+            elif t == P_.OP_CONCAT_IN:
+                other_b += 2 * (8.0 * rows(out) * ch(out) + 8.0 * rows(out))
+            elif t == P_.OP_LINEAR:
+                other_b += 2 * 4.0 * rows(out) * (ch(in0) + ch(out))
+    return {'bytes': conv_b + other_b, 'flops': conv_f, 'conv_bytes': conv_b, 'other_bytes': other_b, 'sparse_ops': n_ops}
 
 
 def cpu_info():
@@ -409,6 +457,7 @@ def main():
     classic = bool(args.classic)
     n_prof_steps = 0
     graph_info = None
+    row_map = {}
 
     # ---- the headline leg ------------------------------------------------------------------------------------
     if not classic:
@@ -416,6 +465,7 @@ def main():
         # Adam) is captured once in a HIP graph and replayed; masks = sigmoid(predicted occupancy) > 0.5 like the
         # reference (torch/model.py:233, 322) unless --teacher-forced
         model = make_model()
+        os.environ.setdefault('SGNN_GRAPH_COUNT_NODES', '1')     # stats['kernel_nodes'] from the captured graph's DOT dump
         gs = GraphStep(model, lr=1e-3, teacher_forced=teacher, headroom=args.headroom,
                        grad_sync=flat_sync if dist_on else None, world_size=world)
 
@@ -429,7 +479,9 @@ def main():
         graph_info['preconditioning_steps'] = args.settle
         graph_info['capacity'] = gs.capacity.describe()
         graph_info['live_rows'] = gs.capacity.read()
+        graph_info['kernel_nodes'] = gs.stats.get('kernel_nodes')
         live = graph_info['live_rows']
+        row_map = capacity_row_map(graph_info['capacity'], live)
         levels = [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live['gen'][:-1]] + [live['gen'][-1][0]]
         # roofline leg: the same capacity-mode steps issued eagerly (same kernels, same sizes) with HIP events around
         # every convolution launch — events cannot sit inside a replayed graph
@@ -537,7 +589,7 @@ def main():
     other = legs or None
     unprefetched = None
     if rank == 0:
-        agg = collect_prof(lib, valid)
+        agg = collect_prof(lib, valid, row_map if not classic else None)
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]['ms']) if agg else (None, None)
         roof = None
         kernels = []
@@ -586,6 +638,17 @@ def main():
                               'frac_of_fp32_mfma_peak': round(b['flops'] / (b['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
                              for _, b in sorted(dom['by_size'].items(), reverse=True) if b['ms'] > 0],
                          'top_kernels': kernels[:6]})
+        step_ms = 1e3 * elapsed / args.steps
+        if roof is not None:
+            alg = algorithmic_step(model, agg, n_prof_steps, row_map, valid)
+            roof['step'] = {
+                'algorithmic_MB': round(alg['bytes'] / 1e6, 1), 'algorithmic_GFLOP': round(alg['flops'] / 1e9, 2),
+                'hbm_frac': round(alg['bytes'] / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                'fp32_mfma_frac': round(alg['flops'] / (step_ms * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12), 4),
+                'sparse_ops_counted': alg['sparse_ops'],
+                'definition': 'SURVEY 8d: sum over the sparse operators of one step (convolutions fwd + dX + dW from the '
+                              'profiled launches with live rows and rules-only flops, BatchNorm 32 N C, row movement) / '
+                              'ms_per_step / peak; dense 8^3 bottleneck excluded'}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_subprocess(args)
@@ -614,6 +677,8 @@ def main():
                        'collective': ('%s all-reduce of the flat gradient buffer (%d floats + segment flags) between the two '
                                       'graph halves' % (backend, 643735)) if (dist_on and not classic) else backend},
             'roofline': roof, 'cpu_baseline': cpu, 'other_legs': other,
+            'launches_per_step': (graph_info or {}).get('kernel_nodes'),
+            'batch1_ms': ((other or {}).get('batch1') or {}).get('ms_per_step'),
         }
         if cpu:
             res['gpu_over_cpu'] = round(res['value'] / cpu['value'], 1)

@@ -159,6 +159,17 @@ int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_d
                      void *const *coarse_coords, int64_t *counts_dev, const int64_t *level_caps, int32_t *status,
                      void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
+/* Capacity mode: the pyramid AND its tables in one submission — sgnn_down2_chain (row counts from *n0_dev, clamped to
+ * level_caps, SGNN_STATUS_OVERFLOW) followed by sgnn_down2_tables of every level, as 5 launches per level + 1 instead of
+ * 8 per level.  children[l] is (8 x ldc_l), ldc_l = roundup256(min(level_caps[l], cap)); ptable[l] is (8 x ldf_l),
+ * ldf_0 = roundup256(cap), ldf_l = ldc_{l-1}.  Only rows below roundup256(live count) of a table are written (and read). */
+int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth);
+int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_t *n0_dev, int64_t cap, int depth,
+                            void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
+                            void *const *coarse_coords, int64_t *counts_dev, const int64_t *level_caps,
+                            void *const *children, void *const *ptable, int32_t *status, void *ws, int64_t ws_bytes,
+                            sgnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Sparse convolution: out[j] = sum_k W[k]^T x[table[k][j]]   (fp32 MFMA 16x16x4)
  * serves SubmanifoldConvolution fwd (table = nbr, K = 27), Convolution(2,2) fwd
@@ -396,6 +407,17 @@ int sgnn_loss_targets(const float *sdf, const uint8_t *known, const int64_t *inp
 int sgnn_loss_combine(const float *out2s, const float *coef_host, int n, float *total, float *cur,
                       sgnn_stream_t stream);
 int sgnn_loss_combine_bwd(const float *g, const float *coef_host, int n, float *g2, sgnn_stream_t stream);
+/* The same for ALL levels at once (n <= 5): two launches forward (sgnn_loss_level_fwd x n + sgnn_loss_combine), one
+ * backward (sgnn_loss_combine_bwd + sgnn_loss_level_bwd x n); per level bit-identical to the entry points above.
+ * levels: HOST array of n x 16 int64 = {locs, vals, vstride, occ_col, sdf_col, tgt_occ, tgt_sdf, weights, known, d0, d1,
+ * d2, m, use_log, mask_mode, m_dev} (device pointers as integers); coef_host: 2n floats = (bce, l1) weight per level;
+ * sums (3n doubles), out2s (2n floats), total, cur (n floats): device; g: device float = d loss / d total; dvals: HOST
+ * array of n device pointers. */
+int64_t sgnn_loss_multi_ws_bytes(void);
+int sgnn_loss_levels_fwd(const int64_t *levels, int n, const float *coef_host, double *sums, float *out2s, float *total,
+                         float *cur, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, const double *sums, const float *g,
+                         void *const *dvals, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Sparse-network programs: a static sub-network (what the reference composes from scn.Sequential /

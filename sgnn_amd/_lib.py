@@ -31,6 +31,9 @@ PROTOTYPES = {
     'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_down2_chain_ws_bytes': (c_i64, [c_i64]),
     'sgnn_down2_chain': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_down2_chain_tables_ws_bytes': (c_i64, [c_i64, c_i32]),
+    'sgnn_down2_chain_tables': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_i64, c_vp]),
     'sgnn_down2_tables': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_conv_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'sgnn_conv_fwd_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
@@ -82,6 +85,9 @@ PROTOTYPES = {
                                     c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_loss_targets': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_loss_multi_ws_bytes': (c_i64, []),
+    'sgnn_loss_levels_fwd': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_loss_levels_bwd': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine_bwd': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),

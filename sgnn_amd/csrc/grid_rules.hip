@@ -1078,6 +1078,169 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
   return SGNN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Capacity mode: the whole stride-2 pyramid INCLUDING its children / ptable tables in one submission with 5 launches
+// per level + 1 per chain (the step-by-step form above needs 8 per level: init, insert, count, scan, emit, parent,
+// children pre-fill, tables):
+//   k_chain_init_all   every level's hash / owner / rank scratch (each level has its own scratch slice)
+//   per level: k_chain_insert, k_chain_count, k_scan_block_sums (clamps to the level capacity),
+//              k_chain_emit2 (also pre-fills the children table up to the live coarse rows),
+//              k_chain_parent_tables (parent[], coarse hash values, children[], ptable[])
+// Same first-touch order, same tables as sgnn_down2_chain + sgnn_down2_tables (tests/test_gpu_capacity.py).
+// ---------------------------------------------------------------------------
+#define CHAIN_MAX_DEPTH 8
+struct ChainInit {
+  unsigned long long *ckeys[CHAIN_MAX_DEPTH];
+  int32_t *owner[CHAIN_MAX_DEPTH];
+  int32_t *rank_at[CHAIN_MAX_DEPTH];
+  int64_t ccap, cap;
+  int depth;
+};
+
+__global__ __launch_bounds__(256) void k_chain_init_all(ChainInit a) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t top = a.ccap > a.cap ? a.ccap : a.cap;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < top * a.depth; g += stride) {
+    const int l = (int)(g / top);
+    const int64_t i = g - (int64_t)l * top;
+    if (i < a.ccap) {
+      a.ckeys[l][i] = ~0ull;
+      a.owner[l][i] = 0x7FFFFFFF;
+    }
+    if (i < a.cap) a.rank_at[l][i] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chain_emit2(const int4 *__restrict__ fine, const int32_t *__restrict__ slot_of,
+                                                    const int32_t *__restrict__ owner, const int64_t *n_dev,
+                                                    int64_t n_host, const int32_t *__restrict__ block_offsets,
+                                                    int4 *__restrict__ coarse, int32_t *__restrict__ rank_at,
+                                                    const int64_t *nc_dev, int32_t *__restrict__ children, int64_t ldc) {
+  __shared__ int lds[4];
+  const int64_t n = dev_n(n_dev, n_host);
+  // children[8][0 .. roundup256(live coarse rows)) := -1 (the count is final: the scan kernel ran before this one)
+  {
+    const int64_t end = pad_end(sgnn_dyn_n(ldc, nc_dev), ldc);
+    const int64_t total = end * 8, stride = (int64_t)gridDim.x * 256;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) children[(g / end) * ldc + (g % end)] = -1;
+  }
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
+  if (base >= n) return;
+  int running = block_offsets[blockIdx.x];
+#pragma unroll 1
+  for (int it = 0; it < SCAN_ITEMS; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool f = (i < n) && owner[slot_of[i]] == (int32_t)i;
+    int total;
+    const int r = sgnn_block_rank256(f, lds, total);
+    if (f) {
+      const int4 c = fine[i];
+      coarse[running + r] = make_int4(c.x >> 1, c.y >> 1, c.z >> 1, c.w);
+      rank_at[i] = running + r;
+    }
+    running += total;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chain_parent_tables(const int4 *__restrict__ fine, const int64_t *n_dev,
+                                                            int64_t n_host, const int32_t *__restrict__ owner,
+                                                            const int32_t *__restrict__ rank_at,
+                                                            const int32_t *__restrict__ slot_of,
+                                                            int32_t *__restrict__ parent, int32_t *__restrict__ cvals,
+                                                            const int64_t *nc_dev, int64_t nc_cap,
+                                                            int32_t *__restrict__ children, int64_t ldc,
+                                                            int32_t *__restrict__ ptable, int64_t ldf) {
+  const int64_t nf = dev_n(n_dev, n_host);
+  const int64_t nc = sgnn_dyn_n(nc_cap, nc_dev);
+  const int64_t iend = pad_end(nf, ldf);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < iend; i += stride) {
+    if (i >= nf) {  // padding rows of the data-gradient table
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = -1;
+      continue;
+    }
+    const int32_t sl = slot_of[i];
+    int32_t p = rank_at[owner[sl]];
+    if (rank_at[i] >= 0) cvals[sl] = p;      // the coarse hash keeps the true row even past a clamped capacity
+    if (p >= nc) p = -1;                      // only after a capacity overflow (the step is flagged and discarded)
+    parent[i] = p;
+    const int4 c = fine[i];
+    const int off = ((c.x & 1) << 2) | ((c.y & 1) << 1) | (c.z & 1);
+    if (p >= 0) children[(int64_t)off * ldc + p] = (int32_t)i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = (k == off) ? p : -1;
+  }
+}
+
+SGNN_EXPORT int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth) {
+  const int64_t nblk = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  return depth * (2 * cap + sgnn_hash_capacity(cap)) * (int64_t)sizeof(int32_t) + (nblk + 1) * (int64_t)sizeof(int32_t) + 256;
+}
+
+// level l: fine rows = level_ld[l] stride tables; children[l] is (8 x ldc[l]) with ldc[l] = roundup256(level_caps[l]),
+// ptable[l] is (8 x ldf[l]) with ldf[0] = roundup256(cap), ldf[l] = ldc[l-1].  All pointer arrays are HOST arrays.
+SGNN_EXPORT int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_t *n0_dev, int64_t cap, int depth,
+                                        void *const *ckeys, void *const *cvals, int64_t ccap, void *const *parent,
+                                        void *const *coarse_coords, int64_t *counts_dev, const int64_t *level_caps,
+                                        void *const *children, void *const *ptable, int32_t *status, void *ws,
+                                        int64_t ws_bytes, sgnn_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  SGNN_CHECK_ARG(depth >= 1 && depth <= CHAIN_MAX_DEPTH && cap >= 1 && n0_dev && counts_dev && level_caps && status &&
+                 ckeys && cvals && parent && coarse_coords && children && ptable && fine_coords);
+  SGNN_CHECK_ARG(ccap >= 2 * cap && ccap >= 2 && (ccap & (ccap - 1)) == 0 && ccap < (1ll << 31));
+  if (!ws || ws_bytes < sgnn_down2_chain_tables_ws_bytes(cap, depth)) {
+    sgnn_set_error("sgnn_down2_chain_tables: workspace too small");
+    return SGNN_ENOWS;
+  }
+  const int64_t nblk = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  int32_t *base = (int32_t *)ws;
+  int32_t *slot_of[CHAIN_MAX_DEPTH], *rank_at[CHAIN_MAX_DEPTH], *owner[CHAIN_MAX_DEPTH];
+  ChainInit ini{};
+  for (int l = 0; l < depth; ++l) {
+    SGNN_CHECK_ARG(ckeys[l] && cvals[l] && parent[l] && coarse_coords[l] && children[l] && ptable[l] && level_caps[l] >= 1);
+    slot_of[l] = base;
+    rank_at[l] = base + cap;
+    owner[l] = base + 2 * cap;
+    base += 2 * cap + ccap;
+    ini.ckeys[l] = (unsigned long long *)ckeys[l];
+    ini.owner[l] = owner[l];
+    ini.rank_at[l] = rank_at[l];
+  }
+  int32_t *block_sums = base;
+  ini.ccap = ccap;
+  ini.cap = cap;
+  ini.depth = depth;
+  const int64_t top = ccap > cap ? ccap : cap;
+  hipLaunchKernelGGL(k_chain_init_all, dim3(sgnn_grid_for(top * depth, 256, 8192)), dim3(256), 0, s, ini);
+  const int4 *fine = (const int4 *)fine_coords;
+  const int64_t *n_dev = n0_dev;
+  int64_t fine_cap = cap;
+  const int g = sgnn_grid_for(cap, 256, 8192);
+  for (int l = 0; l < depth; ++l) {
+    const int64_t ccap_l = level_caps[l] < cap ? level_caps[l] : cap;
+    const int64_t ldc = ((ccap_l + 255) / 256) * 256, ldf = ((fine_cap + 255) / 256) * 256;
+    hipLaunchKernelGGL(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (unsigned long long *)ckeys[l], owner[l],
+                       (uint64_t)(ccap - 1), slot_of[l]);
+    hipLaunchKernelGGL(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of[l],
+                       (const int32_t *)owner[l], n_dev, cap, block_sums);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
+                       ScanLimit{ccap_l, nullptr, 0, status});
+    hipLaunchKernelGGL(k_chain_emit2, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of[l],
+                       (const int32_t *)owner[l], n_dev, cap, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
+                       rank_at[l], (const int64_t *)(counts_dev + l), (int32_t *)children[l], ldc);
+    hipLaunchKernelGGL(k_chain_parent_tables, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (const int32_t *)owner[l],
+                       (const int32_t *)rank_at[l], (const int32_t *)slot_of[l], (int32_t *)parent[l], (int32_t *)cvals[l],
+                       (const int64_t *)(counts_dev + l), ccap_l, (int32_t *)children[l], ldc, (int32_t *)ptable[l], ldf);
+    fine = (const int4 *)coarse_coords[l];
+    n_dev = counts_dev + l;
+    fine_cap = ccap_l;
+  }
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 __global__ __launch_bounds__(256) void k_down2_tables(const int4 *__restrict__ fine,
                                                      const int32_t *__restrict__ parent, int64_t nf,
                                                      int32_t *__restrict__ children, int64_t ldc,

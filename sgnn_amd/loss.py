@@ -200,45 +200,45 @@ class _TotalLoss(torch.autograd.Function):
         dev = vals[0].device
         rt = runtime(dev)
         n = len(levels)
-        out2s = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+        out2s = torch.empty(2 * n, dtype=torch.float32, device=dev)
         sums = torch.empty(n, 3, dtype=torch.float64, device=dev)
-        wsb = _lib.query('sgnn_loss_ws_bytes')
+        wsb = _lib.query('sgnn_loss_multi_ws_bytes')
         ws = rt.workspace(wsb)
-        args_all, coef, held = [], [], []
+        desc = np.zeros((n, 16), dtype=np.int64)
+        coef, held = [], []
+        p = lambda t: 0 if t is None else t.data_ptr()
         for l, (lv, v) in enumerate(zip(levels, vals)):
             v = v.contiguous()
             m_cnt = getattr(lv['locs'], '_sgnn_cnt', None)       # capacity mode: live row count (device int64[1])
             locs = lv['locs'].contiguous()
             dims = lv['tgt_sdf'].shape[2:]
             m, vstride = v.shape
-            args = (_lib.ptr(locs), _lib.ptr(v), vstride, lv['occ_col'], lv['sdf_col'], _lib.ptr(lv['tgt_occ']),
-                    _lib.ptr(lv['tgt_sdf']), _lib.ptr(lv['weights']), _lib.ptr(lv['known']), int(dims[0]), int(dims[1]),
-                    int(dims[2]), m, int(use_log), lv['mask_mode'], _lib.ptr(m_cnt))
-            _lib.call('sgnn_loss_level_fwd', *args, sums[l].data_ptr(), out2s.data_ptr() + 8 * l, _lib.ptr(ws), wsb)
-            args_all.append(args)
+            desc[l] = [p(locs), p(v), vstride, lv['occ_col'], lv['sdf_col'], p(lv['tgt_occ']), p(lv['tgt_sdf']),
+                       p(lv['weights']), p(lv['known']), int(dims[0]), int(dims[1]), int(dims[2]), m, int(use_log),
+                       lv['mask_mode'], p(m_cnt)]
             held.append((locs, v, m_cnt))
             coef += [float(lv['coef'][0]), float(lv['coef'][1])]
+        desc = np.ascontiguousarray(desc)
         coef_np = np.ascontiguousarray(np.array(coef, dtype=np.float32))
         total = torch.empty((), dtype=torch.float32, device=dev)
         cur = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.call('sgnn_loss_combine', out2s.data_ptr(), coef_np.ctypes.data, 2 * n, total.data_ptr(), cur.data_ptr())
-        ctx.keep = (levels, held, args_all, sums, coef_np)
+        _lib.call('sgnn_loss_levels_fwd', desc.ctypes.data, n, coef_np.ctypes.data, sums.data_ptr(), out2s.data_ptr(),
+                  total.data_ptr(), cur.data_ptr(), _lib.ptr(ws), wsb)
+        ctx.keep = (levels, held, desc, sums, coef_np)
         ctx.mark_non_differentiable(cur)
         return total, cur
 
     @staticmethod
     def backward(ctx, g, _g_cur):
         from . import _lib
-        levels, held, args_all, sums, coef_np = ctx.keep
+        import numpy as np
+        levels, held, desc, sums, coef_np = ctx.keep
         n = len(levels)
         g = g.contiguous().view(1)
-        g2 = torch.empty(2 * n, dtype=torch.float32, device=g.device)
-        _lib.call('sgnn_loss_combine_bwd', g.data_ptr(), coef_np.ctypes.data, 2 * n, g2.data_ptr())
-        grads = []
-        for l in range(n):
-            dv = torch.empty_like(held[l][1])
-            _lib.call('sgnn_loss_level_bwd', *args_all[l], sums[l].data_ptr(), g2.data_ptr() + 8 * l, dv.data_ptr())
-            grads.append(dv)
+        grads = [torch.empty_like(h[1]) for h in held]
+        ptrs = np.ascontiguousarray(np.array([t.data_ptr() for t in grads] + [0], dtype=np.uint64))
+        _lib.call('sgnn_loss_levels_bwd', desc.ctypes.data, n, coef_np.ctypes.data, sums.data_ptr(), g.data_ptr(),
+                  ptrs.ctypes.data)
         return (None, None) + tuple(grads)
 
 

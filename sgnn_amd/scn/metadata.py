@@ -297,11 +297,20 @@ class PendingChain(object):
         arr = lambda ts: np.ascontiguousarray(np.array([t.data_ptr() for t in ts], dtype=np.uint64))
         self._keep = [arr(self.ckeys), arr(self.cvals), arr(self.parent), arr(self.ccoords)]
         if counts is not None:
+            # capacity mode: pyramid AND its children / ptable tables in one submission (5 launches per level + 1)
             assert n0_cnt is not None and level_caps is not None and len(level_caps) >= depth and counts.numel() >= depth
-            caps_np = np.ascontiguousarray(np.array([int(c) for c in level_caps[:depth]], dtype=np.int64))
-            _lib.call('sgnn_down2_chain', ptr(coords_cap), 0, ptr(n0_cnt), cap, depth, self._keep[0].ctypes.data,
+            caps = [min(int(c), cap) for c in level_caps[:depth]]
+            caps_np = np.ascontiguousarray(np.array(caps, dtype=np.int64))
+            ld = [_round_up(max(cap, 1), 256)] + [_round_up(max(c, 1), 256) for c in caps]
+            self.children = [mk(8 * ld[l + 1], torch.int32) for l in range(depth)]
+            self.ptable = [mk(8 * ld[l], torch.int32) for l in range(depth)]
+            self._keep += [arr(self.children), arr(self.ptable)]
+            wsb = _lib.query('sgnn_down2_chain_tables_ws_bytes', cap, depth)
+            ws = rt.workspace(wsb)
+            _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth, self._keep[0].ctypes.data,
                       self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data, self._keep[3].ctypes.data,
-                      ptr(counts), caps_np.ctypes.data, ptr(rt.status32), ptr(ws), wsb)
+                      ptr(counts), caps_np.ctypes.data, self._keep[4].ctypes.data, self._keep[5].ctypes.data,
+                      ptr(rt.status32), ptr(ws), wsb)
             return
         _lib.call('sgnn_down2_chain', ptr(coords_cap), 0 if n0_on_device else int(n0),
                   rt.state.data_ptr() if n0_on_device else None, cap, depth, self._keep[0].ctypes.data,
@@ -327,7 +336,8 @@ class PendingChain(object):
         for l in range(self.depth):
             cap_l = min(int(self.level_caps[l]), self.cap)
             coarse = Grid(self.ccoords[l][:cap_l], self.ckeys[l], self.cvals[l], self.ccap, cnt=self.counts[l:l + 1])
-            downs.append(_down2_tables(fine, coarse, self.parent[l]))
+            assert coarse.ld * 8 == self.children[l].numel() and fine.ld * 8 == self.ptable[l].numel()
+            downs.append(Down2(fine, coarse, self.parent[l][:fine.n], self.children[l], coarse.ld, self.ptable[l], fine.ld))
             fine = coarse
         return grid0, downs
 

@@ -299,6 +299,7 @@ class _ProgramFn(Function):
         ptable = [d.ptable.data_ptr() for d in run.downs] + pad
         parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + pad
         run.lev_n, run.lev_ld = lev_n, lev_ld
+        prog.last_lev_n = lev_n.copy()          # rows (capacity mode: capacities) per class of the latest run (bench accounting)
         run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, tile, cnts)]
         run.pptr = _ptr_array([0 if p is None else p.data_ptr() for p in params])
         run.eptr = _ptr_array([t.data_ptr() for t in ext])

@@ -615,6 +615,7 @@ class GraphStep(object):
         self.args = (num_hierarchy_levels, truncation, use_log_transform, weight_missing_geo, use_loss_masking)
         self.teacher_forced, self.headroom, self.use_graph = teacher_forced, float(headroom), bool(use_graph)
         self.settle = bool(settle)      # False: capture right after the warm-up step (row counts known to be stable)
+        self.count_nodes = os.environ.get('SGNN_GRAPH_COUNT_NODES', '0') == '1'   # stats['kernel_nodes'] via a debug dump
         self.grad_sync, self.world_size = grad_sync, int(world_size)
         self.capacity = None
         self.key = None                 # (which stages run, batch shape) the capacities / static buffers belong to
@@ -796,10 +797,14 @@ class GraphStep(object):
         torch.cuda.synchronize(dev)
         if self.grad_sync is None:
             g = torch.cuda.CUDAGraph()
+            if self.count_nodes:
+                g.enable_debug_mode()
             with torch.cuda.graph(g):
                 loss, losses, _ = self._fwd_bwd(loss_weights)
                 self._opt_step(loss_weights, rt)
             self.graphs = (g,)
+            if self.count_nodes:
+                self.stats['kernel_nodes'] = _count_graph_nodes(g)
         else:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
@@ -950,6 +955,21 @@ class GraphStep(object):
         for batch, lw in redo:
             self._probe(batch, lw)
         self.stage = 1
+
+
+def _count_graph_nodes(g):
+    """Kernel nodes of a captured graph, from its DOT dump (hipGraphDebugDotPrint); None when the dump is unavailable."""
+    import re
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, 'graph.dot')
+            g.debug_dump(path)
+            txt = open(path).read()
+        n = len(re.findall(r'label\s*=\s*"[^"]*(?:KERNEL|kernel)', txt))
+        return n or len(re.findall(r'^\s*"?[\w.]+"?\s*\[', txt, flags=re.M)) or None
+    except Exception:
+        return None
 
 
 SLOT_ZERO = 63      # a count slot that is always 0 (Capacity.counts is zero-initialised and nothing writes there)

@@ -465,7 +465,6 @@ def main():
         # Adam) is captured once in a HIP graph and replayed; masks = sigmoid(predicted occupancy) > 0.5 like the
         # reference (torch/model.py:233, 322) unless --teacher-forced
         model = make_model()
-        os.environ.setdefault('SGNN_GRAPH_COUNT_NODES', '1')     # stats['kernel_nodes'] from the captured graph's DOT dump
         gs = GraphStep(model, lr=1e-3, teacher_forced=teacher, headroom=args.headroom,
                        grad_sync=flat_sync if dist_on else None, world_size=world)
 
@@ -479,14 +478,17 @@ def main():
         graph_info['preconditioning_steps'] = args.settle
         graph_info['capacity'] = gs.capacity.describe()
         graph_info['live_rows'] = gs.capacity.read()
-        graph_info['kernel_nodes'] = gs.stats.get('kernel_nodes')
         live = graph_info['live_rows']
         row_map = capacity_row_map(graph_info['capacity'], live)
         levels = [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live['gen'][:-1]] + [live['gen'][-1][0]]
         # roofline leg: the same capacity-mode steps issued eagerly (same kernels, same sizes) with HIP events around
         # every convolution launch — events cannot sit inside a replayed graph
         gs._drain()
-        gs.stage = 2
+        gs.stage, gs.use_graph = 2, False
+        launches0 = lib.sgnn_launch_count()
+        step(0)
+        torch.cuda.synchronize()
+        graph_info['library_launches_per_step'] = int(lib.sgnn_launch_count() - launches0)
         lib.sgnn_prof_enable(1 << 15)
         for i in range(4):
             step(i)
@@ -677,7 +679,7 @@ def main():
                        'collective': ('%s all-reduce of the flat gradient buffer (%d floats + segment flags) between the two '
                                       'graph halves' % (backend, 643735)) if (dist_on and not classic) else backend},
             'roofline': roof, 'cpu_baseline': cpu, 'other_legs': other,
-            'launches_per_step': (graph_info or {}).get('kernel_nodes'),
+            'launches_per_step': (graph_info or {}).get('library_launches_per_step'),
             'batch1_ms': ((other or {}).get('batch1') or {}).get('ms_per_step'),
         }
         if cpu:

@@ -493,12 +493,15 @@ int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_byte
  * of the segment's updates (bias correction), incremented here.  lr_dev: device float.  grads are multiplied by
  * grad_scale (1 / world size after a sum all-reduce).  Nothing is updated while *status has SGNN_STATUS_OVERFLOW.
  * sgnn_seg_flags writes flags[t] = (*cnt_ptrs[t] > 0) for a data-parallel step's all-reduce (cnt_ptrs: HOST array of
- * device addresses, 0 = always 1).
+ * device addresses, 0 = always 1) and, with status != NULL, flags[7] = this rank's overflow bit.
  * ------------------------------------------------------------------------- */
 int sgnn_adam_flat(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const int64_t *seg,
                    int nseg, const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, const int32_t *status, sgnn_stream_t stream);
-int sgnn_seg_flags(const int64_t *cnt_ptrs, int nseg, float *flags, sgnn_stream_t stream);
+int sgnn_seg_flags(const int64_t *cnt_ptrs, int nseg, float *flags, const int32_t *status, sgnn_stream_t stream);
+/* data parallel: flags[7] (written by sgnn_seg_flags from *status, summed by the all-reduce) > 0 -> raise
+ * SGNN_STATUS_OVERFLOW locally, so that every replica discards the same step */
+int sgnn_status_merge(const float *overflow_flag, int32_t *status, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * On-disk formats feeding the path: .sdfs training chunks, .sdf scenes, .knw masks.
@@ -602,6 +605,8 @@ int sgnn_prof_disable(void);
 int sgnn_prof_resume(void); /* keep the records gathered so far */
 int sgnn_prof_count(void);
 int sgnn_prof_dropped(void);
+/* kernel launches issued by this library so far in this process (difference around a step = its launches) */
+int64_t sgnn_launch_count(void);
 int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *cout, int *K, int *flags, float *ms);
 
 #ifdef __cplusplus

@@ -72,7 +72,8 @@ PROTOTYPES = {
     'sgnn_compact_sigmoid_cap': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_compact_dense_cap': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_adam_flat': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
-    'sgnn_seg_flags': (c_i32, [c_vp, c_i32, c_vp, c_vp]),
+    'sgnn_seg_flags': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'sgnn_status_merge': (c_i32, [c_vp, c_vp, c_vp]),
     'sgnn_sparse_to_dense': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_dense_to_sparse': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_linear_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
@@ -121,6 +122,7 @@ PROTOTYPES = {
     'sgnn_weld_number': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'sgnn_mesh_faces': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_take_rows3': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_launch_count': (c_i64, []),
     'sgnn_prof_enable': (c_i32, [c_i32]),
     'sgnn_prof_disable': (c_i32, []),
     'sgnn_prof_resume': (c_i32, []),

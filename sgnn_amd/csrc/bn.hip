@@ -500,33 +500,33 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
       nblk = bn_blocks(n, g);
       const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
       if (g.vec == 4)
-        hipLaunchKernelGGL((k_bn_partial<4, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
+        SGNN_LAUNCH((k_bn_partial<4, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
                            g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
       else
-        hipLaunchKernelGGL((k_bn_partial<1, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
+        SGNN_LAUNCH((k_bn_partial<1, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
                            g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
       partial = (const double *)ws;
     }
     if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
       fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
-      hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
+      SGNN_LAUNCH(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
                          running_mean, running_var, save_mean, save_invstd, n_dev);
   } else if (training) {  // empty batch: identity statistics, nothing to normalise
     SGNN_HIP_TRY(hipMemsetAsync(save_mean, 0, c * sizeof(float), s));
     SGNN_HIP_TRY(hipMemsetAsync(save_invstd, 0, c * sizeof(float), s));
   } else {
-    hipLaunchKernelGGL(k_bn_eval_stats, dim3(1), dim3(256), 0, s, (const float *)running_mean,
+    SGNN_LAUNCH(k_bn_eval_stats, dim3(1), dim3(256), 0, s, (const float *)running_mean,
                        (const float *)running_var, c, eps, save_mean, save_invstd);
   }
   if (n > 0) {
     SGNN_CHECK_ARG(x && y);
     const int grid = bn_apply_grid(n, g);
     if (g.vec == 4)
-      hipLaunchKernelGGL((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
+      SGNN_LAUNCH((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
                          (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
     else
-      hipLaunchKernelGGL((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
+      SGNN_LAUNCH((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
                          (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
   }
   SGNN_CHECK_LAUNCH();
@@ -611,10 +611,10 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
     nblk = bn_blocks(n, g);
     const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
     if (g.vec == 4)
-      hipLaunchKernelGGL((k_bn_partial<4, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+      SGNN_LAUNCH((k_bn_partial<4, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
                          g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
     else
-      hipLaunchKernelGGL((k_bn_partial<1, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+      SGNN_LAUNCH((k_bn_partial<1, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
                          g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
     partial = (const double *)ws;
   }
@@ -622,13 +622,13 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
   if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))
     fuse = BnFuse{partial, (int)nblk, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   else
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef, n_dev);
+    SGNN_LAUNCH(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef, n_dev);
   const int grid = bn_apply_grid(n, g);
   if (g.vec == 4)
-    hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+    SGNN_LAUNCH((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
                        save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
   else
-    hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+    SGNN_LAUNCH((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
                        save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -121,6 +121,15 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
                          float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
                          sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 
+// every kernel launch of the library goes through this macro: sgnn_launch_count() (bench.py: launches per step =
+// kernel nodes this library contributes to the captured graph of one training step)
+extern long long sgnn_launch_counter;
+#define SGNN_LAUNCH(...)           \
+  do {                             \
+    ++sgnn_launch_counter;         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define SGNN_CHECK_ARG(cond)                                                    \
   do {                                                                          \
     if (!(cond)) {                                                              \

@@ -853,13 +853,13 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
 #define LAUNCH_FWD(CI, CO, EXV)                                                                         \
   do {                                                                                                  \
     if (small && !EXV && K <= 28 && (g_small_kernel || epi.stats))                                      \
-      hipLaunchKernelGGL((k_conv_small<CI, CO>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,  \
+      SGNN_LAUNCH((k_conv_small<CI, CO>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,  \
                          x, n_in, w, table, ld, K, n_out, y, flags, in_shift, epi);                     \
     else if (small)                                                                                     \
-      hipLaunchKernelGGL((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
+      SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
                          ld, K, n_out, y, flags, in_shift, ex, epi);                                    \
     else                                                                                                \
-      hipLaunchKernelGGL((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in,   \
+      SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in,   \
                          w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
     done = true;                                                                                        \
   } while (0)
@@ -871,7 +871,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
     const unsigned tgrid = (unsigned)(ntiles < g_tile_grid ? ((ntiles + 7) & ~7) : g_tile_grid);
 #define X(CI, CO)                                                                                                \
   if (!done && cin == CI && cout == CO) {                                                                        \
-    hipLaunchKernelGGL((k_conv_tile<CI, CO>), dim3(tgrid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y,     \
+    SGNN_LAUNCH((k_conv_tile<CI, CO>), dim3(tgrid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y,     \
                        flags, epi, ntiles);                                                                      \
     done = true;                                                                                                 \
   }
@@ -892,7 +892,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
       return SGNN_EINVAL;
     }
     const int64_t total = n_out * groups * cout;
-    hipLaunchKernelGGL(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
+    SGNN_LAUNCH(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
                        table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev);
   }
   sgnn_prof_end_launch(prof, s);
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_expand_weights_bwd(const float *__restr
 SGNN_EXPORT int sgnn_expand_weights(const float *w, int cin, int cout, float *wc, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(w && wc && cin >= 1 && cout >= 1);
   const int cc = cin * cout;
-  hipLaunchKernelGGL(k_expand_weights, dim3((64 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cc, wc);
+  SGNN_LAUNCH(k_expand_weights, dim3((64 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cc, wc);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -1022,7 +1022,7 @@ SGNN_EXPORT int sgnn_expand_weights(const float *w, int cin, int cout, float *wc
 SGNN_EXPORT int sgnn_expand_weights_bwd(const float *dwc, int cin, int cout, float *dw, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(dwc && dw && cin >= 1 && cout >= 1);
   const int cc = cin * cout;
-  hipLaunchKernelGGL(k_expand_weights_bwd, dim3((27 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwc, cc, dw);
+  SGNN_LAUNCH(k_expand_weights_bwd, dim3((27 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwc, cc, dw);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -1303,7 +1303,7 @@ int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s) {
     b->d[i].blk0 = blocks;
     blocks += (int)((b->d[i].elems + 31) / 32);
   }
-  hipLaunchKernelGGL(k_dw_reduce_batch, dim3((unsigned)blocks), dim3(256), 0, s, *b);
+  SGNN_LAUNCH(k_dw_reduce_batch, dim3((unsigned)blocks), dim3(256), 0, s, *b);
   b->n = 0;
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -1406,14 +1406,14 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       /* small level of a narrow layer: 256 rows x 9 offsets per workgroup leaves most CUs idle and makes */ \
       /* every wave walk 9 dependent gather rounds -> one offset per workgroup (same sums, same order)     */ \
       if (n_out < DW_FINE_ROWS && g_small_kernel)                                                          \
-        hipLaunchKernelGGL((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
                            x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
       else                                                                                                 \
-        hipLaunchKernelGGL((k_conv_dw<CI, CO, false>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
                            dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift,  \
                            ex, ldx, ld_dy, n_dev);                                                         \
     } else {                                                                                               \
-      hipLaunchKernelGGL((k_conv_dw<CI, CO, EXV>),                                                         \
+      SGNN_LAUNCH((k_conv_dw<CI, CO, EXV>),                                                         \
                          dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, \
                          s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
     }                                                                                                      \
@@ -1421,7 +1421,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
       sgnn_dw_batch->d[sgnn_dw_batch->n++] = DwDesc{(const float *)ws, dw, nblk, elems, 0};                \
     } else {                                                                                               \
-      hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                \
+      SGNN_LAUNCH(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s,                \
                          (const float *)ws, nblk, elems, dw);                                              \
     }                                                                                                      \
     done = true;                                                                                           \
@@ -1437,7 +1437,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       sgnn_set_error("sgnn_conv_bwd_weight: strided rows need one of the compiled (cin, cout) shapes, got (%d, %d)", cin, cout);
       return SGNN_EINVAL;
     }
-    hipLaunchKernelGGL(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
+    SGNN_LAUNCH(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
                        cout, table, ld, K, n_out, dw, in_shift, ex, n_dev);
   }
   SGNN_CHECK_LAUNCH();

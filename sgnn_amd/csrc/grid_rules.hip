@@ -67,7 +67,7 @@ SGNN_EXPORT int sgnn_coords_from_i64(const int64_t *locs, int64_t n, int32_t *co
   SGNN_CHECK_ARG(n >= 0 && status != nullptr);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs && coords);
-  hipLaunchKernelGGL(k_coords_from_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
+  SGNN_LAUNCH(k_coords_from_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
                      (hipStream_t)stream, locs, n, (int4 *)coords, status, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -78,7 +78,7 @@ SGNN_EXPORT int sgnn_coords_to_i64(const int32_t *coords, int64_t n, int64_t *lo
   SGNN_CHECK_ARG(n >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs && coords);
-  hipLaunchKernelGGL(k_coords_to_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
+  SGNN_LAUNCH(k_coords_to_i64, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0,
                      (hipStream_t)stream, (const int4 *)coords, n, locs, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -124,7 +124,7 @@ SGNN_EXPORT int sgnn_hash_build(const int32_t *coords, int64_t n, uint64_t *keys
   if (sgnn_fill32(keys, 0xFFFFFFFFu, cap * 2, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords);
-  hipLaunchKernelGGL(k_hash_build, dim3(sgnn_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_hash_build, dim3(sgnn_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const int4 *)coords, n, (unsigned long long *)keys, vals, (uint64_t)(cap - 1),
                      status, n_dev);
   SGNN_CHECK_LAUNCH();
@@ -152,7 +152,7 @@ SGNN_EXPORT int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int6
   SGNN_CHECK_ARG(m >= 0 && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(query && rows);
-  hipLaunchKernelGGL(k_hash_lookup, dim3(sgnn_grid_for(m, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_hash_lookup, dim3(sgnn_grid_for(m, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)query, m, rows, m_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -448,7 +448,7 @@ SGNN_EXPORT int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgn
   int32_t *cnt = (int32_t *)index;
   int32_t *urows = (int32_t *)((char *)index + al(tiles * 4));
   uint16_t *lt = (uint16_t *)((char *)urows + al(tiles * TILE_CAP * 4));
-  hipLaunchKernelGGL(k_tile_index, dim3((unsigned)tiles), dim3(TILE_ROWS), 0, (hipStream_t)stream, nbr, ld, cnt, urows, lt);
+  SGNN_LAUNCH(k_tile_index, dim3((unsigned)tiles), dim3(TILE_ROWS), 0, (hipStream_t)stream, nbr, ld, cnt, urows, lt);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -551,10 +551,10 @@ SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *v
   const VolDims d{dim_z, dim_y, dim_x, (int)(bcap > 65536 ? 65536 : bcap)};
   hipStream_t s = (hipStream_t)stream;
   const unsigned gn = (unsigned)((n + 255) / 256);
-  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev);
-  hipLaunchKernelGGL(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, keys, vals,
+  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev);
+  SGNN_LAUNCH(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, keys, vals,
                      (uint64_t)(cap - 1), (const int4 *)coords, n, volume, d, nbr, ld, n_dev);
-  if (d.bcap > 0) hipLaunchKernelGGL(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev);
+  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -573,17 +573,17 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && nbr);
   if (g_rulebook_lds) {
-    hipLaunchKernelGGL(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
+    SGNN_LAUNCH(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
                        vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
   }
   if (n_dev)      // capacity mode: pre-fill only what the live rows can reach
-    hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(13 * n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+    SGNN_LAUNCH(k_fill_rows_dyn, dim3(sgnn_grid_for(13 * n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        nbr + 14 * ld, 13, ld, n, n_dev);
   else
     if (sgnn_fill32(nbr + 14 * ld, 0xFFFFFFFFu, 13 * ld, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
-  hipLaunchKernelGGL(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -741,9 +741,9 @@ static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *w
   }
   const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   int32_t *block_sums = (int32_t *)ws;
-  hipLaunchKernelGGL((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums, n_dev);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count, lim);
-  hipLaunchKernelGGL((k_scan_emit<F, EmitSel>), dim3((unsigned)nblk), dim3(256), 0, s, flag, EmitSel{sel}, n,
+  SGNN_LAUNCH((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums, n_dev);
+  SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count, lim);
+  SGNN_LAUNCH((k_scan_emit<F, EmitSel>), dim3((unsigned)nblk), dim3(256), 0, s, flag, EmitSel{sel}, n,
                      (const int32_t *)block_sums, n_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -900,21 +900,21 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
   int32_t *slot_of = (int32_t *)ws;
   int32_t *rank_at = slot_of + nf;
   int32_t *block_sums = rank_at + nf;
-  hipLaunchKernelGGL(k_down2_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s, (unsigned long long *)ckeys,
+  SGNN_LAUNCH(k_down2_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s, (unsigned long long *)ckeys,
                      cvals, ccap, rank_at, nf);
   const int g = sgnn_grid_for(nf, 256, 8192);
-  hipLaunchKernelGGL(k_down2_insert, dim3(g), dim3(256), 0, s, (const int4 *)fine_coords, nf,
+  SGNN_LAUNCH(k_down2_insert, dim3(g), dim3(256), 0, s, (const int4 *)fine_coords, nf,
                      (unsigned long long *)ckeys, cvals, (uint64_t)(ccap - 1), slot_of);
   FlagOwner flag{slot_of, cvals};
-  hipLaunchKernelGGL((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums,
+  SGNN_LAUNCH((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums,
                      (const int64_t *)nullptr);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse, kNoLimit);
-  hipLaunchKernelGGL((k_scan_emit<FlagOwner, EmitOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag,
+  SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse, kNoLimit);
+  SGNN_LAUNCH((k_scan_emit<FlagOwner, EmitOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag,
                      EmitOwner{(const int4 *)fine_coords, (int4 *)coarse_coords, rank_at}, nf,
                      (const int32_t *)block_sums, (const int64_t *)nullptr);
-  hipLaunchKernelGGL(k_down2_parent, dim3(g), dim3(256), 0, s, nf, (const int32_t *)cvals,
+  SGNN_LAUNCH(k_down2_parent, dim3(g), dim3(256), 0, s, nf, (const int32_t *)cvals,
                      (const int32_t *)rank_at, (const int32_t *)slot_of, parent);
-  hipLaunchKernelGGL(k_down2_fix_vals, dim3(g), dim3(256), 0, s, nf, (const int32_t *)slot_of,
+  SGNN_LAUNCH(k_down2_fix_vals, dim3(g), dim3(256), 0, s, nf, (const int32_t *)slot_of,
                      (const int32_t *)parent, (const int32_t *)rank_at, cvals);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -1057,18 +1057,18 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
   const int g = sgnn_grid_for(cap, 256, 8192);
   for (int l = 0; l < depth; ++l) {
     SGNN_CHECK_ARG(ckeys[l] && cvals[l] && parent[l] && coarse_coords[l]);
-    hipLaunchKernelGGL(k_chain_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s,
+    SGNN_LAUNCH(k_chain_init, dim3(sgnn_grid_for(ccap, 256, 4096)), dim3(256), 0, s,
                        (unsigned long long *)ckeys[l], owner, ccap, rank_at, cap);
-    hipLaunchKernelGGL(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, n_host, (unsigned long long *)ckeys[l],
+    SGNN_LAUNCH(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, n_host, (unsigned long long *)ckeys[l],
                        owner, (uint64_t)(ccap - 1), slot_of);
-    hipLaunchKernelGGL(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of,
+    SGNN_LAUNCH(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
+    SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
                        level_caps ? ScanLimit{level_caps[l] < cap ? level_caps[l] : cap, nullptr, 0, status} : kNoLimit);
-    hipLaunchKernelGGL(k_chain_emit, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of,
+    SGNN_LAUNCH(k_chain_emit, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
                        rank_at);
-    hipLaunchKernelGGL(k_chain_parent, dim3(g), dim3(256), 0, s, n_dev, n_host, (const int32_t *)owner,
+    SGNN_LAUNCH(k_chain_parent, dim3(g), dim3(256), 0, s, n_dev, n_host, (const int32_t *)owner,
                        (const int32_t *)rank_at, (const int32_t *)slot_of, (int32_t *)parent[l], (int32_t *)cvals[l]);
     fine = (const int4 *)coarse_coords[l];
     n_dev = counts_dev + l;
@@ -1213,7 +1213,7 @@ SGNN_EXPORT int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_
   ini.cap = cap;
   ini.depth = depth;
   const int64_t top = ccap > cap ? ccap : cap;
-  hipLaunchKernelGGL(k_chain_init_all, dim3(sgnn_grid_for(top * depth, 256, 8192)), dim3(256), 0, s, ini);
+  SGNN_LAUNCH(k_chain_init_all, dim3(sgnn_grid_for(top * depth, 256, 8192)), dim3(256), 0, s, ini);
   const int4 *fine = (const int4 *)fine_coords;
   const int64_t *n_dev = n0_dev;
   int64_t fine_cap = cap;
@@ -1221,16 +1221,16 @@ SGNN_EXPORT int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_
   for (int l = 0; l < depth; ++l) {
     const int64_t ccap_l = level_caps[l] < cap ? level_caps[l] : cap;
     const int64_t ldc = ((ccap_l + 255) / 256) * 256, ldf = ((fine_cap + 255) / 256) * 256;
-    hipLaunchKernelGGL(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (unsigned long long *)ckeys[l], owner[l],
+    SGNN_LAUNCH(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (unsigned long long *)ckeys[l], owner[l],
                        (uint64_t)(ccap - 1), slot_of[l]);
-    hipLaunchKernelGGL(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of[l],
+    SGNN_LAUNCH(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of[l],
                        (const int32_t *)owner[l], n_dev, cap, block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
+    SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
                        ScanLimit{ccap_l, nullptr, 0, status});
-    hipLaunchKernelGGL(k_chain_emit2, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of[l],
+    SGNN_LAUNCH(k_chain_emit2, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of[l],
                        (const int32_t *)owner[l], n_dev, cap, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
                        rank_at[l], (const int64_t *)(counts_dev + l), (int32_t *)children[l], ldc);
-    hipLaunchKernelGGL(k_chain_parent_tables, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (const int32_t *)owner[l],
+    SGNN_LAUNCH(k_chain_parent_tables, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (const int32_t *)owner[l],
                        (const int32_t *)rank_at[l], (const int32_t *)slot_of[l], (int32_t *)parent[l], (int32_t *)cvals[l],
                        (const int64_t *)(counts_dev + l), ccap_l, (int32_t *)children[l], ldc, (int32_t *)ptable[l], ldf);
     fine = (const int4 *)coarse_coords[l];
@@ -1275,13 +1275,13 @@ SGNN_EXPORT int sgnn_down2_tables(const int32_t *fine_coords, const int32_t *par
   if (nc > 0) {
     SGNN_CHECK_ARG(children);
     if (nc_dev)
-      hipLaunchKernelGGL(k_fill_rows_dyn, dim3(sgnn_grid_for(8 * nc, 256, 4096)), dim3(256), 0, s, children, 8, ldc, nc, nc_dev);
+      SGNN_LAUNCH(k_fill_rows_dyn, dim3(sgnn_grid_for(8 * nc, 256, 4096)), dim3(256), 0, s, children, 8, ldc, nc, nc_dev);
     else
       if (sgnn_fill32(children, 0xFFFFFFFFu, 8 * ldc, s) != SGNN_OK) return SGNN_EHIP;
   }
   if (nf == 0) return SGNN_OK;
   SGNN_CHECK_ARG(fine_coords && parent && ptable && children);
-  hipLaunchKernelGGL(k_down2_tables, dim3(sgnn_grid_for(ldf, 256, 8192)), dim3(256), 0, s,
+  SGNN_LAUNCH(k_down2_tables, dim3(sgnn_grid_for(ldf, 256, 8192)), dim3(256), 0, s,
                      (const int4 *)fine_coords, parent, nf, children, ldc, ptable, ldf, nc, nf_dev, nc_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -1307,7 +1307,7 @@ SGNN_EXPORT int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *o
   SGNN_CHECK_ARG(n >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && out);
-  hipLaunchKernelGGL(k_expand8, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_expand8, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const int4 *)coords, n, (int4 *)out, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -1334,7 +1334,7 @@ SGNN_EXPORT int sgnn_dense_coords(int batch, int d0, int d1, int d2, int32_t *ou
   const int64_t total = (int64_t)batch * d0 * d1 * d2;
   if (total == 0) return SGNN_OK;
   SGNN_CHECK_ARG(out);
-  hipLaunchKernelGGL(k_dense_coords, dim3(sgnn_grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_dense_coords, dim3(sgnn_grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      batch, d0, d1, d2, (int4 *)out);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -177,7 +177,7 @@ SGNN_EXPORT int sgnn_io_flag_entries(const uint32_t *locs_xyz, const float *vals
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs_xyz && vals && voxelsize && seg && mask);
   const uint32_t mz = max_z > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)max_z;
-  hipLaunchKernelGGL(k_io_flag, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz, vals,
+  SGNN_LAUNCH(k_io_flag, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz, vals,
                      voxelsize, seg, nb, n, truncation, mz, mask);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -189,7 +189,7 @@ SGNN_EXPORT int sgnn_io_emit_entries(const uint32_t *locs_xyz, const float *vals
   SGNN_CHECK_ARG(n_max >= 0 && nb >= 1);
   if (n_max == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs_xyz && vals && voxelsize && seg && sel && count && out_locs && out_feats);
-  hipLaunchKernelGGL(k_io_emit, dim3(sgnn_grid_for(n_max, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz,
+  SGNN_LAUNCH(k_io_emit, dim3(sgnn_grid_for(n_max, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz,
                      vals, voxelsize, seg, nb, sel, count, out_locs, out_feats);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -202,7 +202,7 @@ SGNN_EXPORT int sgnn_io_scatter_dense(const uint32_t *locs_xyz, const float *val
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(locs_xyz && vals && voxelsize && seg && dense);
   const uint32_t mz = max_z > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)max_z;
-  hipLaunchKernelGGL(k_io_scatter, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz, vals,
+  SGNN_LAUNCH(k_io_scatter, dim3(sgnn_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, locs_xyz, vals,
                      voxelsize, seg, nb, n, d0, d1, d2, mz, dense);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -167,7 +167,7 @@ int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const 
   bool done = false;
 #define X(CI, CO)                                                                                   \
   if (!done && cin == CI && cout == CO) {                                                           \
-    hipLaunchKernelGGL((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, p, y, n_dev);     \
+    SGNN_LAUNCH((k_linear_fwd<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, p, y, n_dev);     \
     done = true;                                                                                    \
   }
   LIN_CASES(X)
@@ -221,7 +221,7 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
   bool done = false;
 #define X(CI, CO)                                                                                          \
   if (!done && cin == CI && cout == CO) {                                                                  \
-    hipLaunchKernelGGL((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws, n_dev); \
+    SGNN_LAUNCH((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws, n_dev); \
     done = true;                                                                                           \
   }
   LIN_CASES(X)
@@ -230,7 +230,7 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
     sgnn_set_error("sgnn_linear_bwd: unsupported head shape %d -> %d", cin, cout);
     return SGNN_EINVAL;
   }
-  hipLaunchKernelGGL(k_linear_finalize, dim3(nv), dim3(256), 0, s, (const double *)ws, nblk, nv, cin * cout, cin, g);
+  SGNN_LAUNCH(k_linear_finalize, dim3(nv), dim3(256), 0, s, (const double *)ws, nblk, nv, cin * cout, cin, g);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

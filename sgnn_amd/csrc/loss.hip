@@ -167,8 +167,8 @@ SGNN_EXPORT int sgnn_loss_level_fwd(const int64_t *locs, const float *vals, int 
   }
   hipStream_t s = (hipStream_t)stream;
   const int nblk = loss_blocks(m);
-  hipLaunchKernelGGL(k_loss_partial, dim3(nblk), dim3(256), 0, s, a, (double *)ws);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, sums, out2, m_dev);
+  SGNN_LAUNCH(k_loss_partial, dim3(nblk), dim3(256), 0, s, a, (double *)ws);
+  SGNN_LAUNCH(k_loss_finalize, dim3(1), dim3(256), 0, s, (const double *)ws, nblk, sums, out2, m_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -183,7 +183,7 @@ SGNN_EXPORT int sgnn_loss_level_bwd(const int64_t *locs, const float *vals, int 
                            use_log, mask_mode, m_dev) == 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(sums && gout2 && dvals);
-  hipLaunchKernelGGL(k_loss_bwd, dim3(sgnn_grid_for(m, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, sums, gout2,
+  SGNN_LAUNCH(k_loss_bwd, dim3(sgnn_grid_for(m, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, sums, gout2,
                      dvals);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -325,8 +325,8 @@ SGNN_EXPORT int sgnn_loss_levels_fwd(const int64_t *levels, int n, const float *
   int gx = 1;
   for (int l = 0; l < n; ++l) gx = m.nblk[l] > gx ? m.nblk[l] : gx;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_loss_partial_multi, dim3(gx, n), dim3(256), 0, s, m, (double *)ws);
-  hipLaunchKernelGGL(k_loss_finalize_multi, dim3(1), dim3(256), 0, s, (const double *)ws, m, sums, out2s, total, cur);
+  SGNN_LAUNCH(k_loss_partial_multi, dim3(gx, n), dim3(256), 0, s, m, (double *)ws);
+  SGNN_LAUNCH(k_loss_finalize_multi, dim3(1), dim3(256), 0, s, (const double *)ws, m, sums, out2s, total, cur);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -344,7 +344,7 @@ SGNN_EXPORT int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *
     o.dvals[l] = (float *)dvals[l];
     mmax = m.a[l].m > mmax ? m.a[l].m : mmax;
   }
-  hipLaunchKernelGGL(k_loss_bwd_multi, dim3(sgnn_grid_for(mmax, 256, 2048), n), dim3(256), 0, (hipStream_t)stream, m, sums, g, o);
+  SGNN_LAUNCH(k_loss_bwd_multi, dim3(sgnn_grid_for(mmax, 256, 2048), n), dim3(256), 0, (hipStream_t)stream, m, sums, g, o);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -469,10 +469,10 @@ SGNN_EXPORT int sgnn_loss_targets(const float *sdf, const uint8_t *known, const 
   if (total == 0) return SGNN_OK;
   SGNN_CHECK_ARG(sdf && tsdf && hier_last && occ_last && (!masking || known) && (!w_last || n_locs == 0 || input_locs));
   SGNN_CHECK_ARG(ncoarse == 0 || (hier_in && occ && hier && (!w_last || w)));
-  hipLaunchKernelGGL(k_targets_fine, dim3(sgnn_grid_for(total, 256, 4096)), dim3(256), 0, s, sdf, known, total, trunc,
+  SGNN_LAUNCH(k_targets_fine, dim3(sgnn_grid_for(total, 256, 4096)), dim3(256), 0, s, sdf, known, total, trunc,
                      masking, weight_missing_geo, tsdf, hier_last, occ_last, w_last);
   if (w_last && n_locs > 0)
-    hipLaunchKernelGGL(k_targets_sites, dim3(sgnn_grid_for(n_locs, 256, 4096)), dim3(256), 0, s, input_locs, n_locs,
+    SGNN_LAUNCH(k_targets_sites, dim3(sgnn_grid_for(n_locs, 256, 4096)), dim3(256), 0, s, input_locs, n_locs,
                        batch, d0, d1, d2, w_last, n_locs_dev);
   if (ncoarse > 0) {
     CoarseArgs a{};
@@ -487,7 +487,7 @@ SGNN_EXPORT int sgnn_loss_targets(const float *sdf, const uint8_t *known, const 
     }
     a.batch = batch; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.trunc = trunc; a.nlev = ncoarse;
     const int64_t bricks = (int64_t)batch * ((d0 / 2 + 3) / 4) * ((d1 / 2 + 3) / 4) * ((d2 / 2 + 3) / 4);
-    hipLaunchKernelGGL(k_targets_coarse, dim3(sgnn_grid_for(bricks, 4, 8192)), dim3(256), 0, s, a);
+    SGNN_LAUNCH(k_targets_coarse, dim3(sgnn_grid_for(bricks, 4, 8192)), dim3(256), 0, s, a);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -522,7 +522,7 @@ SGNN_EXPORT int sgnn_loss_combine(const float *out2s, const float *coef_host, in
   SGNN_CHECK_ARG(out2s && coef_host && total && cur && n >= 1 && n <= 10);
   Coef10 c{};
   for (int i = 0; i < n; ++i) c.c[i] = coef_host[i];
-  hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, out2s, c, n, total, cur);
+  SGNN_LAUNCH(k_loss_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, out2s, c, n, total, cur);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -531,7 +531,7 @@ SGNN_EXPORT int sgnn_loss_combine_bwd(const float *g, const float *coef_host, in
   SGNN_CHECK_ARG(g && coef_host && g2 && n >= 1 && n <= 10);
   Coef10 c{};
   for (int i = 0; i < n; ++i) c.c[i] = coef_host[i];
-  hipLaunchKernelGGL(k_loss_combine_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g, c, n, g2);
+  SGNN_LAUNCH(k_loss_combine_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g, c, n, g2);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -294,8 +294,8 @@ SGNN_EXPORT int sgnn_mc_count(const float *tsdf, int d0, int d1, int d2, float i
   const McGeom g{d0, d1, d2, isovalue, truncation, thresh};
   const McWs w = mc_ws(ws, vol);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_mc_count, dim3((unsigned)nblk), dim3(MC_BLOCK), 0, s, tsdf, g, vol, w.cnt, w.blocksum);
-  hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, s, (const int32_t *)w.blocksum, nblk, w.blockoff, ntri);
+  SGNN_LAUNCH(k_mc_count, dim3((unsigned)nblk), dim3(MC_BLOCK), 0, s, tsdf, g, vol, w.cnt, w.blocksum);
+  SGNN_LAUNCH(k_mc_scan, dim3(1), dim3(1024), 0, s, (const int32_t *)w.blocksum, nblk, w.blockoff, ntri);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -311,7 +311,7 @@ SGNN_EXPORT int sgnn_mc_emit(const float *tsdf, const uint8_t *colors, int d0, i
   const int64_t vol = (int64_t)d0 * d1 * d2, nblk = mc_blocks(vol);
   const McGeom g{d0, d1, d2, isovalue, truncation, thresh};
   const McWs w = mc_ws(ws, vol);
-  hipLaunchKernelGGL(k_mc_emit, dim3((unsigned)nblk), dim3(MC_BLOCK), 0, (hipStream_t)stream, tsdf, colors, g, vol,
+  SGNN_LAUNCH(k_mc_emit, dim3((unsigned)nblk), dim3(MC_BLOCK), 0, (hipStream_t)stream, tsdf, colors, g, vol,
                      (const uint8_t *)w.cnt, (const int64_t *)w.blockoff, verts, vcols);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -449,8 +449,8 @@ SGNN_EXPORT int sgnn_weld_build(const float *verts, int64_t nv, float thresh, in
   if (nv == 0) return SGNN_OK;
   SGNN_CHECK_ARG(verts && cells);
   const dim3 grid((unsigned)((nv + 255) / 256));
-  hipLaunchKernelGGL(k_weld_cells, grid, dim3(256), 0, s, verts, nv, thresh, (Cell *)cells);
-  hipLaunchKernelGGL(k_weld_insert, grid, dim3(256), 0, s, (const Cell *)cells, nv, rep, first, cap);
+  SGNN_LAUNCH(k_weld_cells, grid, dim3(256), 0, s, verts, nv, thresh, (Cell *)cells);
+  SGNN_LAUNCH(k_weld_insert, grid, dim3(256), 0, s, (const Cell *)cells, nv, rep, first, cap);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -460,7 +460,7 @@ SGNN_EXPORT int sgnn_weld_sweep(const int32_t *cells, const int32_t *rep, const 
   SGNN_CHECK_ARG(cells && rep && first && state && undecided && cap >= 1);
   hipStream_t s = (hipStream_t)stream;
   SGNN_HIP_TRY(hipMemsetAsync(undecided, 0, sizeof(int64_t), s));
-  hipLaunchKernelGGL(k_weld_sweep, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, (const Cell *)cells, rep, first,
+  SGNN_LAUNCH(k_weld_sweep, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, (const Cell *)cells, rep, first,
                      state, cap, (unsigned long long *)undecided);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -472,7 +472,7 @@ SGNN_EXPORT int sgnn_weld_lookup(const int32_t *cells, int64_t nv, const int32_t
   SGNN_CHECK_ARG(nv >= 0 && cap >= 1);
   if (nv == 0) return SGNN_OK;
   SGNN_CHECK_ARG(cells && rep && first && state && creator_of && is_creator);
-  hipLaunchKernelGGL(k_weld_lookup, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_weld_lookup, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const Cell *)cells, nv, rep, first, state, cap, creator_of, is_creator);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -552,7 +552,7 @@ SGNN_EXPORT int sgnn_weld_number(const int32_t *sel, int64_t n, int32_t *newid, 
   SGNN_CHECK_ARG(n >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(sel && newid);
-  hipLaunchKernelGGL(k_weld_number, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sel, n, newid);
+  SGNN_LAUNCH(k_weld_number, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sel, n, newid);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -566,10 +566,10 @@ SGNN_EXPORT int sgnn_mesh_faces(const int32_t *creator_of, const int32_t *newid,
   if (ntri == 0) return SGNN_OK;
   SGNN_CHECK_ARG(creator_of && newid && faces && keep);
   const dim3 grid((unsigned)((ntri + 255) / 256));
-  hipLaunchKernelGGL(k_faces_remap, dim3((unsigned)((3 * ntri + 255) / 256)), dim3(256), 0, s, creator_of, newid, ntri,
+  SGNN_LAUNCH(k_faces_remap, dim3((unsigned)((3 * ntri + 255) / 256)), dim3(256), 0, s, creator_of, newid, ntri,
                      faces);
-  hipLaunchKernelGGL(k_faces_insert, grid, dim3(256), 0, s, (const int32_t *)faces, ntri, frep, ffirst, cap);
-  hipLaunchKernelGGL(k_faces_keep, grid, dim3(256), 0, s, (const int32_t *)faces, ntri, (const int32_t *)frep,
+  SGNN_LAUNCH(k_faces_insert, grid, dim3(256), 0, s, (const int32_t *)faces, ntri, frep, ffirst, cap);
+  SGNN_LAUNCH(k_faces_keep, grid, dim3(256), 0, s, (const int32_t *)faces, ntri, (const int32_t *)frep,
                      (const int32_t *)ffirst, cap, keep);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -591,10 +591,10 @@ SGNN_EXPORT int sgnn_take_rows3(const void *src, int elem_bytes, const int32_t *
   SGNN_CHECK_ARG(src && sel && dst);
   const dim3 grid((unsigned)((3 * n + 255) / 256));
   if (elem_bytes == 4)
-    hipLaunchKernelGGL((k_take3<uint32_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)src, sel, n,
+    SGNN_LAUNCH((k_take3<uint32_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)src, sel, n,
                        (uint32_t *)dst);
   else
-    hipLaunchKernelGGL((k_take3<uint8_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, sel, n,
+    SGNN_LAUNCH((k_take3<uint8_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, sel, n,
                        (uint8_t *)dst);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

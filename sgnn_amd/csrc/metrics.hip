@@ -111,14 +111,14 @@ SGNN_EXPORT int sgnn_iou_counts(const int64_t *locs, const uint8_t *keep, const 
   const dim3 dgrid(sgnn_grid_for(vol, 256 * 8, 256), nb);
   if (tgt_is_u8) {
     if (m > 0)
-      hipLaunchKernelGGL((k_iou_sparse<uint8_t>), dim3(sgnn_grid_for(m, 256, 1024)), dim3(256), 0, s, locs, keep, logits,
+      SGNN_LAUNCH((k_iou_sparse<uint8_t>), dim3(sgnn_grid_for(m, 256, 1024)), dim3(256), 0, s, locs, keep, logits,
                          lstride, m, (const uint8_t *)tgt, g, use_mask, c);
-    hipLaunchKernelGGL((k_iou_dense<uint8_t>), dgrid, dim3(256), 0, s, (const uint8_t *)tgt, vol, c);
+    SGNN_LAUNCH((k_iou_dense<uint8_t>), dgrid, dim3(256), 0, s, (const uint8_t *)tgt, vol, c);
   } else {
     if (m > 0)
-      hipLaunchKernelGGL((k_iou_sparse<float>), dim3(sgnn_grid_for(m, 256, 1024)), dim3(256), 0, s, locs, keep, logits,
+      SGNN_LAUNCH((k_iou_sparse<float>), dim3(sgnn_grid_for(m, 256, 1024)), dim3(256), 0, s, locs, keep, logits,
                          lstride, m, (const float *)tgt, g, use_mask, c);
-    hipLaunchKernelGGL((k_iou_dense<float>), dgrid, dim3(256), 0, s, (const float *)tgt, vol, c);
+    SGNN_LAUNCH((k_iou_dense<float>), dgrid, dim3(256), 0, s, (const float *)tgt, vol, c);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -217,9 +217,9 @@ SGNN_EXPORT int sgnn_l1_tgtsurf(const int64_t *locs, const float *vals, int64_t 
   const int64_t total = (int64_t)nb * d0 * d1 * d2;
   const int nd = sgnn_grid_for(total, 256 * 8, MET_MAX_BLOCKS);
   const int ns = m > 0 ? sgnn_grid_for(m, 256 * 4, MET_MAX_BLOCKS) : 0;
-  hipLaunchKernelGGL(k_l1_tgtsurf_partial, dim3(nd + ns), dim3(256), 0, s, locs, vals, m, tgt_sdf, known, g, truncation,
+  SGNN_LAUNCH(k_l1_tgtsurf_partial, dim3(nd + ns), dim3(256), 0, s, locs, vals, m, tgt_sdf, known, g, truncation,
                      thresh, nd, (double *)ws);
-  hipLaunchKernelGGL(k_l1_tgtsurf_final, dim3(1), dim3(256), 0, s, (const double *)ws, nd + ns, out3);
+  SGNN_LAUNCH(k_l1_tgtsurf_final, dim3(1), dim3(256), 0, s, (const double *)ws, nd + ns, out3);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

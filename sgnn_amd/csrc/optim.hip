@@ -96,9 +96,9 @@ SGNN_EXPORT int sgnn_adam_flat(float *params, const float *grads, float *exp_avg
     SGNN_CHECK_ARG(a.seg[t].begin >= 0 && a.seg[t].end >= a.seg[t].begin && a.seg[t].end <= n && a.seg[t].step);
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam_flat, dim3(sgnn_grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, s, params, grads, exp_avg,
+  SGNN_LAUNCH(k_adam_flat, dim3(sgnn_grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, s, params, grads, exp_avg,
                      exp_avg_sq, n, a, lr_dev, beta1, beta2, eps, weight_decay, grad_scale, status);
-  hipLaunchKernelGGL(k_adam_steps, dim3(1), dim3(64), 0, s, a, status);
+  SGNN_LAUNCH(k_adam_steps, dim3(1), dim3(64), 0, s, a, status);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -108,16 +108,32 @@ SGNN_EXPORT int sgnn_adam_flat(float *params, const float *grads, float *exp_avg
 struct SegCnt {
   const int64_t *cnt[ADAM_MAX_SEG];
 };
-__global__ void k_seg_flags(SegCnt c, int nseg, float *__restrict__ flags) {
+__global__ void k_seg_flags(SegCnt c, int nseg, float *__restrict__ flags, const int32_t *__restrict__ status) {
   const int t = threadIdx.x;
   if (t < nseg) flags[t] = (!c.cnt[t] || *c.cnt[t] > 0) ? 1.f : 0.f;
+  if (t == ADAM_MAX_SEG - 1 && status) flags[ADAM_MAX_SEG - 1] = (*status & SGNN_STATUS_OVERFLOW) ? 1.f : 0.f;
 }
 
-SGNN_EXPORT int sgnn_seg_flags(const int64_t *cnt_ptrs, int nseg, float *flags, sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(cnt_ptrs && flags && nseg >= 1 && nseg <= ADAM_MAX_SEG);
+// status (may be NULL): flags[7] = 1 if this rank's step overflowed a capacity (nseg <= 7 then)
+SGNN_EXPORT int sgnn_seg_flags(const int64_t *cnt_ptrs, int nseg, float *flags, const int32_t *status,
+                               sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(cnt_ptrs && flags && nseg >= 1 && nseg <= ADAM_MAX_SEG && (!status || nseg < ADAM_MAX_SEG));
   SegCnt c{};
   for (int t = 0; t < nseg; ++t) c.cnt[t] = (const int64_t *)(uintptr_t)cnt_ptrs[t];
-  hipLaunchKernelGGL(k_seg_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, c, nseg, flags);
+  SGNN_LAUNCH(k_seg_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, c, nseg, flags, status);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// after the all-reduce of the flags: an overflow on ANY rank becomes this rank's overflow, so that every replica skips
+// the same optimizer step and re-runs the same batch (data-parallel replicas must take identical decisions)
+__global__ void k_status_merge(const float *__restrict__ flag, int32_t *__restrict__ status) {
+  if (threadIdx.x == 0 && *flag > 0.f) atomicOr(status, SGNN_STATUS_OVERFLOW);
+}
+
+SGNN_EXPORT int sgnn_status_merge(const float *overflow_flag, int32_t *status, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(overflow_flag && status);
+  SGNN_LAUNCH(k_status_merge, dim3(1), dim3(64), 0, (hipStream_t)stream, overflow_flag, status);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

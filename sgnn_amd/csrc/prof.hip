@@ -70,3 +70,8 @@ SGNN_EXPORT int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *c
   SGNN_HIP_TRY(hipEventElapsedTime(ms, r.e0, r.e1));
   return SGNN_OK;
 }
+
+
+// number of kernel launches this library has issued in this process (all streams; see SGNN_LAUNCH in common.h)
+long long sgnn_launch_counter = 0;
+SGNN_EXPORT int64_t sgnn_launch_count(void) { return (int64_t)sgnn_launch_counter; }

@@ -32,9 +32,9 @@ __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
   do {                                                                                                 \
     const int grid_ = sgnn_grid_for((total_groups), 256, 4096);                                        \
     if (row_vec(c) == 4)                                                                               \
-      hipLaunchKernelGGL((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+      SGNN_LAUNCH((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
     else                                                                                               \
-      hipLaunchKernelGGL((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+      SGNN_LAUNCH((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -72,7 +72,7 @@ int sgnn_fill32_multi(void *const *p, const int64_t *words, int nregions, uint32
     ++n;
   }
   if (n == 0) return SGNN_OK;
-  hipLaunchKernelGGL(k_fill32_multi, dim3(sgnn_grid_for(r.start[n], 256, 4096)), dim3(256), 0, s, r, n, pattern);
+  SGNN_LAUNCH(k_fill32_multi, dim3(sgnn_grid_for(r.start[n], 256, 4096)), dim3(256), 0, s, r, n, pattern);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, 
 int sgnn_copy_words(void *dst, const void *src, int64_t words, hipStream_t s) {
   if (words <= 0 || dst == src) return SGNN_OK;
   const int vec = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
-  hipLaunchKernelGGL(k_copy_words, dim3(sgnn_grid_for(vec ? words / 4 + 1 : words, 256, 4096)), dim3(256), 0, s,
+  SGNN_LAUNCH(k_copy_words, dim3(sgnn_grid_for(vec ? words / 4 + 1 : words, 256, 4096)), dim3(256), 0, s,
                      (uint32_t *)dst, (const uint32_t *)src, words, vec);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -196,9 +196,9 @@ static inline bool ld_vec4(int c, std::initializer_list<int64_t> lds, std::initi
   do {                                                                                                 \
     const int grid_ = sgnn_grid_for((total_groups), 256, 4096);                                        \
     if (vec4)                                                                                          \
-      hipLaunchKernelGGL((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+      SGNN_LAUNCH((KERNEL<4>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
     else                                                                                               \
-      hipLaunchKernelGGL((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
+      SGNN_LAUNCH((KERNEL<1>), dim3(grid_), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__);  \
   } while (0)
 
 int sgnn_gather_rows_ld(const float *src, int64_t ld_src, int c, const int32_t *idx, int64_t m, float *dst,
@@ -411,7 +411,7 @@ int sgnn_concat_rows_dn(const float *a, int ca, const int32_t *ia, const float *
   SGNN_CHECK_ARG(ca >= 0 && cb >= 0 && ca + cb >= 1 && m >= 0);
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b));
-  hipLaunchKernelGGL(k_concat_rows, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0,
+  SGNN_LAUNCH(k_concat_rows, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0,
                      (hipStream_t)stream, a, ca, ia, b, cb, ib, m, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -460,7 +460,7 @@ int sgnn_concat_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int cb
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG(ia || !da || na >= m);
   SGNN_CHECK_ARG(ib || !db || nb >= m);
-  hipLaunchKernelGGL(k_concat_rows_bwd, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0, s, ddst, ca,
+  SGNN_LAUNCH(k_concat_rows_bwd, dim3(sgnn_grid_for(m * (ca + cb), 256, 4096)), dim3(256), 0, s, ddst, ca,
                      ia, cb, ib, m, da, db, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -523,7 +523,7 @@ int sgnn_concat3_rows_dn(const float *a, int ca, const int32_t *ia, const float 
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b) && (cc == 0 || c));
   const Cat3 s{{a, b, c}, {ia, ib, ic}, {ca, cb, cc}};
-  hipLaunchKernelGGL(k_concat3, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_concat3, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                      s, m, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -551,7 +551,7 @@ int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int c
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG((ia || !da || na >= m) && (ib || !db || nb >= m) && (ic || !dc || nc >= m));
   const Cat3Out o{{da, db, dc}, {ia, ib, ic}, {ca, cb, cc}};
-  hipLaunchKernelGGL(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o, n_dev);
+  SGNN_LAUNCH(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -573,7 +573,7 @@ SGNN_EXPORT int sgnn_add(const float *a, const float *b, int64_t count, float *y
   SGNN_CHECK_ARG(count >= 0);
   if (count == 0) return SGNN_OK;
   SGNN_CHECK_ARG(a && b && y);
-  hipLaunchKernelGGL(k_add, dim3(sgnn_grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b,
+  SGNN_LAUNCH(k_add, dim3(sgnn_grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b,
                      count, y);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -609,7 +609,7 @@ SGNN_EXPORT int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, 
   }
   if (n == 0 || total == 0) return SGNN_OK;
   SGNN_CHECK_ARG(feats && coords);
-  hipLaunchKernelGGL(k_sparse_to_dense, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, s, feats,
+  SGNN_LAUNCH(k_sparse_to_dense, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, s, feats,
                      (const int4 *)coords, n, c, dense, batch, d0, d1, d2);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -638,7 +638,7 @@ SGNN_EXPORT int sgnn_dense_to_sparse(const float *dense, const int32_t *coords, 
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dense && coords && feats);
-  hipLaunchKernelGGL(k_dense_to_sparse, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+  SGNN_LAUNCH(k_dense_to_sparse, dim3(sgnn_grid_for(n * c, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                      dense, (const int4 *)coords, n, c, feats, batch, d0, d1, d2);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -441,7 +441,7 @@ class FlatAdam(object):
             segments = [('all', list(segments))]
         self.segments = [(name, [p for p in ps if p.requires_grad]) for name, ps in segments]
         self.params = [p for _, ps in self.segments for p in ps]
-        assert self.params and len(self.segments) <= 8
+        assert self.params and len(self.segments) <= 7      # flag slot 7 of the gradient tail carries the overflow bit
         dev, dt = self.params[0].device, torch.float32
         self.numel = sum(p.numel() for p in self.params)
         nseg = len(self.segments)
@@ -545,11 +545,18 @@ class FlatAdam(object):
                   self.betas[0], self.betas[1], self.eps, self.weight_decay, float(grad_scale),
                   None if status is None else status.data_ptr())
 
-    def write_flags(self, cnts):
-        """flags tail of flat_g from the device row counts (before a data-parallel all-reduce of flat_g)."""
+    def write_flags(self, cnts, status=None):
+        """flags tail of flat_g from the device row counts (before a data-parallel all-reduce of flat_g); with `status`
+        (device int32 status word) slot 7 carries this rank's capacity-overflow bit."""
         from . import _lib
         ptrs = np.ascontiguousarray(np.array([0 if c is None else c.data_ptr() for c in cnts], dtype=np.int64))
-        _lib.call('sgnn_seg_flags', ptrs.ctypes.data, len(self.segments), self.flags.data_ptr())
+        _lib.call('sgnn_seg_flags', ptrs.ctypes.data, len(self.segments), self.flags.data_ptr(),
+                  None if status is None else status.data_ptr())
+
+    def merge_overflow(self, status):
+        """After the all-reduce: an overflow on any rank (summed flag in slot 7) becomes every rank's overflow."""
+        from . import _lib
+        _lib.call('sgnn_status_merge', self.flat_g.data_ptr() + 4 * (self.numel + 7), status.data_ptr())
 
     # -- torch.optim.Adam checkpoint format ------------------------------------------------------------------
     def state_dict(self):
@@ -615,7 +622,6 @@ class GraphStep(object):
         self.args = (num_hierarchy_levels, truncation, use_log_transform, weight_missing_geo, use_loss_masking)
         self.teacher_forced, self.headroom, self.use_graph = teacher_forced, float(headroom), bool(use_graph)
         self.settle = bool(settle)      # False: capture right after the warm-up step (row counts known to be stable)
-        self.count_nodes = os.environ.get('SGNN_GRAPH_COUNT_NODES', '0') == '1'   # stats['kernel_nodes'] via a debug dump
         self.grad_sync, self.world_size = grad_sync, int(world_size)
         self.capacity = None
         self.key = None                 # (which stages run, batch shape) the capacities / static buffers belong to
@@ -653,6 +659,7 @@ class GraphStep(object):
             loss.backward()
             reached = self.opt.collect()
             if self.grad_sync is not None:
+                self.opt.flat_g[self.opt.numel:].zero_()          # flag slots (slot 7: overflow, none on the classic path)
                 self.opt.flags.copy_(torch.tensor([1.0 if r else 0.0 for r in reached], dtype=torch.float32))
                 self.grad_sync(self.opt.flat_g)
                 self.opt.step(flags_in_grads=True, grad_scale=1.0 / self.world_size)
@@ -758,8 +765,9 @@ class GraphStep(object):
             cnts = self._seg_cnts(loss_weights)
             active = self._active_segments(loss_weights)
             zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
-            self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)])
+            self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)], rt.status32)
             self.grad_sync(self.opt.flat_g)
+            self.opt.merge_overflow(rt.status32)
         self._opt_step(loss_weights, rt)
         return loss, losses, rt
 
@@ -797,14 +805,10 @@ class GraphStep(object):
         torch.cuda.synchronize(dev)
         if self.grad_sync is None:
             g = torch.cuda.CUDAGraph()
-            if self.count_nodes:
-                g.enable_debug_mode()
             with torch.cuda.graph(g):
                 loss, losses, _ = self._fwd_bwd(loss_weights)
                 self._opt_step(loss_weights, rt)
             self.graphs = (g,)
-            if self.count_nodes:
-                self.stats['kernel_nodes'] = _count_graph_nodes(g)
         else:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
@@ -812,8 +816,9 @@ class GraphStep(object):
                 cnts = self._seg_cnts(loss_weights)
                 active = self._active_segments(loss_weights)
                 zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
-                self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)])
+                self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)], rt.status32)
             with torch.cuda.graph(g2, pool=g1.pool()):
+                self.opt.merge_overflow(rt.status32)
                 self._opt_step(loss_weights, rt)
             self.graphs = (g1, g2)
         self._graph_out = (loss, losses)
@@ -955,21 +960,6 @@ class GraphStep(object):
         for batch, lw in redo:
             self._probe(batch, lw)
         self.stage = 1
-
-
-def _count_graph_nodes(g):
-    """Kernel nodes of a captured graph, from its DOT dump (hipGraphDebugDotPrint); None when the dump is unavailable."""
-    import re
-    import tempfile
-    try:
-        with tempfile.TemporaryDirectory() as d:
-            path = os.path.join(d, 'graph.dot')
-            g.debug_dump(path)
-            txt = open(path).read()
-        n = len(re.findall(r'label\s*=\s*"[^"]*(?:KERNEL|kernel)', txt))
-        return n or len(re.findall(r'^\s*"?[\w.]+"?\s*\[', txt, flags=re.M)) or None
-    except Exception:
-        return None
 
 
 SLOT_ZERO = 63      # a count slot that is always 0 (Capacity.counts is zero-initialised and nothing writes there)

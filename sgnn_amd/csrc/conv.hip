@@ -1152,7 +1152,10 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       for (int m = 0; m < 4; ++m) {
         const int64_t row = base + m * 16 + i16;
         const uint32_t off =
-            (row < blk_row1) ? (uint32_t)((row * groups + grp) * ld_dy + q * W) * 4u : 0xFFFFFFFFu;
+            (row < blk_row1) ? (uint32_t)((row * groups + grp) * ld_dy + q * W) * 4u : 0xFFFFF800u;
+        // (not 0xFFFFFFFF: buf_load_floats issues its tail loads at off + 16, +32: a 32-bit wrap would land them INSIDE the
+        //  buffer at a misaligned address — garbage that is multiplied by the zero x row of a missing rule, i.e. harmless
+        //  unless it happens to be NaN / Inf; slabs are limited to 0xFFFFF000 bytes, so this offset is out of range)
         buf_load_floats<W>(rs_dy, off, g[m]);
         if constexpr (COUTP != COUT) {
 #pragma unroll

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: run the CPU leg alone, print its JSON')
     ap.add_argument('--cpu-torch-only', action='store_true',
                     help='CPU leg: torch-op oracle only (default: its C/OpenMP kernels for convolutions + rulebooks when built)')
-    ap.add_argument('--cpu-blocks', type=int, default=2, help='blocks in the CPU-baseline sample')
+    ap.add_argument('--cpu-blocks', type=int, default=8, help='blocks in the CPU-baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='internal: thread count of a CPU-baseline child process')
     ap.add_argument('--teacher-forced', action='store_true',
                     help='generative masks from the target hierarchy instead of the predicted occupancy (per-level row counts '
@@ -210,16 +210,18 @@ def cpu_baseline(args):
         opt.step()
         return time.time() - t0
 
-    for _ in range(2):
+    n_warm, n_timed = (1, 3) if nthreads == 1 else (2, 5)        # the single-thread leg is ~10 s per step
+    for _ in range(n_warm):
         step()
-    times = sorted(step() for _ in range(5))
-    med = times[2]
-    how = ('convolutions + 3x3x3 rulebooks in C/OpenMP (oracle/csrc/scn_cpu.c, %d threads), BatchNorm / stride-2 rulebooks / '
-           'glue / loss torch-CPU (%d threads)' % (_fast.threads(), nthreads)) if scn_oracle.FAST else \
+    times = sorted(step() for _ in range(n_timed))
+    med = times[len(times) // 2]
+    how = ('convolutions (neighbour-table form, ONE OpenMP region per convolution over the output rows, pair / table '
+           'lists cached per grid) + 3x3x3 rulebooks in C/OpenMP (oracle/csrc/scn_cpu.c, %d threads), BatchNorm / stride-2 '
+           'rulebooks / glue / loss torch-CPU (%d threads)' % (_fast.threads(), nthreads)) if scn_oracle.FAST else \
         'torch-CPU ops only (%d threads)' % nthreads
     return {'value': nb / med, 'unit': 'blocks/s', 'cores': nthreads, 'kind': 'port', 's_per_step': round(med, 3),
             'sample': '%d synthetic %d^3 blocks (cfg 2 seeds), full GenModel targets+fwd+loss+bwd+Adam on the CPU oracle [%s], '
-                      'median of 5 timed steps after 2 warm-up steps' % (nb, args.dim, how)}
+                      'median of %d timed steps after %d warm-up steps' % (nb, args.dim, how, n_timed, n_warm)}
 
 
 def cpu_baseline_subprocess(args):

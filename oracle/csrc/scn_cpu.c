@@ -103,4 +103,86 @@ void scn_subm_rules(const int64_t *coords, int64_t n, const int64_t *sorted_keys
   }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Table form of the same convolution: tab[k*n_out + j] = input row feeding output row j through offset k (-1 = no rule)
+ * — the rulebook as an offset-major neighbour table.  One parallel region per convolution (rows are independent), no
+ * barrier between offsets; every output element is accumulated over (k, c) in the same order as the per-offset form
+ * above, so the results are identical to it.  What bench.py's cpu_baseline leg times (27 fork/joins per
+ * convolution made 128 threads slower than one).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* y[j] = sum_k x[tab[k][j]] @ w[k]      (transpose_w: w[k] is (cout_layer = cin here ... ) see scn_conv_tab_t) */
+void scn_conv_tab(const float *x, int cin, const float *w, int cout, int K, const int64_t *tab, int64_t n_out, float *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n_out; ++j) {
+    float *yr = y + j * cout;
+    for (int k = 0; k < K; ++k) {
+      const int64_t i = tab[(int64_t)k * n_out + j];
+      if (i < 0) continue;
+      const float *xr = x + i * cin;
+      const float *wk = w + (int64_t)k * cin * cout;
+      for (int c = 0; c < cin; ++c) {
+        const float xv = xr[c];
+        const float *wr = wk + (int64_t)c * cout;
+        for (int n = 0; n < cout; ++n) yr[n] += xv * wr[n];
+      }
+    }
+  }
+}
+
+/* dx[i] = sum_k dy[tab[k][i]] @ w[kmap(k)]^T, w (K, cin, cout); flip: kmap(k) = K-1-k (3x3x3: the mirrored table) */
+void scn_conv_tab_t(const float *dy, int cout, const float *w, int cin, int K, const int64_t *tab, int64_t n_in, int flip,
+                    float *dx) {
+  float *wt = (float *)malloc((size_t)K * cin * cout * sizeof(float));
+  if (!wt) return;
+  for (int k = 0; k < K; ++k)
+    for (int c = 0; c < cin; ++c)
+      for (int n = 0; n < cout; ++n) wt[((size_t)k * cout + n) * cin + c] = w[((size_t)k * cin + c) * cout + n];
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n_in; ++i) {
+    float *xr = dx + i * cin;
+    for (int k = 0; k < K; ++k) {
+      const int64_t j = tab[(int64_t)k * n_in + i];
+      if (j < 0) continue;
+      const float *dr = dy + j * cout;
+      const float *tk = wt + (size_t)(flip ? (K - 1 - k) : k) * cout * cin;
+      for (int n = 0; n < cout; ++n) {
+        const float dv = dr[n];
+        const float *tr = tk + (size_t)n * cin;
+        for (int c = 0; c < cin; ++c) xr[c] += dv * tr[c];
+      }
+    }
+  }
+  free(wt);
+}
+
+/* dw[k] (cin x cout) = sum_j x[tab[k][j]]^T dy[j]: thread-local (K, cin, cout) tiles, reduced in thread order */
+void scn_conv_tab_w(const float *x, int cin, const float *dy, int cout, int K, const int64_t *tab, int64_t n_out, float *dw) {
+  const int nt = omp_get_max_threads();
+  const size_t tile = (size_t)K * cin * cout;
+  float *acc = (float *)calloc((size_t)nt * tile, sizeof(float));
+  if (!acc) return;
+#pragma omp parallel
+  {
+    float *mine = acc + (size_t)omp_get_thread_num() * tile;
+#pragma omp for schedule(static)
+    for (int64_t j = 0; j < n_out; ++j) {
+      const float *dr = dy + j * cout;
+      for (int k = 0; k < K; ++k) {
+        const int64_t i = tab[(int64_t)k * n_out + j];
+        if (i < 0) continue;
+        const float *xr = x + i * cin;
+        float *mk = mine + (size_t)k * cin * cout;
+        for (int c = 0; c < cin; ++c) {
+          const float xv = xr[c];
+          float *mr = mk + (size_t)c * cout;
+          for (int n = 0; n < cout; ++n) mr[n] += xv * dr[n];
+        }
+      }
+    }
+  }
+  for (int t = 0; t < nt; ++t)
+    for (size_t e = 0; e < tile; ++e) dw[e] += acc[(size_t)t * tile + e];
+  free(acc);
+}
+
 int scn_cpu_threads(void) { return omp_get_max_threads(); }

@@ -180,12 +180,15 @@ FAST = False   # True: convolutions and 3x3x3 rulebooks through the C/OpenMP ker
                # cpu_baseline leg of bench.py switches it on; parity tests and fixtures use the torch-op path below
 
 
-def rule_conv(x, weight, nbr_or_pairs, n_out):
+def rule_conv(x, weight, nbr_or_pairs, n_out, tables=None):
     """Per-offset gather -> mm -> index_add (upstream CPU algorithm).
-    nbr_or_pairs: list over offsets of (in_idx, out_idx) LongTensors."""
+    nbr_or_pairs: list over offsets of (in_idx, out_idx) LongTensors.  tables = (tab_f (K, n_out), tab_b (K, n_in),
+    flip_b): the same rules as neighbour tables — only the optional C/OpenMP mode (FAST) uses them."""
     if FAST and x.dtype == torch.float32 and weight.dtype == torch.float32:
         from . import _fast
         if _fast.available:
+            if tables is not None and hasattr(_fast, 'TableConv'):
+                return _fast.TableConv.apply(x, weight, tables[0], tables[1], tables[2], n_out)
             return _fast.RuleConv.apply(x, weight, nbr_or_pairs, n_out)
     out = x.new_zeros(n_out, weight.shape[2])
     for k, (i_idx, o_idx) in enumerate(nbr_or_pairs):
@@ -201,6 +204,17 @@ def pairs_from_nbr(nbr):
         o = np.nonzero(nbr[k] >= 0)[0]
         pairs.append((torch.from_numpy(nbr[k][o].copy()), torch.from_numpy(o.copy())))
     return pairs
+
+
+def down_tables(parent, off, n_coarse):
+    """Stride-2 rules as tables: children (8, n_coarse) = fine row per (offset, coarse row); ptable (8, n_fine) = coarse
+    row of fine row i in row off[i], -1 elsewhere."""
+    n = parent.shape[0]
+    children = np.full((8, n_coarse), -1, dtype=np.int64)
+    children[off, parent] = np.arange(n, dtype=np.int64)
+    ptable = np.full((8, n), -1, dtype=np.int64)
+    ptable[off, np.arange(n)] = parent
+    return children, ptable, False
 
 
 def pairs_from_down(parent, off, transpose=False):
@@ -293,7 +307,10 @@ class SubmanifoldConvolution(nn.Module):
 
     def forward(self, x):
         g = x.metadata.grid(x.spatial_size)
-        out = rule_conv(x.features, self.weight, pairs_from_nbr(g.subm_rules(3)), g.n)
+        nbr = g.subm_rules(3)
+        if getattr(g, '_pairs3', None) is None:       # pair lists of a grid serve every convolution of its level
+            g._pairs3 = pairs_from_nbr(nbr)
+        out = rule_conv(x.features, self.weight, g._pairs3, g.n, tables=(nbr, nbr, True))
         if self.bias is not None:
             out = out + self.bias
         return SparseConvNetTensor(out, x.metadata, x.spatial_size)
@@ -314,7 +331,7 @@ class Convolution(nn.Module):
         out_size = x.spatial_size // 2
         parent, off = x.metadata.down2(x.spatial_size, out_size)
         n_out = x.metadata.grid(out_size).n
-        out = rule_conv(x.features, self.weight, pairs_from_down(parent, off), n_out)
+        out = rule_conv(x.features, self.weight, pairs_from_down(parent, off), n_out, tables=down_tables(parent, off, n_out))
         if self.bias is not None:
             out = out + self.bias
         return SparseConvNetTensor(out, x.metadata, out_size)

@@ -17,6 +17,11 @@ if os.path.exists(_PATH):
         _lib.scn_conv_bwd_x.argtypes = [vp, i32, vp, i32, vp, vp, i64, vp]
         _lib.scn_conv_bwd_w.argtypes = [vp, i32, vp, i32, vp, vp, i64, vp]
         _lib.scn_subm_rules.argtypes = [vp, i64, vp, vp, vp]
+        _lib.scn_conv_tab.argtypes = [vp, i32, vp, i32, i32, vp, i64, vp]
+        _lib.scn_conv_tab_t.argtypes = [vp, i32, vp, i32, i32, vp, i64, i32, vp]
+        _lib.scn_conv_tab_w.argtypes = [vp, i32, vp, i32, i32, vp, i64, vp]
+        for f in (_lib.scn_conv_tab, _lib.scn_conv_tab_t, _lib.scn_conv_tab_w):
+            f.restype = None
         _lib.scn_cpu_threads.restype = i32
         for f in (_lib.scn_conv_fwd, _lib.scn_conv_bwd_x, _lib.scn_conv_bwd_w, _lib.scn_subm_rules):
             f.restype = None
@@ -63,6 +68,39 @@ class RuleConv(torch.autograd.Function):
                 _lib.scn_conv_bwd_w(x.data_ptr(), cin, dy.data_ptr(), cout, i.data_ptr(), o.data_ptr(), i.numel(),
                                     dw[k].data_ptr())
         return dx, dw, None, None
+
+
+class TableConv(torch.autograd.Function):
+    """The same convolution from its neighbour tables (one OpenMP region per call): tab_f (K, n_out) int64 numpy =
+    input row per (offset, output row); tab_b (K, n_in) = output row per (offset, input row); flip_b: the data gradient
+    walks the weights in reverse offset order (3x3x3: tab_b is the forward table itself, mirrored)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, tab_f, tab_b, flip_b, n_out):
+        x, w = x.contiguous(), weight.contiguous()
+        K, cin, cout = (int(v) for v in w.shape)
+        y = x.new_zeros(n_out, cout)
+        if n_out and x.shape[0]:
+            _lib.scn_conv_tab(x.data_ptr(), cin, w.data_ptr(), cout, K, tab_f.ctypes.data, n_out, y.data_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.tabs = (tab_f, tab_b, flip_b, n_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        tab_f, tab_b, flip_b, n_out = ctx.tabs
+        dy = dy.contiguous()
+        K, cin, cout = (int(v) for v in w.shape)
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        if n_out and x.shape[0]:
+            if dx is not None:
+                _lib.scn_conv_tab_t(dy.data_ptr(), cout, w.data_ptr(), cin, K, tab_b.ctypes.data, x.shape[0], int(flip_b),
+                                    dx.data_ptr())
+            if dw is not None:
+                _lib.scn_conv_tab_w(x.data_ptr(), cin, dy.data_ptr(), cout, K, tab_f.ctypes.data, n_out, dw.data_ptr())
+        return dx, dw, None, None, None, None
 
 
 def subm_rules(coords, sorted_keys, order):

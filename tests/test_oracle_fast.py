@@ -60,3 +60,40 @@ def test_float64_keeps_the_torch_path():
     pairs = scn_oracle.pairs_from_nbr(g.subm_rules(3))
     y = scn_oracle.rule_conv(torch.randn(g.n, 4, dtype=torch.float64), torch.randn(27, 4, 4, dtype=torch.float64), pairs, g.n)
     assert y.dtype == torch.float64
+
+
+@pytest.mark.parametrize('kind', ['subm', 'down', 'deconv'])
+def test_table_convolutions_equal_the_torch_path(kind):
+    """The table-form kernels (one OpenMP region per convolution: what bench.py's cpu_baseline leg times) through the
+    oracle's modules, forward and both gradients, against the per-offset torch-op path."""
+    locs = random_sites(2, 16, 0.2, 9, True)
+    res = []
+    for fast in (False, True):
+        scn_oracle.FAST = fast
+        torch.manual_seed(4)
+        x = torch.randn(locs.shape[0], 12).requires_grad_()
+        t = scn_oracle.InputLayer(3, [16, 16, 16], mode=0)([locs, x])
+        if kind == 'subm':
+            m = scn_oracle.SubmanifoldConvolution(3, 12, 16, 3, False)
+            y = m(t).features
+        elif kind == 'down':
+            m = scn_oracle.Convolution(3, 12, 16, 2, 2, False)
+            y = m(t).features
+        else:
+            d = scn_oracle.Convolution(3, 12, 12, 2, 2, False)
+            m = scn_oracle.Deconvolution(3, 12, 16, 2, 2, False)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                d.weight.copy_(torch.randn_like(d.weight) * 0.2)
+            y = m(d(t)).features
+        torch.manual_seed(6)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn_like(m.weight) * 0.2)
+        if kind == 'deconv':
+            y = m(d(t)).features
+        else:
+            y = m(t).features
+        (y * torch.linspace(-1, 1, y.shape[1])).sum().backward()
+        res.append((y.detach().clone(), x.grad.clone(), m.weight.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * max(1.0, a.abs().max().item()))

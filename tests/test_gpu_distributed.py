@@ -157,7 +157,7 @@ def _worker_graph(rank, world, port, out):
     model = param_fill(GenModel(8, DIMS, 1, 16, 16, 4, True, True, 1, 1), 5).train().to(dev)
     batches = [to_device(synth.make_batch(2, DIMS, cfg=7, first_block=10 * it + 2 * rank, occupancy=0.08), dev)
                for it in range(2)]
-    step = GraphStep(model, lr=1e-3, headroom=1.6, grad_sync=lambda flat: dist.all_reduce(flat), world_size=world)
+    step = GraphStep(model, lr=1e-3, headroom=1.6, settle=False, grad_sync=lambda flat: dist.all_reduce(flat), world_size=world)
     lw = np.ones(5, dtype=np.float32)
     for it in range(6):
         loss = step(batches[it % 2], lw)

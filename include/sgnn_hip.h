@@ -110,19 +110,6 @@ int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t
                               int dim_z, int dim_y, int dim_x, int32_t *volume, int64_t volume_entries, int32_t *nbr,
                               int64_t ld, const int64_t *n_dev, sgnn_stream_t stream);
 
-/* Tile index of a 3x3x3 table (ld % 256 == 0): per 128-row tile the unique input rows its rules refer to and the
- * table in 16-bit tile-local slots (tiles with more than 768 unique rows are flagged and keep using the int32 table).
- * Large levels of narrow layers (cin, cout <= 16) then run sgnn_conv_fwd_tiled: each unique row is copied into LDS once
- * and the MFMAs are fed from there - 3.5 instead of 23.7 row fetches per output row on surface data.  The program
- * executor takes the index per level (lev_tile[], NULL = none).  index: sgnn_tile_index_bytes(ld) bytes. */
-int64_t sgnn_tile_index_bytes(int64_t ld);
-int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgnn_stream_t stream);
-int sgnn_conv_fwd_tiled(const float *x, int64_t n_in, int cin, const float *w, const int32_t *table, int64_t ld,
-                        int64_t n_out, int cout, float *y, int flags, const void *tile_index, sgnn_stream_t stream);
-/* 0: never use the tile kernel (A/B measurements, parity test); 1: use it where a tile index is passed; n > 1: the same
- * and n (rounded up to a multiple of 8) persistent workgroups instead of 512.  Returns the previous on/off setting. */
-int sgnn_conv_set_tiled(int on);
-
 /* stride-2 / size-2 rulebook, phase 1 (scn.Convolution(...,2,2), torch/model.py:44):
  * finds the coarse active set unique(floor(p/2)) in FIRST-TOUCH order of the fine
  * rows (wave ballot + prefix-sum compaction), writes
@@ -438,9 +425,7 @@ int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, c
  *         linear heads (weight row o = slot par+2o, bias par+2o+1).  Buffers [0, n_ext) are caller-owned inputs
  *         (ext[] pointers; their gradients go to gext[]), the rest live in the arena.
  *   lev_* per level: rows, table ld, nbr table, and for the transition level -> level+1 the children /
- *         ptable tables and the parent array (device pointers, NULL where unused); lev_tile: the level's tile index
- *         (sgnn_tile_index) or NULL — the array itself may be NULL — selecting the LDS-staged 3x3x3 kernel for 16->16
- *         layers of that level; a JoinTable's inputs are column ranges of its output (no concat pass) unless `keep`
+ *         ptable tables and the parent array (device pointers, NULL where unused); a JoinTable's inputs are column ranges of its output (no concat pass) unless `keep`
  *         asks for one of them; lev_cnt (the array may be NULL): per rows class a device int64 with the live row
  *         count (capacity mode, see the conventions above; lev_n then holds the capacities) or NULL
  *   params / pgrads: host arrays of device pointers.
@@ -464,14 +449,14 @@ int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *buf
 int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                      void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, int nparams,
+                      void *const *lev_cnt, int nlev, void *const *params, int nparams,
                       void *const *ext, void *const *idx, int nidx,
                       float *arena, int64_t arena_floats, const int32_t *keep, int training, void *ws,
                       int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                       void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, void *const *pgrads,
+                       void *const *lev_cnt, int nlev, void *const *params, void *const *pgrads,
                        int nparams, void *const *ext,
                        void *const *gext, void *const *idx, int nidx, const float *arena, float *garena,
                        int64_t arena_floats, void *const *gout, const int32_t *keep, int training, void *ws,

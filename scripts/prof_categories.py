@@ -2,7 +2,7 @@
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
-cats = [('conv_fwd', r'k_conv_fwd|k_conv_small|k_conv_tile'), ('conv_dw', r'k_conv_dw'), ('dw_reduce', r'k_dw_reduce'), ('bn', r'k_bn_'),
+cats = [('conv_fwd', r'k_conv_fwd|k_conv_small'), ('conv_dw', r'k_conv_dw'), ('dw_reduce', r'k_dw_reduce'), ('bn', r'k_bn_'),
         ('rulebook_subm', r'k_rulebook|k_vol_mark|k_tile_index'), ('hash', r'k_hash'), ('down2+scan', r'k_down2|k_scan|k_chain|k_compact|k_flag'),
         ('rows', r'k_concat|k_gather|k_add|k_sum_groups|k_scatter|k_repeat|k_sparse_to|k_dense_to|k_expand|k_coords|k_dense_coords'),
         ('linear', r'k_linear'), ('loss', r'k_loss'), ('copy/fill', r'rocclr'), ('adam', r'multi_tensor'),

@@ -40,10 +40,6 @@ PROTOTYPES = {
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_conv_stats_blocks': (c_i64, [c_i64]),
     'sgnn_conv_set_small': (c_i32, [c_i32]),
-    'sgnn_conv_set_tiled': (c_i32, [c_i32]),
-    'sgnn_tile_index_bytes': (c_i64, [c_i64]),
-    'sgnn_tile_index': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
-    'sgnn_conv_fwd_tiled': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     'sgnn_conv_set_small_rows': (c_i64, [c_i64]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
@@ -96,9 +92,9 @@ PROTOTYPES = {
     'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
-    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+    'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                   c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
-    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+    'sgnn_prog_backward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                    c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_concat3_rows': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_concat3_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,

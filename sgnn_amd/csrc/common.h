@@ -20,9 +20,6 @@ void sgnn_prof_end_launch(int slot, hipStream_t s);
 //    stats = 2: y is the gradient reaching a BatchNormReLU output; column sums of dz and dz*xhat with
 //    dz = y * (bn_out > 0 ? 1 : leak), xhat from bn_x / mean / invstd (what BatchNorm backward reduces first).
 //    partial[blk][2][COUT] doubles, blk = workgroup; summed later in fixed order (deterministic).
-#define TILE_ROWS 128     // rows per tile of the rulebook tile index (grid_rules.hip: k_tile_index)
-#define TILE_CAP 768      // unique input rows a tile may refer to before it falls back to the int32 table
-#define TILE_LTW 32       // 16-bit slots per row in the tile-local table (27 used): one 64-byte line per row
 struct ConvEpi {
   int64_t ldx, ldy, ld_add;
   const float *addend;
@@ -32,31 +29,17 @@ struct ConvEpi {
   int64_t ld_bnx;
   const float *mean, *invstd, *gamma, *beta;
   float leak;
-  // tile index of the 3x3x3 table (sgnn_tile_index), or NULL: large levels of narrow layers then stage each tile's
-  // unique input rows in LDS instead of gathering every rule entry
-  const int32_t *tile_cnt, *tile_u;
-  const uint16_t *tile_lt;
-  int tile_all;   // 1: every compiled tile shape (sgnn_conv_fwd_tiled); 0: only those that beat the gather kernel
   // capacity mode: the output row count lives in device memory (*n_dev, clamped to the n_out the launch was sized
   // for); NULL = the host value is exact.  Lets a whole training step be captured in a HIP graph.
   const int64_t *n_dev;
 };
-
-// the three arrays inside a tile-index blob of a table with leading dimension ld
-static inline void sgnn_tile_ptrs(const void *index, int64_t ld, const int32_t **cnt, const int32_t **u, const uint16_t **lt) {
-  const int64_t tiles = ld / TILE_ROWS;
-  const int64_t a = (tiles * 4 + 255) & ~int64_t(255), b = (tiles * TILE_CAP * 4 + 255) & ~int64_t(255);
-  *cnt = (const int32_t *)index;
-  *u = (const int32_t *)((const char *)index + a);
-  *lt = (const uint16_t *)((const char *)index + a + b);
-}
 
 // conv.hip internals used by prog.hip
 int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                        int64_t n_out, int cout, float *y, int flags, int in_shift, const int32_t *kmap,
                        const int32_t *kadd, int in_mul, int groups, int table_rows, const ConvEpi *epi,
                        sgnn_stream_t stream);
-int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K, bool tiled);
+int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K);
 // bn.hip internals used by prog.hip (strided rows, statistics partials supplied by a convolution epilogue)
 // n_dev (every internal entry point below, default NULL): device row count, clamped to the host value n, which then
 // is the capacity the launch is sized for

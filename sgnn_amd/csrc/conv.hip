@@ -352,235 +352,6 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 }
 
 // ---------------------------------------------------------------------------
-// Large levels of narrow layers (CIN, COUT <= 16; 3x3x3): the tile kernel.  The gather kernel above fetches every rule
-// entry's row separately — 23.7 x 64-byte gathers per output row on surface data, and the texture addresser, not HBM
-// or the MFMA pipe, is its limit (0.83-0.94 busy, profiles/r01i_conv_pmc.txt).  With the rulebook's tile index
-// (grid_rules.hip: k_tile_index) a workgroup owns a 128-row tile, copies the tile's ~450 UNIQUE input rows into LDS
-// once (3.5 instead of 23.7 row fetches per output row), and every A fragment of its 27 x 8 MFMAs per wave comes from
-// LDS (two ds_read per offset and wave against 256 MFMA cycles).  All 27 weight slices are resident (<= 27.6 KiB);
-// 76.8 KiB of LDS per workgroup -> two workgroups per CU, one staging while the other multiplies.  A tile whose
-// row set does not fit (cnt < 0: no locality in the site order) walks the int32 table like the gather kernel, without
-// the pipeline.  Same products and the same summation order over the offsets as k_conv_fwd.
-// ---------------------------------------------------------------------------
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_conv_tile(const float *__restrict__ x, int64_t n_in,
-                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
-                                                  int64_t ld, int64_t n_out, float *y, int flags, ConvEpi epi,
-                                                  int ntiles) {
-  using C = ConvCfg<CIN, COUT>;
-  constexpr int V = C::V, CINP = C::CINP, NT = C::NT, M = 2, K = 27;
-  // LDS holds each lane quarter's V channels in VP floats (12 channels: 3 of 4, so that every read is one aligned
-  // ds_read_b128 instead of three dwords); RS = floats per staged row
-  constexpr int VP = V == 3 ? 4 : V, RS = 4 * VP, PASSES_X = TILE_CAP / 64, KSPLIT = 9;
-  static_assert(NT == 1 && CINP <= 16, "tile kernel: narrow layers");
-  __shared__ __attribute__((aligned(16))) float xs[(TILE_CAP + 1) * RS];
-  __shared__ __attribute__((aligned(16))) float wl[K * 64 * VP];
-  static_assert(sizeof(xs) >= 4 * 2 * NT * 16 * sizeof(double), "row stage too small for the statistics scratch");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
-  const uint32_t ldx4 = (uint32_t)epi.ldx * 4u;
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
-  // persistent workgroups (gridDim.x % 8 == 0): XCD c = blockIdx % 8 owns the contiguous tiles [c*per, (c+1)*per) and
-  // its gridDim/8 workgroups walk them interleaved, so that at any time an XCD's L2 serves one window of the level
-  const int per = (ntiles + 7) >> 3, nbx = (int)(gridDim.x >> 3);
-  const int t_end = min(((int)(blockIdx.x & 7u) + 1) * per, ntiles);
-  int t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-
-  const int sq = tid & 3, sr = tid >> 2;                 // staging: four lanes per row, 64 rows per pass
-  int32_t id[PASSES_X];
-  uint32_t pk[M][TILE_LTW / 2], pkn[M][TILE_LTW / 2];
-  float g[PASSES_X][V];
-  auto load_index = [&](int tile, int cnt, uint32_t(&pkv)[M][TILE_LTW / 2]) {
-    const int32_t *up = epi.tile_u + (int64_t)tile * TILE_CAP;
-#pragma unroll
-    for (int p = 0; p < PASSES_X; ++p) id[p] = p * 64 + sr < cnt ? up[p * 64 + sr] : -1;   // -1: outside the window -> 0
-    const uint4 *ltp = reinterpret_cast<const uint4 *>(epi.tile_lt) +
-                       (((int64_t)tile * TILE_ROWS + wave * (16 * M) + r) * (TILE_LTW / 8));
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int j = 0; j < TILE_LTW / 8; ++j) {
-        const uint4 v = ltp[m * 16 * (TILE_LTW / 8) + j];
-        pkv[m][4 * j] = v.x, pkv[m][4 * j + 1] = v.y, pkv[m][4 * j + 2] = v.z, pkv[m][4 * j + 3] = v.w;
-      }
-  };
-  auto load_rows = [&]() {                                // the unique rows, all passes in flight
-#pragma unroll
-    for (int p = 0; p < PASSES_X; ++p) {
-      buf_load_floats<V>(rs_x, (uint32_t)id[p] * ldx4 + (uint32_t)(sq * V * 4), g[p]);
-      if constexpr (CINP != CIN) {
-#pragma unroll
-        for (int s = 0; s < V; ++s)
-          if (3 * V + s >= CIN) g[p][s] = (sq == 3) ? 0.f : g[p][s];
-      }
-    }
-  };
-  int cnt = t < t_end ? epi.tile_cnt[t] : -1;
-  if (cnt >= 0) {
-    load_index(t, cnt, pk);
-    load_rows();
-  }
-  // weights, once per workgroup, in B-fragment order: wl[k][lane = q*16 + n][s] = W[c = q*V + s][n], zero padded; one
-  // 16-byte global load per four values (along n, or along c for the transposed call)
-  {
-    constexpr int UNITS = K * CINP * 4;                   // (k, c, n/4) resp. (k, n, c/4) with n < 16, c < CINP
-    constexpr int PASSES_W = (UNITS + 255) / 256;
-    f32x4 wv[PASSES_W];
-#pragma unroll
-    for (int p = 0; p < PASSES_W; ++p) {
-      const int e = p * 256 + tid;
-      wv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e < UNITS) {
-        const int k = e / (CINP * 4), ks = flip ? (K - 1 - k) : k, i = e % (CINP * 4);
-        if (!transpose) {
-          const int c = i >> 2, n4 = (i & 3) * 4;
-          if (c < CIN && n4 < COUT) wv[p] = *reinterpret_cast<const f32x4 *>(w + ((int64_t)ks * CIN + c) * COUT + n4);
-        } else {
-          const int n = i / (CINP / 4), c4 = (i % (CINP / 4)) * 4;
-          if (n < COUT && c4 < CIN) wv[p] = *reinterpret_cast<const f32x4 *>(w + ((int64_t)ks * COUT + n) * CIN + c4);
-        }
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < PASSES_W; ++p) {
-      const int e = p * 256 + tid;
-      if (e < UNITS) {
-        const int k = e / (CINP * 4), i = e % (CINP * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = transpose ? (i % (CINP / 4)) * 4 + j : (i >> 2);
-          const int n = transpose ? i / (CINP / 4) : (i & 3) * 4 + j;
-          wl[(k * 64 + (c / V) * 16 + n) * VP + (c % V)] = wv[p][j];
-        }
-      }
-    }
-  }
-  f32x4 acc[M][NT];
-  auto mma = [&](const float(&a)[M][VP], const float(&b)[VP]) {
-#pragma unroll
-    for (int s = 0; s < V; ++s)
-#pragma unroll
-      for (int m = 0; m < M; ++m) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][0], 0, 0, 0);
-  };
-  auto lds_b = [&](int k, float(&b)[VP]) {
-    const float *bp = wl + (k * 64 + lane) * VP;
-#pragma unroll
-    for (int s = 0; s < VP; ++s) b[s] = bp[s];
-  };
-  auto lds_a = [&](int k, float(&av)[M][VP]) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const uint32_t raw = (k & 1) ? (pk[m][k >> 1] >> 16) : (pk[m][k >> 1] & 0xFFFFu);
-      const float *src = xs + raw * RS + (VP == 4 ? ((q ^ (raw >> 2)) & 3u) : (uint32_t)q) * VP;
-#pragma unroll
-      for (int s = 0; s < VP; ++s) av[m][s] = src[s];
-    }
-  };
-
-  while (t < t_end) {
-    const int64_t row0 = (int64_t)t * TILE_ROWS + wave * (16 * M);
-    const bool staged = cnt >= 0;
-    if (staged) {
-#pragma unroll
-      for (int p = 0; p < PASSES_X; ++p) {
-        const int s0 = p * 64 + sr;
-        if (s0 < cnt) {
-          float *dst = xs + s0 * RS + (VP == 4 ? ((sq ^ (s0 >> 2)) & 3) : sq) * VP;   // quarter swizzle: bank spread
-#pragma unroll
-          for (int s = 0; s < V; ++s) dst[s] = g[p][s];
-        }
-      }
-      if (tid < RS) xs[cnt * RS + tid] = 0.f;             // the zero row: slot of the offsets without a rule
-    }
-    __syncthreads();                                      // rows (and, the first time, weights) staged
-    // the next tile's index words travel while this tile multiplies; its rows follow once the ids are there
-    const int tn = t + nbx;
-    const int cntn = tn < t_end ? epi.tile_cnt[tn] : -1;
-    if (cntn >= 0) load_index(tn, cntn, pkn);
-#pragma unroll
-    for (int m = 0; m < M; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (staged) {
-      float a[3][M][VP], b[3][VP];                        // two offsets ahead of the MFMAs
-      lds_a(0, a[0]);
-      lds_b(0, b[0]);
-      lds_a(1, a[1]);
-      lds_b(1, b[1]);
-#pragma unroll
-      for (int k = 0; k < KSPLIT; ++k) {
-        lds_a(k + 2, a[(k + 2) % 3]);
-        lds_b(k + 2, b[(k + 2) % 3]);
-        mma(a[k % 3], b[k % 3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (cntn >= 0) load_rows();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = KSPLIT; k < K; ++k) {
-        if (k + 2 < K) {
-          lds_a(k + 2, a[(k + 2) % 3]);
-          lds_b(k + 2, b[(k + 2) % 3]);
-        }
-        mma(a[k % 3], b[k % 3]);
-      }
-    } else {
-      // no locality in this tile (more than TILE_CAP distinct rows): walk the int32 table like the gather kernel
-      const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
-      const uint32_t ld4 = (uint32_t)ld * 4u;
-#pragma unroll 1
-      for (int k = 0; k < K; ++k) {
-        float a[M][VP], av[V], b[VP];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const int32_t rid = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)(row0 + m * 16 + r) * 4u, k * ld4, 0);
-          buf_load_floats<V>(rs_x, (uint32_t)rid * ldx4 + (uint32_t)(q * V * 4), av);
-#pragma unroll
-          for (int s = 0; s < V; ++s) a[m][s] = (CINP != CIN && 3 * V + s >= CIN && q == 3) ? 0.f : av[s];
-        }
-        lds_b(k, b);
-        mma(a, b);
-      }
-      if (cntn >= 0) load_rows();
-    }
-    __syncthreads();                                      // every wave is done with xs: statistics scratch, next rows
-    conv_epilogue<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, reinterpret_cast<double *>(xs), x, (size_t)t);
-    if (epi.stats) __syncthreads();
-    t = tn;
-    cnt = cntn;
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int j = 0; j < TILE_LTW / 2; ++j) pk[m][j] = pkn[m][j];
-  }
-}
-
-// layers the tile kernel is compiled for (forward and the transposed data-gradient shapes of the narrow layers)
-#define CONV_TILE_CASES(X) X(8, 8) X(8, 12) X(12, 8) X(12, 12) X(12, 16) X(16, 12) X(16, 16)
-// ... of which the executor uses only those that measured faster than the gather kernel (sgnn_conv_fwd_tiled: all)
-#define CONV_TILE_AUTO(X) X(16, 16)
-
-static int g_tile_grid = 512;   // persistent workgroups of the tile kernel (sgnn_conv_set_tiled(n > 1): n, a multiple of 8)
-static int g_tile_kernel = 1;    // sgnn_conv_set_tiled: 0 = never use the tile kernel (A/B measurements, parity test)
-SGNN_EXPORT int sgnn_conv_set_tiled(int on) {
-  const int prev = g_tile_kernel;
-  g_tile_kernel = on ? 1 : 0;
-  if (on > 1) g_tile_grid = (on + 7) & ~7;
-  return prev;
-}
-
-static bool conv_tile_shape(int cin, int cout, bool all) {
-#define X(CI, CO) \
-  if (cin == CI && cout == CO) return true;
-  if (all) {
-    CONV_TILE_CASES(X)
-  } else {
-    CONV_TILE_AUTO(X)
-  }
-#undef X
-  return false;
-}
-
-// ---------------------------------------------------------------------------
 // Small levels (< ~40 k rows: every coarse U-Net level, ~60 % of all convolution launches of a step).  The kernel
 // above walks the offsets serially with a short prefetch distance: on a level that cannot fill the chip its time is
 // K dependent gather round trips (~0.4 us each, 11 us per launch at K = 27), not bandwidth and not MFMA.  Here a
@@ -779,13 +550,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
 #define CONV_FWD_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) \
   X(8, 1) X(12, 8) X(16, 12) X(16, 34) X(16, 30) X(16, 26) X(16, 48) X(32, 16) X(16, 32) X(4, 16) X(16, 4) \
-  X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56)
+  X(16, 24) X(24, 16) X(24, 32) X(32, 24) X(64, 32) X(32, 64) X(56, 28) X(28, 56) X(32, 32) X(28, 16) X(16, 28)
 
 // number of workgroups (= statistics partial blocks) a plain launch over n_out rows uses
-int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K, bool tiled) {
+int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K) {
   const int64_t grid4 = (n_out + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK;
   if (grid4 < CONV_SMALL_GRID) return (n_out + 15) / 16;         // k_conv_small: 16 rows per workgroup
-  if (tiled && g_tile_kernel && K == 27 && conv_tile_shape(cin, cout, false)) return (n_out + TILE_ROWS - 1) / TILE_ROWS;
   return grid4;
 }
 
@@ -829,7 +599,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   if (epi.ld_add <= 0) epi.ld_add = cout;
   if (epi.ld_bnx <= 0) epi.ld_bnx = cout;
   const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
-  const bool has_epi = epi.ldx != cin || epi.ldy != cout || epi.addend || epi.stats || epi.tile_cnt;
+  const bool has_epi = epi.ldx != cin || epi.ldy != cout || epi.addend || epi.stats;
   SGNN_CHECK_ARG(epi.ldx >= cin && epi.ldx <= 1024 && epi.ldy >= cout && epi.ldy <= 1024 && epi.ld_add >= cout &&
                  epi.ld_add <= 1024 && epi.ld_bnx >= cout && epi.ld_bnx <= 1024);
   SGNN_CHECK_ARG(epi.stats >= 0 && epi.stats <= 2 && (!epi.stats || (plain && epi.partial)));
@@ -863,21 +633,6 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                          w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
     done = true;                                                                                        \
   } while (0)
-  // large level of a narrow 3x3x3 layer with a tile index: unique rows through LDS (k_conv_tile)
-  if (plain && !small && K == 27 && in_shift == 0 && g_tile_kernel && epi.tile_cnt && epi.tile_u && epi.tile_lt &&
-      conv_tile_shape(cin, cout, epi.tile_all != 0) && !epi.n_dev) {
-    // persistent workgroups, two per CU (76.8 KiB of LDS each); grid % 8 == 0 for the XCD schedule
-    const int ntiles = (int)((n_out + TILE_ROWS - 1) / TILE_ROWS);
-    const unsigned tgrid = (unsigned)(ntiles < g_tile_grid ? ((ntiles + 7) & ~7) : g_tile_grid);
-#define X(CI, CO)                                                                                                \
-  if (!done && cin == CI && cout == CO) {                                                                        \
-    SGNN_LAUNCH((k_conv_tile<CI, CO>), dim3(tgrid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y,     \
-                       flags, epi, ntiles);                                                                      \
-    done = true;                                                                                                 \
-  }
-    CONV_TILE_CASES(X)
-#undef X
-  }
 #define X(CI, CO) \
   if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)
@@ -915,19 +670,7 @@ SGNN_EXPORT int sgnn_conv_fwd(const float *x, int64_t n_in, int cin, const float
                             K, nullptr, stream);
 }
 
-SGNN_EXPORT int64_t sgnn_conv_stats_blocks(int64_t n_out) { return n_out > 0 ? sgnn_conv_grid_blocks(n_out, 0, 0, 0, false) : 0; }
-
-// 3x3x3 convolution through the rulebook's tile index (sgnn_tile_index): what the program executor uses on large
-// levels; exported for the parity test and measurements
-SGNN_EXPORT int sgnn_conv_fwd_tiled(const float *x, int64_t n_in, int cin, const float *w, const int32_t *table,
-                                    int64_t ld, int64_t n_out, int cout, float *y, int flags, const void *tile_index,
-                                    sgnn_stream_t stream) {
-  ConvEpi epi{};
-  if (tile_index) sgnn_tile_ptrs(tile_index, ld, &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
-  epi.tile_all = 1;
-  return sgnn_conv_fwd_impl(x, n_in, cin, w, 27, table, ld, n_out, cout, y, flags, 0, nullptr, nullptr, 1, 1, 27, &epi,
-                            stream);
-}
+SGNN_EXPORT int64_t sgnn_conv_stats_blocks(int64_t n_out) { return n_out > 0 ? sgnn_conv_grid_blocks(n_out, 0, 0, 0) : 0; }
 
 // plain rulebook walk with strided rows and a fused epilogue (see ConvEpi; sgnn_hip.h)
 SGNN_EXPORT int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
@@ -935,7 +678,7 @@ SGNN_EXPORT int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t
                                   int flags, const float *addend, int64_t ld_add, int stats, double *partial,
                                   const float *bn_x, int64_t ld_bnx, const float *mean, const float *invstd,
                                   const float *gamma, const float *beta, float leak, sgnn_stream_t stream) {
-  ConvEpi epi{ldx, ldy, ld_add, addend, stats, partial, bn_x, ld_bnx, mean, invstd, gamma, beta, leak, nullptr, nullptr, nullptr, 0};
+  ConvEpi epi{ldx, ldy, ld_add, addend, stats, partial, bn_x, ld_bnx, mean, invstd, gamma, beta, leak, nullptr};
   return sgnn_conv_fwd_impl(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, 0, nullptr, nullptr, 1, 1, K, &epi,
                             stream);
 }
@@ -1344,7 +1087,7 @@ static int64_t dw_rows_per_block(int64_t n_out) {
 
 bool dw_shape_ok(int cin, int cout) {   // compiled weight-gradient shapes (CONV_DW_CASES)
   static const int shapes[][2] = {{1, 8}, {8, 8}, {8, 12}, {12, 12}, {12, 16}, {16, 16}, {34, 16}, {30, 16}, {26, 16}, {48, 16},
-                                  {32, 16}, {4, 16}, {16, 24}, {24, 32}, {64, 32}, {56, 28}};
+                                  {32, 16}, {4, 16}, {16, 24}, {24, 32}, {64, 32}, {56, 28}, {32, 32}, {28, 16}};
   for (const auto &sh : shapes)
     if (sh[0] == cin && sh[1] == cout) return true;
   return false;
@@ -1359,7 +1102,7 @@ SGNN_EXPORT int64_t sgnn_conv_bwd_weight_ws_bytes(int64_t n_out, int K, int cin,
 
 #define CONV_DW_CASES(X) \
   X(1, 8) X(8, 8) X(8, 12) X(12, 12) X(12, 16) X(16, 16) X(34, 16) X(30, 16) X(26, 16) X(48, 16) X(32, 16) X(4, 16) \
-  X(16, 24) X(24, 32) X(64, 32) X(56, 28)
+  X(16, 24) X(24, 32) X(64, 32) X(56, 28) X(32, 32) X(28, 16)
 
 SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *dy, int cout,
                                         const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw,

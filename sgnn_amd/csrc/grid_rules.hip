@@ -337,123 +337,6 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3_lds(const uint64_t *__re
 // (incl. its memset), N = 2 017 264 children-ordered sites 661 vs 498 us: the 26 dependent LDS probe walks + 768 LDS CAS
 // inserts per workgroup cost more than the 13 L2-resident global probes they replace, so the global kernel is the default.
 // ---------------------------------------------------------------------------
-// Tile index of a 3x3x3 rulebook: for every 128-row tile, the UNIQUE input rows its 27 x 128 rule entries refer to
-// (surface data: ~450 instead of 27 x 128 x 0.88 = 3 000 gathers) and the table re-expressed in 16-bit tile-local
-// slots.  conv.hip's tile kernel stages those rows in LDS once and feeds its MFMAs from there (the texture
-// addresser, not HBM, limits the gather kernel: profiles/r01i_conv_pmc.txt).  Built once per level, used by the
-// forward and data-gradient passes of every 3x3x3 convolution of the level (the rulebook is symmetric, so the same
-// row set serves both).  Slots are numbered by hash position: deterministic.
-//   cnt[t]                 unique rows of tile t, or -1 when there are more than TILE_CAP (the conv kernel then walks
-//                          the int32 table for that tile)
-//   urows[t][TILE_CAP]     the rows
-//   lt[t][27][128]         slot of nbr[k][t*128 + j], 0xFFFF = no rule
-// ---------------------------------------------------------------------------
-#define TILE_HASH 4096
-
-__global__ __launch_bounds__(TILE_ROWS) void k_tile_index(const int32_t *__restrict__ nbr, int64_t ld,
-                                                         int32_t *__restrict__ cnt, int32_t *__restrict__ urows,
-                                                         uint16_t *__restrict__ lt) {
-  __shared__ int32_t hkey[TILE_HASH];
-  __shared__ uint16_t hslot[TILE_HASH];
-  __shared__ int s_ins, s_over, s_wsum[2];
-  const int tid = threadIdx.x;
-  const int64_t tile = blockIdx.x, row = tile * TILE_ROWS + tid;
-  for (int e = tid; e < TILE_HASH; e += TILE_ROWS) hkey[e] = -1;
-  if (tid == 0) {
-    s_ins = 0;
-    s_over = 0;
-  }
-  __syncthreads();
-  int32_t ids[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) ids[k] = nbr[(int64_t)k * ld + row];     // padding rows hold -1
-  // phase 1: the set of rows (insert only; give up as soon as the tile cannot fit)
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int32_t id = ids[k];
-    if (id < 0 || s_over) continue;
-    unsigned h = ((unsigned)id * 2654435761u) >> 20;                    // 12 bits
-    while (true) {
-      const int32_t prev = atomicCAS(&hkey[h], -1, id);
-      if (prev == id) break;
-      if (prev == -1) {
-        if (atomicAdd(&s_ins, 1) >= TILE_CAP) s_over = 1;
-        break;
-      }
-      h = (h + 1) & (TILE_HASH - 1);
-    }
-  }
-  __syncthreads();
-  if (s_over) {
-    if (tid == 0) cnt[tile] = -1;
-    return;
-  }
-  // phase 2: slot = rank of the hash position among the occupied ones (32 positions per thread, wave scan)
-  const int e0 = tid * (TILE_HASH / TILE_ROWS);
-  int mine = 0;
-#pragma unroll
-  for (int e = 0; e < TILE_HASH / TILE_ROWS; ++e) mine += hkey[e0 + e] >= 0;
-  int incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if ((tid & 63) >= d) incl += t;
-  }
-  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-  __syncthreads();
-  int slot = incl - mine + (tid >= 64 ? s_wsum[0] : 0);
-#pragma unroll
-  for (int e = 0; e < TILE_HASH / TILE_ROWS; ++e)
-    if (hkey[e0 + e] >= 0) {
-      hslot[e0 + e] = (uint16_t)slot;
-      urows[tile * TILE_CAP + slot] = hkey[e0 + e];
-      ++slot;
-    }
-  if (tid == 0) cnt[tile] = s_wsum[0] + s_wsum[1];
-  __syncthreads();
-  // phase 3: the table in tile-local slots, one 64-byte line per row (no rule -> slot total: the kernel's zero row)
-  const int total = s_wsum[0] + s_wsum[1];
-  uint32_t pk[TILE_LTW / 2];
-#pragma unroll
-  for (int j = 0; j < TILE_LTW / 2; ++j) pk[j] = 0;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int32_t id = ids[k];
-    uint32_t sl = (uint32_t)total;
-    if (id >= 0) {
-      unsigned h = ((unsigned)id * 2654435761u) >> 20;
-      while (hkey[h] != id) h = (h + 1) & (TILE_HASH - 1);
-      sl = hslot[h];
-    }
-    pk[k >> 1] |= sl << ((k & 1) * 16);
-  }
-  uint4 *dst = reinterpret_cast<uint4 *>(lt) + (tile * TILE_ROWS + tid) * (TILE_LTW / 8);
-#pragma unroll
-  for (int j = 0; j < TILE_LTW / 8; ++j) dst[j] = make_uint4(pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3]);
-}
-
-SGNN_EXPORT int64_t sgnn_tile_index_bytes(int64_t ld) {   // cnt + urows + lt, each 256-byte aligned, in this order
-  const int64_t tiles = ld / TILE_ROWS;
-  auto al = [](int64_t v) { return (v + 255) & ~int64_t(255); };
-  return al(tiles * 4) + al(tiles * TILE_CAP * 4) + al(tiles * TILE_ROWS * TILE_LTW * 2);
-}
-
-// nbr: a 3x3x3 table [27][ld] (ld % 256 == 0, padding -1).  index: sgnn_tile_index_bytes(ld) bytes.
-SGNN_EXPORT int sgnn_tile_index(const int32_t *nbr, int64_t ld, void *index, sgnn_stream_t stream) {
-  SGNN_CHECK_ARG(ld >= 0 && ld % 256 == 0);
-  if (ld == 0) return SGNN_OK;
-  SGNN_CHECK_ARG(nbr && index);
-  const int64_t tiles = ld / TILE_ROWS;
-  auto al = [](int64_t v) { return (v + 255) & ~int64_t(255); };
-  int32_t *cnt = (int32_t *)index;
-  int32_t *urows = (int32_t *)((char *)index + al(tiles * 4));
-  uint16_t *lt = (uint16_t *)((char *)urows + al(tiles * TILE_CAP * 4));
-  SGNN_LAUNCH(k_tile_index, dim3((unsigned)tiles), dim3(TILE_ROWS), 0, (hipStream_t)stream, nbr, ld, cnt, urows, lt);
-  SGNN_CHECK_LAUNCH();
-  return SGNN_OK;
-}
-
-// ---------------------------------------------------------------------------
 // The same rulebook through a dense index volume: vol[((b*Z + z)*Y + y)*X + x] = row of the site, -1 elsewhere.  A
 // neighbour look-up is then ONE 4-byte read next to the reads of the neighbouring threads (sites arrive in raster or
 // children order) instead of a hash probe into a random 8-byte key plus the value read, and all 27 entries of a site

@@ -241,7 +241,7 @@ int64_t ws_stats(const View &v) {
     const int32_t *o = v.ops + OPW * i;
     if (o[0] != OP_CONV_SUBM && o[0] != OP_CONV_DOWN) continue;
     const int64_t rows_f = v.lev_n[o[5]], rows_o = o[0] == OP_CONV_DOWN ? v.lev_n[o[5] + 1] : rows_f;
-    // block counts of the finest-grained kernel that may run (16-row small kernel / 128-row tile kernel)
+    // block counts of the finest-grained kernel that may run (the 16-row small kernel)
     const int64_t a = ((rows_o > 0 ? rows_o : 1) + 15) / 16 * 2 * o[7] * (int64_t)sizeof(double);   // forward: out rows x cout
     const int64_t b = ((rows_f > 0 ? rows_f : 1) + 15) / 16 * 2 * o[6] * (int64_t)sizeof(double);   // data gradient: in rows x cin
     if (a > need) need = a;
@@ -316,7 +316,7 @@ SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const 
 SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                   const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                   void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                  void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params, int nparams,
+                                  void *const *lev_cnt, int nlev, void *const *params, int nparams,
                                   void *const *ext, void *const *idx,
                                   int nidx, float *arena, int64_t arena_floats, const int32_t *keep, int training,
                                   void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
@@ -377,15 +377,13 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
           epi.ld_add = LD(other);
           dst_buf = PL.add_dst[i];
         }
-        const bool tiled = !down && lev_tile && lev_tile[lev];
-        if (tiled) sgnn_tile_ptrs(lev_tile[lev], lev_ld[lev], &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
         int j = i + 1 + (PL.add_dst[i] >= 0 ? 1 : 0);
         if (g_fuse && training && n_out > 0 && j < nops && ops[OPW * j] == OP_BN && ops[OPW * j + 1] == dst_buf &&
             sgnn_conv_epi_supported(cin, cout)) {
           epi.stats = 1;
           epi.partial = stats_ws;
           pre[j] = stats_ws;
-          pre_nblk[j] = sgnn_conv_grid_blocks(n_out, cin, cout, down ? 8 : 27, tiled);
+          pre_nblk[j] = sgnn_conv_grid_blocks(n_out, cin, cout, down ? 8 : 27);
         }
         epi.ldx = LD(in0);
         epi.ldy = LD(dst_buf);
@@ -456,7 +454,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
 SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                    const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                                    void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
-                                   void *const *lev_tile, void *const *lev_cnt, int nlev, void *const *params,
+                                   void *const *lev_cnt, int nlev, void *const *params,
                                    void *const *pgrads, int nparams,
                                    void *const *ext, void *const *gext, void *const *idx, int nidx,
                                    const float *arena, float *garena, int64_t arena_floats, void *const *gout,
@@ -591,8 +589,6 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             // store (in place), and when in0 is the output of the BatchNormReLU right before this op and this is the
             // last contribution to its gradient, the epilogue also reduces sum dz / sum dz*xhat for that BatchNorm
             ConvEpi epi{};
-            const bool tiled = !down && lev_tile && lev_tile[lev];      // symmetric rulebook: the same row sets
-            if (tiled) sgnn_tile_ptrs(lev_tile[lev], lev_ld[lev], &epi.tile_cnt, &epi.tile_u, &epi.tile_lt);
             if (init[in0]) {                    // what the buffer (or its alias / the caller's tensor) already holds
               epi.addend = GR(in0);
               epi.ld_add = GRLD(in0);
@@ -610,7 +606,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
               epi.beta = P(bo[4] + 1);
               epi.leak = opf[4 * (i - 1) + 2];
               pre[i - 1] = stats_ws;
-              pre_nblk[i - 1] = sgnn_conv_grid_blocks(n, cout, cin, K, tiled);
+              pre_nblk[i - 1] = sgnn_conv_grid_blocks(n, cout, cin, K);
             }
             epi.ldx = ld_dy;
             epi.ldy = LD(in0);

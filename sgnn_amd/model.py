@@ -34,10 +34,59 @@ STAGES = True   # each generative stage (skip join .. heads) as one native progr
 TEACHER_GEOMETRY_FIRST = os.environ.get('SGNN_TEACHER_GEOMETRY_FIRST', '1') != '0'
 
 
+class DenseConv(nn.Module):
+    """Parameter holder of an nn.Conv3d / nn.ConvTranspose3d (bias=False, torch/model.py:89-136) whose `weight` lives
+    in the layout the rulebook kernels read — (K = k^3 taps, Cin, Cout) — instead of torch's (Cout, Cin, k, k, k) /
+    (Cin, Cout, k, k, k): the training step no longer re-permutes six weight tensors (and their gradients) every
+    iteration.  state_dict() / load_state_dict() speak the torch layout, so reference checkpoints load unchanged and
+    saved ones load into the reference; initial values are drawn exactly as the torch module draws them."""
+
+    def __init__(self, cin, cout, k, stride, pad, transposed=False):
+        nn.Module.__init__(self)
+        self.cin, self.cout, self.k, self.stride, self.pad, self.transposed = cin, cout, k, stride, pad, transposed
+        ref = (nn.ConvTranspose3d if transposed else nn.Conv3d)(cin, cout, kernel_size=k, stride=stride, padding=pad,
+                                                                 bias=False)
+        self.weight = nn.Parameter(self.to_native(ref.weight.detach()))
+        self.weight._sgnn_dense = self     # optimizer checkpoints convert their per-parameter state with it too
+        self._register_state_dict_hook(DenseConv._save_hook)
+
+    def to_native(self, w):      # torch layout -> (K, Cin, Cout)
+        perm = (2, 3, 4, 0, 1) if self.transposed else (2, 3, 4, 1, 0)
+        return w.permute(*perm).reshape(self.k ** 3, self.cin, self.cout).contiguous()
+
+    def to_torch(self, w):       # (K, Cin, Cout) -> torch layout
+        k = self.k
+        w = w.reshape(k, k, k, self.cin, self.cout)
+        return (w.permute(3, 4, 0, 1, 2) if self.transposed else w.permute(4, 3, 0, 1, 2)).contiguous()
+
+    @staticmethod
+    def _save_hook(module, state, prefix, local_metadata):
+        state[prefix + 'weight'] = module.to_torch(state[prefix + 'weight'])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        w = state_dict.get(prefix + 'weight')
+        want = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
+        if w is not None and w.dim() == 5 and tuple(w.shape[:2]) == want:
+            state_dict[prefix + 'weight'] = self.to_native(w)
+        return nn.Module._load_from_state_dict(self, state_dict, prefix, *args, **kwargs)
+
+
+def named_gradients(model):
+    """{parameter name: gradient} with every tensor in the REFERENCE's layout (the dense convolutions keep their weights
+    as (K, Cin, Cout), see DenseConv) — what a test or a tool that compares against the reference's `.grad`s wants."""
+    owners = {}
+    for mn, mod in model.named_modules():
+        if isinstance(mod, DenseConv):
+            owners[(mn + '.' if mn else '') + 'weight'] = mod
+    out = {}
+    for n, p in model.named_parameters():
+        g = p.grad
+        out[n] = owners[n].to_torch(g) if (g is not None and n in owners) else g
+    return out
+
+
 def _dense_block(cin, cout, k, stride, pad, transposed=False):
-    conv = (nn.ConvTranspose3d if transposed else nn.Conv3d)(cin, cout, kernel_size=k, stride=stride, padding=pad,
-                                                              bias=False)
-    return nn.Sequential(conv, nn.BatchNorm3d(cout), nn.ReLU(True))
+    return nn.Sequential(DenseConv(cin, cout, k, stride, pad, transposed), nn.BatchNorm3d(cout), nn.ReLU(True))
 
 
 class SparseEncoderLayer(nn.Module):
@@ -133,15 +182,18 @@ class TSDFEncoder(nn.Module):
         geo = dense_geometry(batch_size, dims, x.features.device)
         rows = F_.ScatterRows.apply(x.features, geo.grid.lookup(g.coords, g.cnt), geo.grid.n, g.cnt)
         t0, t1 = geo.level(0), geo.level(1)
-        enc0 = _bn3d_relu(self.encode_dense0[1], _dense_conv(rows, self.encode_dense0[0], t0, down=True))
-        enc1 = _bn3d_relu(self.encode_dense1[1], _dense_conv(enc0, self.encode_dense1[0], t1, down=True))
-        bott = _bn3d_relu(self.bottleneck_dense2[1], _conv1x1(enc1, self.bottleneck_dense2[0]))
+        tr = []
+        enc0 = _bn3d_relu(self.encode_dense0[1], _dense_conv(rows, self.encode_dense0[0], t0, down=True), tr)
+        enc1 = _bn3d_relu(self.encode_dense1[1], _dense_conv(enc0, self.encode_dense1[0], t1, down=True), tr)
+        bott = _bn3d_relu(self.bottleneck_dense2[1], _conv1x1(enc1, self.bottleneck_dense2[0]), tr)
         d_in = _join(bott, enc1) if self.use_skip_dense else bott
-        dec0 = _bn3d_relu(self.decode_dense3[1], _dense_conv(d_in, self.decode_dense3[0], t1, down=False))
+        dec0 = _bn3d_relu(self.decode_dense3[1], _dense_conv(d_in, self.decode_dense3[0], t1, down=False), tr)
         d_in = _join(dec0, enc0) if self.use_skip_dense else dec0
-        xr = _bn3d_relu(self.decode_dense4[1], _dense_conv(d_in, self.decode_dense4[0], t0, down=False))
-        xr = _bn3d_relu(self.final[1], _conv1x1(xr, self.final[0]))
+        xr = _bn3d_relu(self.decode_dense4[1], _dense_conv(d_in, self.decode_dense4[0], t0, down=False), tr)
+        xr = _bn3d_relu(self.final[1], _conv1x1(xr, self.final[0]), tr)
         # both 1x1 heads in one pass; column 0 = occupancy logit, 1 = sdf (model.py:163-165)
+        if tr:
+            torch._foreach_add_(tr, 1)
         w = torch.cat([self.occpred[0].weight.view(1, -1), self.sdfpred[0].weight.view(1, -1)], 0)
         return xr, F_.RowLinear.apply(xr, w, None), skips, geo
 
@@ -222,23 +274,48 @@ def _dense_conv(rows, conv, tables, down):
     """nn.Conv3d(k4,s2,p1) (down=True) or nn.ConvTranspose3d(k4,s2,p1) (down=False) on channel-last rows."""
     tdown, ld_c, n_c, tup, ld_f, n_f = tables
     w = conv.weight
-    if down:   # weight (Cout, Cin, 4,4,4) -> (64, Cin, Cout)
+    if isinstance(conv, DenseConv):        # already (64, Cin, Cout)
+        wk = w
+    elif down:   # nn.Conv3d weight (Cout, Cin, 4,4,4) -> (64, Cin, Cout)
         wk = w.permute(2, 3, 4, 1, 0).reshape(64, w.shape[1], w.shape[0])
+    else:        # nn.ConvTranspose3d (Cin, Cout, 4,4,4) -> (64, Cin, Cout)
+        wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])
+    if down:
         return F_.SparseConv.apply(rows, wk, tdown, ld_c, n_c, tup, ld_f, n_f, F_.CONV_TRANSPOSE_W, 0)
-    wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])   # (Cin, Cout, 4,4,4) -> (64, Cin, Cout)
     return F_.SparseConv.apply(rows, wk, tup, ld_f, n_f, tdown, ld_c, n_c, F_.CONV_TRANSPOSE_W, 0)
 
 
+_ident_tables = {}
+
+
 def _conv1x1(rows, conv):
-    return rows @ conv.weight.view(conv.weight.shape[0], -1).t()   # plain GEMM (rocBLAS)
+    """1x1x1 convolution of a dense level = a K = 1 rulebook convolution on the identity table (same MFMA kernels as every
+    other convolution; the rocBLAS GEMMs this replaces took 45-66 us each for their tiny shapes)."""
+    if not isinstance(conv, DenseConv):
+        return rows @ conv.weight.view(conv.weight.shape[0], -1).t()
+    n = int(rows.shape[0])
+    key = (n, str(rows.device))
+    tab = _ident_tables.get(key)
+    if tab is None:
+        if len(_ident_tables) > 16:
+            _ident_tables.clear()
+        ld = ((max(n, 1) + 255) // 256) * 256
+        t = torch.full((ld,), -1, dtype=torch.int32, device=rows.device)
+        t[:n] = torch.arange(n, dtype=torch.int32, device=rows.device)
+        tab = _ident_tables[key] = (t, ld)
+    t, ld = tab
+    return F_.SparseConv.apply(rows, conv.weight, t, ld, n, t, ld, n, F_.CONV_TRANSPOSE_W, 0)
 
 
-def _bn3d_relu(bn, rows):
+def _bn3d_relu(bn, rows, tracked=None):
     """nn.BatchNorm3d + ReLU on channel-last rows (statistics over all B*V voxels, like BatchNorm3d)."""
     y = F_.BatchNormLeaky.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                 1.0 - bn.momentum, bn.training, 0.0)
     if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if tracked is None:
+            bn.num_batches_tracked.add_(1)
+        else:
+            tracked.append(bn.num_batches_tracked)      # the caller advances all its counters in ONE launch
     return y
 
 

@@ -242,13 +242,15 @@ class BatchNormLeaky(Function):
         dy = _f32c(dy)
         rt = runtime(x.device)
         dx = torch.empty_like(x)
-        dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        # two tensors (not two rows of one): autograd can hand them to the parameters' .grad without cloning
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
         wsb = _ws_bytes('sgnn_bn_ws_bytes', 0, c)
         ws = rt.workspace(wsb)
         _lib.call('sgnn_bn_bwd', ptr(x), ptr(dy), n, c, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
-                  int(training), leak, ptr(dx), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), wsb)
-        dgamma = dgb[0] if gamma is not None else None
-        dbeta = dgb[1] if beta is not None else None
+                  int(training), leak, ptr(dx), ptr(dg), ptr(db), ptr(ws), wsb)
+        dgamma = dg if gamma is not None else None
+        dbeta = db if beta is not None else None
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -143,16 +143,6 @@ def runtime(device=None):
     return rt
 
 
-# Opt-in tile kernel (conv.hip: k_conv_tile): levels with at least SGNN_TILE_MIN_ROWS rows get a tile index and their
-# 16->16 3x3x3 layers run from LDS-staged unique rows.  Off by default (-1): measured on MI355X at N = 366 k it is
-# 62 us against 73 us for the gather kernel stand-alone, but inside the training step the index build (50 us per level)
-# and the contention of its 512 persistent 77 KiB workgroups with the weight-gradient lane cost more than that
-# (9.22 vs 9.00 ms/step, scripts/ab_tile.sh).
-TILE_MIN_ROWS = int(os.environ.get('SGNN_TILE_MIN_ROWS', '-1'))
-if TILE_MIN_ROWS < 0:
-    TILE_MIN_ROWS = 1 << 62
-
-
 # 3x3x3 rulebooks of levels with at least DENSE_RULEBOOK_MIN_ROWS rows whose spatial size is known (levels registered
 # in a Metadata) are built through a dense index volume instead of hash probes (grid_rules.hip: k_rulebook_subm3_vol;
 # identical tables).  Below that the three small launches of the dense path cost more than the probes save.
@@ -180,7 +170,6 @@ class Grid(object):
         self.device = coords32.device
         self.keys, self.vals, self.cap = keys, vals, cap
         self._nbr = None
-        self._tile = None
         self.dims = None       # spatial size (z, y, x) of the level once a Metadata registers the grid
         self.ld = _round_up(max(self.n, 1), 256)   # table leading dimension (conv kernels: multiple of 256)
 
@@ -218,17 +207,6 @@ class Grid(object):
                 _lib.call('sgnn_rulebook_subm3', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, ptr(self._nbr),
                           self.ld, ptr(self.cnt))
         return self._nbr
-
-    def tile_index(self):
-        """Tile index of the 3x3x3 table (sgnn_tile_index: unique rows + 16-bit local slots per 128-row tile) for the
-        LDS-staged convolution kernel; None below TILE_MIN_ROWS, where the small / gather kernels are used."""
-        if self.n < TILE_MIN_ROWS or self.cnt is not None:
-            return None
-        if self._tile is None:
-            nbr = self.subm_table()
-            self._tile = torch.empty(_lib.query('sgnn_tile_index_bytes', self.ld), dtype=torch.uint8, device=self.device)
-            _lib.call('sgnn_tile_index', ptr(nbr), self.ld, ptr(self._tile))
-        return self._tile
 
     def locations_i64(self):
         out = torch.empty(self.n, 4, dtype=torch.int64, device=self.device)

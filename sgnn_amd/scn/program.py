@@ -277,7 +277,6 @@ class _ProgramFn(Function):
         for name, cid in prog.class_ids.items():
             lev_n[cid] = run.extra_rows[name]
         nbr = [0] * prog.n_classes
-        tile = [0] * prog.n_classes
         # capacity mode: device row count per rows class (0 = lev_n is exact); lev_n then holds the capacities
         cnts = [0] * prog.n_classes
         for l, g in enumerate(run.grids):
@@ -287,20 +286,15 @@ class _ProgramFn(Function):
             c = run.extra_cnt.get(name)
             if c is not None:
                 cnts[cid] = c.data_ptr()
-        run.tile_hold = []
         for l in prog.subm_levels:
             nbr[l] = run.grids[l].subm_table().data_ptr()
-            t = run.grids[l].tile_index()
-            if t is not None:
-                run.tile_hold.append(t)
-                tile[l] = t.data_ptr()
         pad = [0] * (prog.n_classes - len(run.downs))
         children = [d.children.data_ptr() for d in run.downs] + pad
         ptable = [d.ptable.data_ptr() for d in run.downs] + pad
         parent = [d.parent.data_ptr() if d.parent.numel() else 0 for d in run.downs] + pad
         run.lev_n, run.lev_ld = lev_n, lev_ld
         prog.last_lev_n = lev_n.copy()          # rows (capacity mode: capacities) per class of the latest run (bench accounting)
-        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, tile, cnts)]
+        run.tabs = [_ptr_array(v) for v in (nbr, children, ptable, parent, cnts)]
         run.pptr = _ptr_array([0 if p is None else p.data_ptr() for p in params])
         run.eptr = _ptr_array([t.data_ptr() for t in ext])
         run.iptr = _ptr_array([t.data_ptr() for t in run.idx] + [0])
@@ -320,7 +314,7 @@ class _ProgramFn(Function):
         ws = rt.workspace(wsb)
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, run.tabs[5].ctypes.data, ncls,
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
                   run.pptr.ctypes.data, len(params),
                   run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), total,
                   keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
@@ -392,7 +386,7 @@ class _ProgramFn(Function):
         rt.side_lane(run.wsb)
         _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, run.tabs[5].ctypes.data, ncls,
+                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
                   run.pptr.ctypes.data, gp.ctypes.data,
                   len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
                   arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, run.keep.ctypes.data,

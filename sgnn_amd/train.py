@@ -566,8 +566,12 @@ class FlatAdam(object):
             for p in ps:
                 n = p.numel()
                 if steps[t] > 0:
-                    state[i] = {'step': torch.tensor(float(steps[t])), 'exp_avg': self.flat_m[o:o + n].view_as(p).clone(),
-                                'exp_avg_sq': self.flat_v[o:o + n].view_as(p).clone()}
+                    # (dense convolutions store (K, Cin, Cout): checkpoints carry the reference's layout)
+                    conv = getattr(p, '_sgnn_dense', None)
+                    ea, es = self.flat_m[o:o + n].view_as(p), self.flat_v[o:o + n].view_as(p)
+                    state[i] = {'step': torch.tensor(float(steps[t])),
+                                'exp_avg': conv.to_torch(ea) if conv is not None else ea.clone(),
+                                'exp_avg_sq': conv.to_torch(es) if conv is not None else es.clone()}
                 i += 1
                 o += n
         group = {'lr': self.param_groups[0]['lr'], 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
@@ -588,8 +592,12 @@ class FlatAdam(object):
                 n = p.numel()
                 st = sd['state'].get(i)
                 if st is not None:
-                    self.flat_m[o:o + n].copy_(st['exp_avg'].reshape(-1))
-                    self.flat_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    conv = getattr(p, '_sgnn_dense', None)
+                    ea, es = st['exp_avg'], st['exp_avg_sq']
+                    if conv is not None and ea.dim() == 5:
+                        ea, es = conv.to_native(ea), conv.to_native(es)
+                    self.flat_m[o:o + n].copy_(ea.reshape(-1))
+                    self.flat_v[o:o + n].copy_(es.reshape(-1))
                     steps[t] = max(steps[t], float(st['step']))
                 i += 1
                 o += n

@@ -17,6 +17,7 @@ import scn_oracle as oscn
 import model_oracle as mo
 from util import random_sites, param_fill, copy_params
 from sgnn_amd import synth
+from sgnn_amd.model import named_gradients
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -256,9 +257,9 @@ def test_config1_model_loss_and_gradients_bs4():
     report('configs[1] 64^3 bs4 loss: HIP %.7f  oracle fp32 %.7f  fp64 %.7f' % (float(loss), l32, l64))
     assert abs(float(loss) - l64) <= max(1e-4 * abs(l64), 2 * abs(l32 - l64))
     worst, ratios = (0.0, ''), []
-    for name, p in hm.named_parameters():
+    for name, gh in named_gradients(hm).items():      # reference layout
         g64, g32 = res['f64_grads'][name], res['f32_grads'][name]
-        gh = p.grad.detach().cpu().double()
+        gh = gh.detach().cpu().double()
         scale = float(g64.abs().max()) + 1e-30
         eh, eo = float((gh - g64).abs().max()) / scale, float((g32 - g64).abs().max()) / scale
         worst = max(worst, (eh, name))

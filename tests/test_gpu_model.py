@@ -11,6 +11,7 @@ import torch
 import model_oracle as mo
 from util import param_fill
 from sgnn_amd import synth
+from sgnn_amd.model import named_gradients
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -87,16 +88,16 @@ def test_hip_model_matches_reference_golden(name):
                                   locs.cuda(), True, known)
     loss.backward()
     assert abs(loss.item() - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss'])))
-    params = dict(m.named_parameters())
+    grads = named_gradients(m)            # reference layout (dense convolutions store (K, Cin, Cout))
     for n, a in zip(g['grad_names'], g['grad_abssum']):
-        gr = params[str(n)].grad
+        gr = grads[str(n)]
         got = 0.0 if gr is None else gr.double().abs().sum().item()
         # 5 %: fp32 evaluations of a ReLU network differ at the per-cent level on parameter gradients (mask
         # flips, see test_hip_model_vs_oracle_fresh_inputs_all_grads); the fixture is the reference's fp32 run
         assert abs(got - a) <= 5e-2 * max(1.0, a), (str(n), got, a)
     for k in g.files:
         if k.startswith('grad::'):
-            gr = params[k[6:]].grad.cpu().numpy()
+            gr = grads[k[6:]].cpu().numpy()
             assert np.abs(gr - g[k]).max() <= 5e-2 * max(1.0, np.abs(g[k]).max()), k
         if k.startswith('buf::'):
             assert np.abs(dict(m.named_buffers())[k[5:]].cpu().numpy() - g[k]).max() < 1e-5, k
@@ -137,12 +138,12 @@ def test_hip_model_vs_oracle_fresh_inputs_all_grads():
     check_levels(hocc, hsdf, [(o[0].numpy(), o[1].detach().numpy()) for o in oocc],
                  (osdf[0].numpy(), osdf[1].detach().numpy()))
     assert abs(hloss.item() - l64) < 1e-5 * max(1.0, abs(l64))
-    hp, p32 = dict(hm.named_parameters()), dict(o32.named_parameters())
+    hp, p32 = named_gradients(hm), dict(o32.named_parameters())
     e_hip, e_cpu = [], []
     for n, p in o64.named_parameters():
-        assert p.grad is not None and hp[n].grad is not None, n
+        assert p.grad is not None and hp[n] is not None, n
         scale = max(1e-12, p.grad.abs().max().item())
-        e_hip.append((p.grad - hp[n].grad.cpu().double()).abs().max().item() / scale)
+        e_hip.append((p.grad - hp[n].cpu().double()).abs().max().item() / scale)
         e_cpu.append((p.grad - p32[n].grad.double()).abs().max().item() / scale)
     e_hip, e_cpu = np.array(e_hip), np.array(e_cpu)
     assert np.median(e_hip) <= 1.5 * np.median(e_cpu) + 1e-4, (np.median(e_hip), np.median(e_cpu))

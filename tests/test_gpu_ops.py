@@ -225,61 +225,6 @@ def test_lds_window_rulebook_equals_global_probe_rulebook(order):
 
 
 @pytest.mark.parametrize('order', ['raster', 'shuffled', 'children'])
-@pytest.mark.parametrize('cin,cout', [(16, 16), (8, 12), (12, 8), (12, 16)])
-def test_tile_conv_equals_gather_conv(order, cin, cout):
-    """k_conv_tile (unique rows of a 128-row tile staged through LDS, 16-bit local slots from sgnn_tile_index) forms
-    the same products in the same order as the gather kernel: bit-identical outputs, forward and flipped/transposed
-    (the data-gradient call), with the residual addend and the BatchNorm statistics partials.  'shuffled' has no
-    locality (tiles overflow the 768-row stage: cnt < 0 -> the int32-table path inside the tile kernel)."""
-    import ctypes
-    from sgnn_amd import synth, _lib
-    from sgnn_amd.scn import functions as F_
-    from sgnn_amd.scn.metadata import Grid, coords_from_locs
-    lib = _lib.load()
-    dev = torch.device('cuda')
-    locs = synth.make_batch(8, (64, 64, 64), cfg=2)['input'][0]
-    if order == 'shuffled':
-        locs = locs[torch.randperm(locs.shape[0], generator=torch.Generator().manual_seed(0))]
-    coords = coords_from_locs(locs, dev)
-    if order == 'children':
-        coords = F_.expand8_coords(coords[: coords.shape[0] // 4])
-    g = Grid(coords)
-    assert g.n >= 45000          # large enough for the 256-row gather kernel (what the tile kernel replaces)
-    tab = g.subm_table()
-    index = torch.empty(_lib.query('sgnn_tile_index_bytes', g.ld), dtype=torch.uint8, device=dev)
-    _lib.call('sgnn_tile_index', tab.data_ptr(), g.ld, index.data_ptr())
-    cnt = index[: 4 * (g.ld // 128)].view(torch.int32)[: (g.n + 127) // 128]
-    if order == 'shuffled':
-        assert int((cnt < 0).sum()) > 0
-    else:
-        assert int((cnt < 0).sum()) == 0 and int(cnt.max()) <= 768
-    gen = torch.Generator(device='cuda').manual_seed(1)
-    x = torch.randn(g.n, cin, device=dev, generator=gen)
-    w = torch.randn(27, cin, cout, device=dev, generator=gen) * 0.2
-    for flags, (ci, co) in ((0, (cin, cout)), (3, (cout, cin))):
-        xin = x if flags == 0 else torch.randn(g.n, ci, device=dev, generator=gen)
-        ref = torch.empty(g.n, co, device=dev)
-        _lib.call('sgnn_conv_fwd', xin.data_ptr(), g.n, ci, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, co,
-                  ref.data_ptr(), flags, 0)
-        out = torch.full((g.n, co), float('nan'), device=dev)
-        _lib.call('sgnn_conv_fwd_tiled', xin.data_ptr(), g.n, ci, w.data_ptr(), tab.data_ptr(), g.ld, g.n, co,
-                  out.data_ptr(), flags, index.data_ptr())
-        assert torch.equal(out, ref), (order, flags, float((out - ref).abs().max()))
-    # switched off: the same entry point falls back to the gather kernel
-    prev = lib.sgnn_conv_set_tiled(0)
-    try:
-        out = torch.empty(g.n, cout, device=dev)
-        _lib.call('sgnn_conv_fwd_tiled', x.data_ptr(), g.n, cin, w.data_ptr(), tab.data_ptr(), g.ld, g.n, cout,
-                  out.data_ptr(), 0, index.data_ptr())
-    finally:
-        lib.sgnn_conv_set_tiled(prev)
-    ref = torch.empty(g.n, cout, device=dev)
-    _lib.call('sgnn_conv_fwd', x.data_ptr(), g.n, cin, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, cout,
-              ref.data_ptr(), 0, 0)
-    assert torch.equal(out, ref)
-
-
-@pytest.mark.parametrize('order', ['raster', 'shuffled', 'children'])
 @pytest.mark.parametrize('volume_blocks', [8, 1, 0])
 def test_dense_volume_rulebook_equals_hash_rulebook(order, volume_blocks):
     """sgnn_rulebook_subm3_dense (neighbours read from a dense index volume) must produce the hash rulebook's table for

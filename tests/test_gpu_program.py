@@ -185,50 +185,6 @@ def test_fused_targets_equal_tensor_op_targets(dims, masking, wgeo):
         assert w is None
 
 
-def test_program_with_tile_kernel_equals_gather_kernel():
-    """The opt-in tile kernel inside the executor (SGNN_TILE_MIN_ROWS: levels with a tile index run k_conv_tile for
-    the 16->16 layers, forward and data gradient): the convolutions are bit-identical, only the BatchNorm statistics
-    partials are cut at 128-row instead of 256-row boundaries (fp64), so outputs and gradients agree to rounding."""
-    import sgnn_amd.scn as scn
-    from sgnn_amd.scn import program as P, metadata as MD
-    nf = 16
-    torch.manual_seed(3)
-    chain = [scn.SubmanifoldConvolution(3, 4, nf, 3, False),
-             scn.FullyConvolutionalNet(3, reps=1, nPlanes=[nf, nf, nf], residual_blocks=True),
-             scn.BatchNormReLU(nf * 3)]
-    for m in chain:
-        m.cuda().train()
-    prog = P.compile_or_none(chain, 4)
-    assert prog is not None
-    locs = synth.make_batch(8, (64, 64, 64), cfg=2)['input'][0].cuda()
-    assert locs.shape[0] >= 45000
-    feats = torch.randn(locs.shape[0], 4, device='cuda')
-    gout = None
-    res = []
-    for min_rows in (1 << 62, 45000):
-        prev = MD.TILE_MIN_ROWS
-        MD.TILE_MIN_ROWS = min_rows
-        try:
-            x = feats.clone().requires_grad_(True)
-            x0 = scn.InputLayer(3, (64, 64, 64), mode=0)([locs, x])
-            assert (x0.grid().tile_index() is not None) == (min_rows == 45000)
-            outs, _, _ = P.run_program(prog, x0, True)
-            if gout is None:
-                gout = torch.randn_like(outs[0])
-            for p in prog_params(chain):
-                p.grad = None
-            outs[0].backward(gout)
-            res.append((outs[0].detach().clone(), x.grad.clone(), [p.grad.clone() for p in prog_params(chain)]))
-        finally:
-            MD.TILE_MIN_ROWS = prev
-    (ya, ga, pa), (yb, gb, pb) = res
-    scale = float(ya.abs().max())
-    assert float((ya - yb).abs().max()) <= 2e-5 * scale
-    assert float((ga - gb).abs().max()) <= 1e-3 * float(ga.abs().max())
-    for a, b in zip(pa, pb):
-        assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 1e-6
-
-
 def prog_params(chain):
     return [p for m in chain for p in m.parameters()]
 

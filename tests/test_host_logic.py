@@ -233,10 +233,6 @@ def test_host_side_size_queries_of_the_c_abi():
     with them, so their formulas are part of the contract (include/sgnn_hip.h)."""
     from sgnn_amd import _lib
     al = lambda v: (v + 255) // 256 * 256
-    for ld in (256, 1024, 366336):
-        tiles = ld // 128
-        assert _lib.query('sgnn_tile_index_bytes', ld) == al(4 * tiles) + al(4 * 768 * tiles) + al(2 * 32 * 128 * tiles)
-    assert _lib.query('sgnn_tile_index_bytes', 0) == 0
     # a plain (gather-kernel) launch: one statistics partial per 256-row workgroup above ~40 k rows, per 16 rows below
     assert _lib.query('sgnn_conv_stats_blocks', 366085) == (366085 + 255) // 256
     assert _lib.query('sgnn_conv_stats_blocks', 1000) == (1000 + 15) // 16

@@ -441,11 +441,16 @@ int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, c
  * setting.
  * ------------------------------------------------------------------------- */
 int sgnn_prog_set_fusion(int on);
+/* mode 0: floats of the gradient arena sgnn_prog_backward needs (buffers + per-op areas + backward scratch);
+ * mode 1: floats of the arena sgnn_prog_forward needs (buffers + per-op areas);
+ * mode 2: the same for an INFERENCE call (sgnn_prog_forward with training = 2): no backward pass may follow, so a
+ *         buffer's storage is reused once its last reader has run — the arena is the high-water mark of the live set,
+ *         3-4x smaller for a U-Net stage (whole-scene inference, BASELINE configs[3]). */
 int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                               const int64_t *lev_n, int nlev, const int32_t *keep);
+                               const int64_t *lev_n, int nlev, const int32_t *keep, int mode);
 int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
 int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                const int64_t *lev_n, int nlev, const int32_t *keep, int b);
+                                const int64_t *lev_n, int nlev, const int32_t *keep, int infer, int b);
 int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,

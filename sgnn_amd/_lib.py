@@ -87,9 +87,9 @@ PROTOTYPES = {
     'sgnn_loss_levels_bwd': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'sgnn_loss_combine_bwd': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
-    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    'sgnn_prog_arena_floats': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
-    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32]),
+    'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
     'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,

@@ -9,6 +9,7 @@
 // host-bound (every microsecond of host time shows up in the step time, profiles/r02_host_bound.txt): one native call
 // per stage and direction replaces ~12 Python autograd nodes and their tensor allocations.
 // Host-side code only: no kernels here.
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -161,14 +162,112 @@ void make_plan(const View &v, const int32_t *keep, Plan &P) {
 // gradient + its split data-gradient rows]
 struct Layout {
   std::vector<int64_t> buf_off, buf_floats, aux_off;
-  int64_t max_buf = 0, total = 0, scratch0 = 0, scratch1 = 0, bextra = 0;
+  int64_t max_buf = 0, total = 0, fwd_total = 0, scratch0 = 0, scratch1 = 0, bextra = 0;
 };
 
-int make_layout(const View &v, const Plan &P, Layout &L) {
+// Inference layout (no backward pass will read the arena): a buffer's storage is handed to later buffers once its last
+// reader has run.  Storage roots are allocated at the first op that writes into them (an in-place JoinTable's inputs
+// write into the join buffer), released after the last op that touches them, outputs (`keep`) never; first-fit over an
+// offset-ordered free list, so the arena is the high-water mark of the live set instead of the sum of all buffers —
+// 3-4x smaller for a FullyConvolutionalNet stage (what bounds whole-scene inference, BASELINE configs[3]).
+int make_layout_infer(const View &v, const Plan &P, const int32_t *keep, Layout &L) {
+  const int never = v.nops + 1;
+  std::vector<int> first(v.nbuf, never), last(v.nbuf, -1);
+  auto touch = [&](int b, int i) {
+    if (b < v.n_ext || b >= v.nbuf) return;
+    const int r = P.root[b];
+    if (i < first[r]) first[r] = i;
+    if (i > last[r]) last[r] = i;
+  };
+  for (int i = 0; i < v.nops; ++i) {
+    const int32_t *o = v.ops + OPW * i;
+    touch(o[1], i);
+    if (o[0] == OP_ADD || o[0] == OP_JOIN || o[0] == OP_CONCAT_IN) touch(o[2], i);
+    if (o[0] == OP_CONCAT_IN) touch(o[8], i);
+    if (P.add_dst[i] >= 0) touch(P.add_dst[i], i);   // fused AddTable: the convolution writes the sum buffer itself
+    else touch(o[3], i);
+  }
+  for (int b = v.n_ext; b < v.nbuf; ++b)
+    if (keep && keep[b]) last[P.root[b]] = never;
+  int64_t off = 0;
+  for (int i = 0; i < v.nops; ++i) {   // per-op areas first: small and alive for the whole call
+    const int32_t *o = v.ops + OPW * i;
+    if (o[0] == OP_BN) {
+      L.aux_off[i] = off;
+      off += round64(2 * (int64_t)o[6]);
+    } else if (o[0] == OP_EXPAND) {
+      L.aux_off[i] = off;
+      off += round64(64 * (int64_t)o[6] * o[7]);
+    }
+  }
+  std::vector<std::pair<int64_t, int64_t>> free_list;   // (offset, floats), ordered by offset, neighbours merged
+  int64_t top = off;
+  auto release = [&](int64_t o, int64_t n) {
+    if (n <= 0) return;
+    size_t k = 0;
+    while (k < free_list.size() && free_list[k].first < o) ++k;
+    free_list.insert(free_list.begin() + k, std::make_pair(o, n));
+    if (k + 1 < free_list.size() && free_list[k].first + free_list[k].second == free_list[k + 1].first) {
+      free_list[k].second += free_list[k + 1].second;
+      free_list.erase(free_list.begin() + k + 1);
+    }
+    if (k > 0 && free_list[k - 1].first + free_list[k - 1].second == free_list[k].first) {
+      free_list[k - 1].second += free_list[k].second;
+      free_list.erase(free_list.begin() + k);
+    }
+  };
+  auto take = [&](int64_t n) -> int64_t {
+    if (n <= 0) return 0;
+    size_t best = free_list.size();
+    for (size_t k = 0; k < free_list.size(); ++k)
+      if (free_list[k].second >= n && (best == free_list.size() || free_list[k].second < free_list[best].second)) best = k;
+    if (best < free_list.size()) {
+      const int64_t o = free_list[best].first;
+      free_list[best].first += n;
+      free_list[best].second -= n;
+      if (free_list[best].second == 0) free_list.erase(free_list.begin() + best);
+      return o;
+    }
+    if (!free_list.empty() && free_list.back().first + free_list.back().second == top) {   // grow the block at the top
+      const int64_t o = free_list.back().first;
+      free_list.pop_back();
+      top = o + n;
+      return o;
+    }
+    const int64_t o = top;
+    top += n;
+    return o;
+  };
+  for (int i = 0; i < v.nops; ++i) {
+    for (int b = v.n_ext; b < v.nbuf; ++b)      // everything whose last toucher ran before this op
+      if (P.root[b] == b && L.buf_off[b] >= 0 && last[b] == i - 1) release(L.buf_off[b], round64(L.buf_floats[b]));
+    for (int b = v.n_ext; b < v.nbuf; ++b)
+      if (P.root[b] == b && first[b] == i) L.buf_off[b] = take(round64(L.buf_floats[b]));
+  }
+  for (int b = v.n_ext; b < v.nbuf; ++b) {
+    if (P.root[b] == b && L.buf_off[b] < 0) L.buf_off[b] = 0;   // never touched (a fused-away convolution output)
+  }
+  for (int b = v.n_ext; b < v.nbuf; ++b)
+    if (P.root[b] != b) L.buf_off[b] = L.buf_off[P.root[b]] + P.col[b];
+  L.fwd_total = L.total = top;
+  L.scratch0 = L.scratch1 = L.bextra = top;
+  return 0;
+}
+
+int make_layout(const View &v, const Plan &P, Layout &L, bool infer = false, const int32_t *keep = nullptr) {
   L.buf_off.assign(v.nbuf, -1);
   L.buf_floats.resize(v.nbuf);
   L.aux_off.assign(v.nops, -1);
   int64_t off = 0;
+  if (infer) {
+    for (int b = 0; b < v.nbuf; ++b) {
+      const int lev = v.bufs[2 * b], ch = v.bufs[2 * b + 1];
+      if (lev < 0 || lev >= v.nlev || ch < 1) return -1;
+      L.buf_floats[b] = v.lev_n[lev] * (int64_t)(P.root[b] == b ? P.ld[b] : ch);
+      if (L.buf_floats[b] > L.max_buf) L.max_buf = L.buf_floats[b];
+    }
+    return make_layout_infer(v, P, keep, L);
+  }
   for (int b = 0; b < v.nbuf; ++b) {
     const int lev = v.bufs[2 * b], ch = v.bufs[2 * b + 1];
     if (lev < 0 || lev >= v.nlev || ch < 1) return -1;
@@ -193,6 +292,7 @@ int make_layout(const View &v, const Plan &P, Layout &L) {
       if (need > bextra) bextra = need;
     }
   }
+  L.fwd_total = off;       // what a forward pass touches: buffers + per-op areas
   L.scratch0 = off;
   off += round64(L.max_buf);
   L.scratch1 = off;
@@ -260,11 +360,17 @@ struct SideLane {
   int64_t ws_bytes = 0;
   hipEvent_t fork = nullptr, join = nullptr;
 } g_side;
+// The lane (its workspace and its two events) is one per process = one per GPU.  A backward call holds g_side_mu while
+// it issues work; a second host thread that calls sgnn_prog_backward at the same time does not get the lane (its weight
+// gradients run on its own stream and workspace — correct, just not overlapped), and sgnn_prog_set_side_stream waits
+// for a call in flight before it swaps the lane.
+std::mutex g_side_mu;
 
 }  // namespace
 
 // stream2 == NULL switches the lane off.  ws2 must not be used by anything else while a backward call is in flight.
 SGNN_EXPORT int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_bytes) {
+  std::lock_guard<std::mutex> hold(g_side_mu);
   if (stream2 && !g_side.fork) {
     SGNN_HIP_TRY(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
     SGNN_HIP_TRY(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
@@ -287,14 +393,16 @@ SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
     if (rc_ != SGNN_OK) return rc_; \
   } while (0)
 
+// mode 0: the gradient arena of sgnn_prog_backward (buffers + per-op areas + backward scratch); 1: the arena of
+// sgnn_prog_forward (buffers + per-op areas); 2: the forward arena of an inference call (training = 2: liveness-packed)
 SGNN_EXPORT int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                           const int64_t *lev_n, int nlev, const int32_t *keep) {
+                                           const int64_t *lev_n, int nlev, const int32_t *keep, int mode) {
   View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
   Plan P;
   make_plan(v, keep, P);
   Layout L;
-  if (make_layout(v, P, L) != 0) return -1;
-  return L.total;
+  if (mode < 0 || mode > 2 || make_layout(v, P, L, mode == 2, keep) != 0) return -1;
+  return mode == 0 ? L.total : L.fwd_total;
 }
 
 SGNN_EXPORT int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev) {
@@ -304,12 +412,12 @@ SGNN_EXPORT int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64
 
 // float offset of buffer `b` inside an arena (so the host layer can hand out views); -1 for externals
 SGNN_EXPORT int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
-                                            const int64_t *lev_n, int nlev, const int32_t *keep, int b) {
+                                            const int64_t *lev_n, int nlev, const int32_t *keep, int infer, int b) {
   View v{ops, nullptr, nops, bufs, nbuf, n_ext, lev_n, nullptr, nullptr, nullptr, nullptr, nullptr, nlev};
   Plan P;
   make_plan(v, keep, P);
   Layout L;
-  if (make_layout(v, P, L) != 0 || b < 0 || b >= nbuf) return -1;
+  if (make_layout(v, P, L, infer != 0, keep) != 0 || b < 0 || b >= nbuf) return -1;
   return P.root[b] == b ? L.buf_off[b] : -1;      // buffers the caller keeps are never views
 }
 
@@ -326,10 +434,12 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
   Plan PL;
   make_plan(v, keep, PL);
   Layout L;
-  SGNN_CHECK_ARG(make_layout(v, PL, L) == 0);
-  if (arena_floats < L.total) {
+  const bool infer = (training & 2) != 0;     // inference layout: no backward call may follow
+  training &= 1;
+  SGNN_CHECK_ARG(make_layout(v, PL, L, infer, keep) == 0);
+  if (arena_floats < L.fwd_total) {
     sgnn_set_error("sgnn_prog_forward: arena too small (%lld < %lld floats)", (long long)arena_floats,
-                   (long long)L.total);
+                   (long long)L.fwd_total);
     return SGNN_ENOWS;
   }
   if (ws_bytes < ws_need(v)) {
@@ -526,7 +636,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   };
   auto wants = [&](int b) { return b >= n_ext || gext[b] != nullptr; };
   // dW launches go to the side lane when one is configured and its workspace is big enough
-  const bool side = g_side.stream && g_side.stream != hs && g_side.ws && g_side.ws_bytes >= dw_ws_need(v);
+  std::unique_lock<std::mutex> lane_lock(g_side_mu, std::try_to_lock);
+  const bool side = lane_lock.owns_lock() && g_side.stream && g_side.stream != hs && g_side.ws &&
+                    g_side.ws_bytes >= dw_ws_need(v);
   bool forked = false;
   auto dw_lane = [&]() -> hipStream_t {
     if (!side) return hs;

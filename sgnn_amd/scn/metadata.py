@@ -78,8 +78,9 @@ class _Runtime(object):
         self.raise_status(int(host[1]))
         return host
 
-    def raise_status(self, word):
-        """Turn a copy of the status word into the input error it stands for (and clear the device word)."""
+    def raise_status(self, word, where=None):
+        """Turn a copy of the status word into the input error it stands for (and clear the device word).  `where`:
+        which step / batch the word belongs to when it is looked at later than it was written (deferred checks)."""
         status = int(word) & 0xFFFFFFFF
         if status:
             self.state[1] = 0
@@ -92,7 +93,7 @@ class _Runtime(object):
                 raise CapacityOverflow('capacity mode: a level produced more rows than its capacity (step discarded)')
             if status & 4:
                 msgs.append('capacity overflow')
-            raise _lib.SgnnError('; '.join(msgs))
+            raise _lib.SgnnError('; '.join(msgs) + (' [%s]' % where if where else ''))
 
 
 class CapacityOverflow(_lib.SgnnError):

@@ -32,13 +32,33 @@ ENABLED = True   # False: run the containers layer by layer (one autograd node p
 # same program (fine for a training loop, wrong for code that keeps two forward results alive).
 PERSISTENT_ARENAS = False
 _garenas = {}
+_iarenas = {}      # inference: one forward arena per device, shared by all programs
 
 
-def _arena(owner, key, floats, dev):
+ARENA_SHRINK_AFTER = 32     # calls in a row that used less than half of a persistent arena before it is re-allocated
+
+
+def _arena(owner, key, floats, dev, headroom=1.25):
+    """Grow-only (x headroom) persistent arena that also SHRINKS: after ARENA_SHRINK_AFTER consecutive calls that needed
+    less than half of it (a curriculum switched a level off, a large scene was followed by small ones) it is
+    re-allocated at the size now needed — level sizes that merely fluctuate never trigger it."""
     t = owner.get(key)
-    if t is None or t.numel() < floats or t.device != dev:
-        t = owner[key] = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=dev)
+    idle = owner.get((key, 'idle'), 0)
+    idle = idle + 1 if (t is not None and floats * 2 < t.numel()) else 0
+    if t is None or t.numel() < floats or t.device != dev or idle >= ARENA_SHRINK_AFTER:
+        owner[key] = None
+        del t
+        t = owner[key] = torch.empty(int(floats * headroom) + 1024, dtype=torch.float32, device=dev)
+        idle = 0
+    owner[(key, 'idle')] = idle
     return t[:floats]
+
+
+def arena_bytes():
+    """Bytes currently held by persistent arenas: (forward arenas of all programs are reported by their owners, see
+    memory_report) gradient arenas, inference arenas."""
+    f = lambda d: sum(4 * t.numel() for k, t in d.items() if torch.is_tensor(t))
+    return {'gradient': f(_garenas), 'inference': f(_iarenas)}
 
 
 class Unsupported(Exception):
@@ -303,30 +323,40 @@ class _ProgramFn(Function):
         keep = np.zeros(nbuf, dtype=np.int32)          # buffers read after the call: never fused away / never views
         keep[run.out_bufs] = 1
         run.keep = keep
-        total = _lib.query('sgnn_prog_arena_floats', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
-                           lev_n.ctypes.data, ncls, keep.ctypes.data)
+        qa = (ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext, lev_n.ctypes.data, ncls, keep.ctypes.data)
+        infer = bool(run.infer)
+        # gradient arena (backward: buffers + scratch) / forward arena (buffers only; liveness-packed for inference)
+        total = _lib.query('sgnn_prog_arena_floats', *qa, 0)
+        fwd_total = _lib.query('sgnn_prog_arena_floats', *qa, 2 if infer else 1)
         wsb = _lib.query('sgnn_prog_ws_bytes', ops.ctypes.data, nops, lev_n.ctypes.data, ncls)
         run.total, run.wsb = total, wsb
-        if PERSISTENT_ARENAS:
-            arena = _arena(prog.__dict__.setdefault('_arenas', {}), 'fwd', total, dev)
+        prog.last_arena_floats = (fwd_total, total)
+        if infer:           # one arena for ALL programs of the device: the outputs are copied out below
+            arena = _arena(_iarenas, str(dev), fwd_total, dev, 1.1)
+        elif PERSISTENT_ARENAS:
+            arena = _arena(prog.__dict__.setdefault('_arenas', {}), 'fwd', fwd_total, dev)
         else:
-            arena = torch.empty(total, dtype=torch.float32, device=dev)
+            arena = torch.empty(fwd_total, dtype=torch.float32, device=dev)
         ws = rt.workspace(wsb)
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                   run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
                   run.pptr.ctypes.data, len(params),
-                  run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), total,
-                  keep.ctypes.data, int(run.training), ws.data_ptr(), wsb)
+                  run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), fwd_total,
+                  keep.ctypes.data, int(run.training) | (2 if infer else 0), ws.data_ptr(), wsb)
         run.offsets = {}
         outs = []
         for b in run.out_bufs:
-            off = _lib.query('sgnn_prog_buffer_offset', ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
-                             lev_n.ctypes.data, ncls, keep.ctypes.data, b)
+            off = _lib.query('sgnn_prog_buffer_offset', *qa, int(infer), b)
             assert off >= 0
             rows, ch = int(lev_n[bufs[b, 0]]), int(bufs[b, 1])
             run.offsets[b] = (off, rows, ch)
-            outs.append(arena[off:off + rows * ch].view(rows, ch))
+            o = arena[off:off + rows * ch].view(rows, ch)
+            # inference: the arena is dropped (or handed to the next program) right away, only the outputs stay
+            outs.append(o.clone() if infer else o)
+        if infer:
+            ctx.run = None
+            return tuple(outs)
         ctx.run = run
         ctx.save_for_backward(arena, *ext, *[p for p in params if p is not None])
         ctx.param_none = [p is None for p in params]
@@ -412,9 +442,12 @@ def run_program(prog, x, training, out_bufs=None, ext=None, idx=(), extra_rows=N
     run.idx = list(idx)
     run.extra_rows = dict(extra_rows or {})
     run.extra_cnt = dict(extra_cnt or {})
+    tensors = [x.features] if ext is None else list(ext)
+    # nothing will ask for a gradient: inference layout (buffers share storage by liveness, outputs copied out)
+    run.infer = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                     for t in list(tensors) + list(prog.tensors())))
     if 'child' in prog.class_ids and 'child' not in run.extra_rows:
         run.extra_rows['child'] = 8 * run.grids[0].n
-    tensors = [x.features] if ext is None else list(ext)
     outs = _ProgramFn.apply(run, *tensors, *prog.tensors())
     return list(outs), run.grids, run.downs
 

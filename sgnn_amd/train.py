@@ -258,12 +258,14 @@ class GeometryPrefetcher(object):
         import time
         t0 = time.perf_counter()
         while len(self.issued) > keep:
-            ev, _plan, status = self.issued.pop(0)
+            ev, _plan, status, index = self.issued.pop(0)
             ev.synchronize()
             if status is not None and int(status[0]):
                 # the training stream has no read-back of its own any more: input errors its kernels flagged during
-                # that step (duplicate / out-of-range sites) surface here, two steps later at most
-                self._rt.raise_status(int(status[0]))
+                # that step (duplicate / out-of-range sites) surface here, two steps later at most — named by the
+                # step they belong to (its optimizer update has already been applied)
+                self._rt.raise_status(int(status[0]), 'raised by train_step call %d of this prefetcher (0-based), %d call(s) '
+                                      'ago; that step\'s parameter update was applied' % (index, self._n - 1 - index))
         self.t_throttle += time.perf_counter() - t0
 
     def _start(self, batch, loss_weights):
@@ -321,7 +323,7 @@ class GeometryPrefetcher(object):
         status.copy_(self._rt.state[1:2], non_blocking=True)       # rides the training stream, no synchronisation
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self.issued.append((ev, plan, status))
+        self.issued.append((ev, plan, status, self._n - 1))
         if not self.threaded and next_batch is not None:
             self._retire(1)
             self.pending = self._start(next_batch, loss_weights)
@@ -788,13 +790,14 @@ class GraphStep(object):
         pin[1:].copy_(self.capacity.counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(rt.device))
-        self.pending.append((ev, pin, batch, loss_weights, self.capacity))
+        self._n_issued = getattr(self, '_n_issued', 0) + 1
+        self.pending.append((ev, pin, batch, loss_weights, self.capacity, self._n_issued - 1))
 
     def _check(self, keep):
         """Retire all but the `keep` newest issued steps; returns the batches whose step overflowed."""
         redo = []
         while len(self.pending) > keep:
-            ev, pin, batch, lw, cap = self.pending.pop(0)
+            ev, pin, batch, lw, cap, index = self.pending.pop(0)
             ev.synchronize()
             word = int(pin[0]) & 0xFFFFFFFF
             if cap is self.capacity:
@@ -803,7 +806,9 @@ class GraphStep(object):
                 redo.append((batch, lw))
             elif word:
                 from .scn.metadata import runtime
-                runtime(self.static['sdf'].device).raise_status(word)
+                runtime(self.static['sdf'].device).raise_status(
+                    word, 'raised by capacity-mode step %d of this GraphStep (0-based), %d step(s) ago; that step\'s '
+                          'parameter update was applied' % (index, self._n_issued - 1 - index))
         return redo
 
     def _capture(self, loss_weights):

@@ -195,12 +195,12 @@ def test_program_planner_turns_join_inputs_into_column_views():
     nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
     lev_n = np.array([1000, 300, 90], dtype=np.int64)[:ncls]
 
-    def plan(keep_bufs):
+    def plan(keep_bufs, mode=1):
         keep = np.zeros(nbuf, dtype=np.int32)
         keep[list(keep_bufs)] = 1
         a = (ops.ctypes.data, nops, bufs.ctypes.data, nbuf, prog.n_ext, lev_n.ctypes.data, ncls, keep.ctypes.data)
-        total = _lib.query('sgnn_prog_arena_floats', *a)
-        return total, [_lib.query('sgnn_prog_buffer_offset', *(a + (b,))) for b in range(nbuf)]
+        total = _lib.query('sgnn_prog_arena_floats', *(a + (mode,)))
+        return total, [_lib.query('sgnn_prog_buffer_offset', *(a + (int(mode == 2), b))) for b in range(nbuf)]
 
     OP_JOIN = 5
     joins = [o for o in ops if o[0] == OP_JOIN]
@@ -226,6 +226,83 @@ def test_program_planner_turns_join_inputs_into_column_views():
     lev_n = lev_n * 2
     total3, _ = plan([prog.out])
     assert abs(total3 - 2 * total) <= 64 * nbuf
+
+
+def test_inference_layout_packs_buffers_by_liveness():
+    """sgnn_prog_arena_floats(mode 2) / sgnn_prog_forward(training = 2): buffers whose live ranges (first writer .. last
+    reader, a JoinTable view's members counted with the joined buffer) do not intersect may share storage, buffers alive
+    at the same op never overlap, the outputs stay to the end; the arena is several times smaller than the training
+    layout of the same program.  Host arithmetic only."""
+    from sgnn_amd import _lib
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.scn import program as P
+    m = GenModel(8, (64,) * 3, 1, 16, 16, 4, True, True, 1, 1)
+    ref = m.refinement[1]
+    for mods, cin in (([ref.p1, ref.p2, ref.p3], ref.nf_in), (list(m.encoder.process_sparse[0].children())[1:], None)):
+        prog = P.compile_or_none(mods, cin) if cin is not None else m.encoder.process_sparse[0].__dict__.get('_prog')
+        if prog is None:
+            continue
+        ops, bufs = prog.ops_np, prog.bufs_np
+        nops, nbuf, ncls, n_ext = ops.shape[0], bufs.shape[0], prog.n_classes, prog.n_ext
+        lev_n = np.array([100000, 27000, 6100, 1500, 800000, 5000][:ncls], dtype=np.int64)
+        keep = np.zeros(nbuf, dtype=np.int32)
+        keep[prog.out] = 1
+        a = (ops.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext, lev_n.ctypes.data, ncls, keep.ctypes.data)
+        train_total = _lib.query('sgnn_prog_arena_floats', *(a + (1,)))
+        total = _lib.query('sgnn_prog_arena_floats', *(a + (2,)))
+        offs = [_lib.query('sgnn_prog_buffer_offset', *(a + (1, b))) for b in range(nbuf)]
+        offs_train = [_lib.query('sgnn_prog_buffer_offset', *(a + (0, b))) for b in range(nbuf)]
+        assert [o >= 0 for o in offs] == [o >= 0 for o in offs_train]       # same views in both layouts
+        # storage owner of every buffer: views (offset -1) belong to the JoinTable output that swallowed them
+        owner = list(range(nbuf))
+        for o in ops:
+            if o[0] == 5:
+                for q in (int(o[1]), int(o[2])):
+                    if q >= n_ext and offs[q] < 0:
+                        owner[q] = int(o[3])
+        def root(b):
+            while owner[b] != b:
+                b = owner[b]
+            return b
+        first, last, fused_away = {}, {}, set()
+        def touch(b, i):
+            if b < n_ext:
+                return
+            r = root(b)
+            first[r] = min(first.get(r, i), i)
+            last[r] = max(last.get(r, i), i)
+        readers = {}
+        for o in ops:
+            for q in ([int(o[1])] + ([int(o[2])] if o[0] in (4, 5, 6) else [])):
+                readers[q] = readers.get(q, 0) + 1
+        for i, o in enumerate(ops):
+            touch(int(o[1]), i) if o[1] >= 0 else None
+            if o[0] in (4, 5, 6) and o[2] >= 0:
+                touch(int(o[2]), i)
+            nxt = ops[i + 1] if i + 1 < nops else None
+            if (o[0] in (0, 1) and nxt is not None and nxt[0] == 4 and int(o[3]) in (int(nxt[1]), int(nxt[2])) and
+                    readers.get(int(o[3])) == 1 and nxt[1] != nxt[2]):
+                touch(int(nxt[3]), i)       # fused AddTable: the convolution stores the sum, its own buffer is never used
+                fused_away.add(int(o[3]))
+            elif o[3] >= 0:
+                touch(int(o[3]), i)
+        for b in fused_away:
+            if first.get(b) == last.get(b):
+                first.pop(b), last.pop(b)
+        last[root(prog.out)] = nops + 1
+        spans = [(offs[b], offs[b] + int(lev_n[bufs[b, 0]]) * int(bufs[b, 1]), first[b], last[b], b)
+                 for b in first if offs[b] >= 0]
+        assert max(e for _, e, _, _, _ in spans) <= total
+        shared = 0
+        for x in range(len(spans)):
+            for y in range(x + 1, len(spans)):
+                s0, e0, f0, l0, b0 = spans[x]
+                s1, e1, f1, l1, b1 = spans[y]
+                if s0 < e1 and s1 < e0:             # same storage: the live ranges must be disjoint
+                    assert l0 < f1 or l1 < f0, 'buffers %d and %d are alive together and overlap' % (b0, b1)
+                    shared += 1
+        assert shared > 0
+        assert total * 3 < train_total * 2, (total, train_total)
 
 
 def test_host_side_size_queries_of_the_c_abi():

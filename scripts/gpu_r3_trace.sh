@@ -7,6 +7,6 @@ export TMPDIR=/tmp; D=/tmp/prof_$TAG; rm -rf $D; ROOT=$(pwd)
 tail -2 $ROOT/gpurun_out/${TAG}_prof.err
 F=$(find $D -name '*kernel_stats.csv' | head -1); T=$(find $D -name '*kernel_trace.csv' | head -1)
 [ -n "$F" ] && cp $F gpurun_out/${TAG}_kernel_stats.csv
-[ -n "$T" ] && python scripts/trace_graph.py $T -2 gpurun_out/${TAG}_step_launches.csv > gpurun_out/${TAG}_trace_summary.txt 2>&1
+[ -n "$T" ] && python scripts/trace_graph.py $T ${WHICH:--9} gpurun_out/${TAG}_step_launches.csv > gpurun_out/${TAG}_trace_summary.txt 2>&1
 head -12 gpurun_out/${TAG}_trace_summary.txt
 head -3 $T

@@ -255,15 +255,17 @@ def test_prefetched_geometry_is_the_same_training_run():
         res.append(([l.item() for l in losses], [p.detach().clone() for p in m.parameters()], syncs, mem))
     a = res[0]
     assert a[2] == 35                            # 5 read-backs per step on the main lane without the prefetcher
-    from sgnn_amd.scn import program as P_
-    assert max(a[3]) - min(a[3]) < 65536, (a[3], P_.PERSISTENT_ARENAS, P_.ENABLED, len(P_._garenas))
+    # live bytes are counted in allocator blocks: a request served from a larger cached block (torch does not split
+    # large-pool blocks for a remainder under 1 MB) moves the figure by up to 1 MB per tensor depending on what earlier
+    # tests left in the cache.  A leak would be >= 1.5 MB per step, i.e. >= 6 MB over the four steps spanned here.
+    assert max(a[3]) - min(a[3]) < (2 << 20), a[3]
     for b in res[1:]:
         assert a[0] == b[0], (a[0], b[0])
         assert all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
         assert b[2] == 0                         # ... none with it
         # no plan may outlive its step by more than the retention window (a plan hung on a tensor its own Grid views
         # is an uncollectable cycle); the kept loss scalars account for 512 bytes per step
-        assert max(b[3]) - min(b[3]) < (1 << 20), b[3]      # a leaked plan is >= 1.5 MB per step here
+        assert max(b[3]) - min(b[3]) < (2 << 20), b[3]      # a leaked plan is >= 1.5 MB per step here (6 MB over the span)
 
 
 def test_input_errors_still_surface_with_the_prefetcher():

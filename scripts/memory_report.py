@@ -45,13 +45,15 @@ def processed(n_in, outs):
 
 
 def run_steps(step, n, sync=True):
-    outs = None
+    """n steps; returns the last step's outputs and the median time of the last (up to) 5 steps in ms."""
+    outs, ts = None, []
     for _ in range(n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs = step()
         torch.cuda.synchronize()
-    return outs, 1e3 * (time.perf_counter() - t0)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return outs, float(np.median(ts[-5:]))
 
 
 if which == 'c1':
@@ -85,8 +87,8 @@ elif which == 'c4':
     m = GenModel(8, (D,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
     opt = make_optimizer(m.parameters())
     torch.cuda.reset_peak_memory_stats()
-    outs, ms = run_steps(lambda: train_step(m, opt, batch, lw), 6)
-    line('configs[4] bs8 128^3 @20%% training, classic eager', n_in, processed(n_in, outs[2]), m, ms)
+    outs, ms = run_steps(lambda: train_step(m, opt, batch, lw), 12)
+    line('configs[4] bs8 128^3 @20 pct training, classic eager', n_in, processed(n_in, outs[2]), m, ms)
     small = to_device(synth.make_batch(1, (D,) * 3, cfg=5, occupancy=0.2, dist='iid'), 'cuda')
     del outs
     outs, ms = run_steps(lambda: train_step(m, opt, small, lw), P_.ARENA_SHRINK_AFTER + 8)

@@ -16,6 +16,9 @@ from .._lib import ptr
 
 
 SIDE_LANE = os.environ.get('SGNN_SIDE_LANE', '1') != '0'     # run dW on a second stream during program backward (sgnn_prog_set_side_stream)
+# HIP stream priority of that lane (0 = default, positive = lower than the training stream, negative = higher): the
+# weight-gradient kernels are off the critical path, the data-gradient chain they overlap is on it
+SIDE_PRIORITY = int(os.environ.get('SGNN_SIDE_PRIORITY', '0'))
 
 
 class _Runtime(object):
@@ -50,7 +53,7 @@ class _Runtime(object):
                 self._side_on = False
             return
         if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_stream = torch.cuda.Stream(device=self.device, priority=SIDE_PRIORITY)
             self._side_ws = None
         if self._side_ws is None or self._side_ws.numel() < nbytes or not getattr(self, '_side_on', False):
             if self._side_ws is None or self._side_ws.numel() < nbytes:

@@ -305,6 +305,39 @@ def test_inference_layout_packs_buffers_by_liveness():
         assert total * 3 < train_total * 2, (total, train_total)
 
 
+def test_dense_conv_keeps_native_layout_and_speaks_the_reference_layout():
+    """model.DenseConv stores (K, Cin, Cout) — what the rulebook kernels read — while state_dict / load_state_dict /
+    named_gradients use nn.Conv3d's (Cout, Cin, k, k, k) and nn.ConvTranspose3d's (Cin, Cout, k, k, k)."""
+    from sgnn_amd.model import DenseConv, GenModel, named_gradients
+    torch.manual_seed(3)
+    for transposed, (cin, cout, k) in ((False, (16, 24, 4)), (True, (64, 32, 4)), (False, (32, 32, 1))):
+        ref = (torch.nn.ConvTranspose3d if transposed else torch.nn.Conv3d)(cin, cout, k, stride=2 if k == 4 else 1,
+                                                                             padding=1 if k == 4 else 0, bias=False)
+        d = DenseConv(cin, cout, k, 2 if k == 4 else 1, 1 if k == 4 else 0, transposed)
+        assert tuple(d.weight.shape) == (k ** 3, cin, cout)
+        assert tuple(d.state_dict()['weight'].shape) == tuple(ref.weight.shape)
+        d.load_state_dict(ref.state_dict())
+        assert torch.equal(d.state_dict()['weight'], ref.weight.detach())
+        # tap (a, b, c) of the torch weight is slice a*k*k + b*k + c of the native one, transposed to (Cin, Cout)
+        a, b, c = (1, 2, 3) if k == 4 else (0, 0, 0)
+        want = ref.weight[:, :, a, b, c] if transposed else ref.weight[:, :, a, b, c].t()
+        assert torch.equal(d.weight[(a * k + b) * k + c], want)
+        assert torch.equal(d.to_native(d.to_torch(d.weight)), d.weight)
+    torch.manual_seed(5)
+    hm = GenModel(8, (32,) * 3, 1, 16, 16, 4, True, True, 1, 1)
+    torch.manual_seed(5)
+    om = mo.GenModel(8, (32,) * 3, 1, 16, 16, 4, True, True, 1, 1)
+    for (k1, v1), (k2, v2) in zip(hm.state_dict().items(), om.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1          # same initialisation stream, same layout on the outside
+    for p in hm.parameters():
+        p.grad = torch.randn_like(p)
+    g = named_gradients(hm)
+    sd = om.state_dict()
+    assert all(tuple(g[n].shape) == tuple(sd[n].shape) for n, _ in om.named_parameters())
+    w = hm.encoder.encode_dense0[0]
+    assert torch.equal(g['encoder.encode_dense0.0.weight'], w.to_torch(w.weight.grad))
+
+
 def test_host_side_size_queries_of_the_c_abi():
     """Workspace / blob size queries are plain host arithmetic (callable without a GPU): the caller sizes its buffers
     with them, so their formulas are part of the contract (include/sgnn_hip.h)."""

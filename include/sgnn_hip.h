@@ -451,13 +451,17 @@ int64_t sgnn_prog_arena_floats(const int32_t *ops, int nops, const int32_t *bufs
 int64_t sgnn_prog_ws_bytes(const int32_t *ops, int nops, const int64_t *lev_n, int nlev);
 int64_t sgnn_prog_buffer_offset(const int32_t *ops, int nops, const int32_t *bufs, int nbuf, int n_ext,
                                 const int64_t *lev_n, int nlev, const int32_t *keep, int infer, int b);
+/* training: 0 = eval, 1 = training (batch statistics), | 2 = inference layout (see sgnn_prog_arena_floats mode 2).
+ * wait_event (hipEvent_t or NULL): the stream waits for it right before the program's first Convolution(2,2) — the
+ * first operation that touches the stride-2 tables and the coarser levels' hash / rulebook / row counts, which the caller
+ * may have built on another stream (they then overlap the level-0 operations in front of it). */
 int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                       const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                       void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,
                       void *const *lev_cnt, int nlev, void *const *params, int nparams,
                       void *const *ext, void *const *idx, int nidx,
-                      float *arena, int64_t arena_floats, const int32_t *keep, int training, void *ws,
-                      int64_t ws_bytes, sgnn_stream_t stream);
+                      float *arena, int64_t arena_floats, const int32_t *keep, int training, void *wait_event,
+                      void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int32_t *bufs, int nbuf, int n_ext,
                        const int64_t *lev_n, const int64_t *lev_ld, void *const *lev_nbr,
                        void *const *lev_children, void *const *lev_ptable, void *const *lev_parent,

@@ -427,7 +427,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
                                   void *const *lev_cnt, int nlev, void *const *params, int nparams,
                                   void *const *ext, void *const *idx,
                                   int nidx, float *arena, int64_t arena_floats, const int32_t *keep, int training,
-                                  void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
+                                  void *wait_event, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(ops && opf && bufs && lev_n && lev_ld && params && arena && nops >= 0 && nbuf >= 1 && nlev >= 1 &&
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || ext));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
@@ -470,6 +470,12 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
     SGNN_CHECK_ARG(type == OP_CONCAT_IN || in0 >= 0);
     const int64_t n = lev_n[lev];
     if (PL.skip[i]) continue;
+    if (type == OP_CONV_DOWN && wait_event) {
+      // the stride-2 tables and everything of the coarser levels (hash, 3x3x3 rulebooks, row counts) may still be in
+      // flight on the caller's pyramid lane: the first Convolution(2,2) is the first operation that touches them
+      SGNN_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_event, 0));
+      wait_event = nullptr;
+    }
     switch (type) {
       case OP_CONV_SUBM:
       case OP_CONV_DOWN: {

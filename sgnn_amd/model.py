@@ -603,6 +603,10 @@ class GenModel(nn.Module):
             res = self._forward_stages(feat_rows, occ_rows, skips, geo, loss_weights, runs, teacher, plans, capacity)
             if res is not None:
                 if capacity is not None:
+                    # a pyramid built on the pyramid lane that no program consumed (a level whose stage did not run) must
+                    # still be joined: the training stream owns every buffer it wrote, and a capture needs all forks closed
+                    from .scn.metadata import join_pyramid_lane
+                    join_pyramid_lane(feat_rows.device)
                     return res
                 if not self.training:     # inference: report input errors (duplicate / out-of-range sites) from THIS call
                     from .scn.metadata import runtime

@@ -8,6 +8,7 @@ torch tensors that back the tables and caches them per (spatial size, filter) li
 import numpy as np
 import os
 import threading
+from contextlib import nullcontext as _nullcontext
 
 import torch
 
@@ -19,6 +20,11 @@ SIDE_LANE = os.environ.get('SGNN_SIDE_LANE', '1') != '0'     # run dW on a secon
 # HIP stream priority of that lane (0 = default, positive = lower than the training stream, negative = higher): the
 # weight-gradient kernels are off the critical path, the data-gradient chain they overlap is on it
 SIDE_PRIORITY = int(os.environ.get('SGNN_SIDE_PRIORITY', '0'))
+# Capacity mode: the stride-2 pyramid of a level (sgnn_down2_chain_tables) and the 3x3x3 rulebooks of its coarse levels
+# are issued on a third stream (scratch lane 2) and joined inside sgnn_prog_forward right before the program's first
+# Convolution(2,2): they overlap the level's hash / rulebook build and its first convolutions instead of preceding them.
+SIDE_PYRAMID = os.environ.get('SGNN_SIDE_PYRAMID', '1') != '0'
+PYRAMID_LANE = 2
 
 
 class _Runtime(object):
@@ -43,6 +49,17 @@ class _Runtime(object):
         if self.ws.numel() < nbytes:
             self.ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
         return self.ws
+
+    def pyramid_stream(self):
+        """Stream of the pyramid lane (see SIDE_PYRAMID); kernels issued there use the scratch of lane PYRAMID_LANE.
+        It IS the weight-gradient lane's stream (idle during the forward pass): a third concurrently active stream was
+        measured to collide with the training stream on one hardware pipe on some runs — both queues then stall
+        40-70 us at every switch (18.8 instead of 6.2 ms per step, profiles/r03t_trace_summary.txt)."""
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device, priority=SIDE_PRIORITY)
+            self._side_ws = None
+        self._pyr_stream = self._side_stream
+        return self._pyr_stream
 
     def side_lane(self, nbytes):
         """Second stream + private workspace for the weight-gradient lane of sgnn_prog_backward (registered with the
@@ -174,6 +191,7 @@ class Grid(object):
         self.device = coords32.device
         self.keys, self.vals, self.cap = keys, vals, cap
         self._nbr = None
+        self.ready = None      # see Down2.ready
         self.dims = None       # spatial size (z, y, x) of the level once a Metadata registers the grid
         self.ld = _round_up(max(self.n, 1), 256)   # table leading dimension (conv kernels: multiple of 256)
 
@@ -221,7 +239,9 @@ class Grid(object):
 
 
 class Down2(object):
-    """Stride-2 rulebook between a fine and a coarse grid."""
+    """Stride-2 rulebook between a fine and a coarse grid.  `ready` (capacity mode, SIDE_PYRAMID): torch.cuda.Event after
+    which the tables — and the coarse grid's hash and 3x3x3 rulebook — are complete; they are built on another stream."""
+    ready = None
 
     def __init__(self, fine, coarse, parent, children, ldc, ptable, ldf):
         self.fine, self.coarse = fine, coarse
@@ -288,11 +308,24 @@ class PendingChain(object):
             self.ptable = [mk(8 * ld[l], torch.int32) for l in range(depth)]
             self._keep += [arr(self.children), arr(self.ptable)]
             wsb = _lib.query('sgnn_down2_chain_tables_ws_bytes', cap, depth)
-            ws = rt.workspace(wsb)
-            _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth, self._keep[0].ctypes.data,
-                      self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data, self._keep[3].ctypes.data,
-                      ptr(counts), caps_np.ctypes.data, self._keep[4].ctypes.data, self._keep[5].ctypes.data,
-                      ptr(rt.status32), ptr(ws), wsb)
+            self.side = None
+            if SIDE_PYRAMID:
+                # every tensor above was allocated on the training stream (its pool, its ordering); only the launches
+                # move: the lane waits for what the training stream has issued so far (coordinates, level-0 count)
+                self.side = rt.pyramid_stream()
+                with lane(PYRAMID_LANE):
+                    rt2 = runtime(dev)
+                    if rt2.ws.numel() < wsb:
+                        self.side.synchronize()        # growing: the old scratch may still be in use over there
+                    ws = rt2.workspace(wsb)
+                self.side.wait_stream(torch.cuda.current_stream(dev))
+            else:
+                ws = rt.workspace(wsb)
+            with (torch.cuda.stream(self.side) if self.side is not None else _nullcontext()):
+                _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth,
+                          self._keep[0].ctypes.data, self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data,
+                          self._keep[3].ctypes.data, ptr(counts), caps_np.ctypes.data, self._keep[4].ctypes.data,
+                          self._keep[5].ctypes.data, ptr(rt.status32), ptr(ws), wsb)
             return
         _lib.call('sgnn_down2_chain', ptr(coords_cap), 0 if n0_on_device else int(n0),
                   rt.state.data_ptr() if n0_on_device else None, cap, depth, self._keep[0].ctypes.data,
@@ -321,6 +354,21 @@ class PendingChain(object):
             assert coarse.ld * 8 == self.children[l].numel() and fine.ld * 8 == self.ptable[l].numel()
             downs.append(Down2(fine, coarse, self.parent[l][:fine.n], self.children[l], coarse.ld, self.ptable[l], fine.ld))
             fine = coarse
+        if getattr(self, 'side', None) is not None:
+            # the coarse levels' 3x3x3 rulebooks on the same lane (hash builder: the dense index volume belongs to the
+            # training stream), then the event the consuming program waits for
+            for d in downs:
+                g = d.coarse
+                g._nbr = torch.empty(27 * g.ld, dtype=torch.int32, device=g.device)        # training-stream allocation
+            with torch.cuda.stream(self.side):
+                for d in downs:
+                    g = d.coarse
+                    _lib.call('sgnn_rulebook_subm3', ptr(g.keys), ptr(g.vals), g.cap, ptr(g.coords), g.n, ptr(g._nbr),
+                              g.ld, ptr(g.cnt))
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            for d in downs:
+                d.ready = d.coarse.ready = ev
         return grid0, downs
 
 
@@ -413,6 +461,14 @@ class Metadata(object):
                 self._register(self.key(out_size), d.coarse)
             self.down[k] = d
         return self.down[k]
+
+
+def join_pyramid_lane(device):
+    """The training stream waits for everything issued on the pyramid lane so far (no-op if the lane was never used)."""
+    rt = runtime(device)
+    side = getattr(rt, '_pyr_stream', None)
+    if side is not None:
+        torch.cuda.current_stream(rt.device).wait_stream(side)
 
 
 def coords_from_locs(locs, device):

@@ -338,12 +338,15 @@ class _ProgramFn(Function):
         else:
             arena = torch.empty(fwd_total, dtype=torch.float32, device=dev)
         ws = rt.workspace(wsb)
+        # capacity mode: the pyramid below level 0 may still be in flight on the pyramid lane (metadata.SIDE_PYRAMID)
+        ready = next((d.ready for d in run.downs if d.ready is not None), None)
+        wait = ready.cuda_event if ready is not None else None
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                   run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
                   run.pptr.ctypes.data, len(params),
                   run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), fwd_total,
-                  keep.ctypes.data, int(run.training) | (2 if infer else 0), ws.data_ptr(), wsb)
+                  keep.ctypes.data, int(run.training) | (2 if infer else 0), wait, ws.data_ptr(), wsb)
         run.offsets = {}
         outs = []
         for b in run.out_bufs:

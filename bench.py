@@ -18,10 +18,11 @@ import os
 import sys
 import time
 
-# A rank drives four or more HIP streams at once (main, weight-gradient lane, geometry prefetch, RCCL's own): with the
-# ROCm default of 4 hardware queues per process, streams beyond that share a queue and the prefetch lane's small kernels
-# would wait behind whole convolutions (measured with 2 queues: 8.7 instead of 7.4 ms/step).  Read at HIP start-up.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Hardware queues per process (read at HIP start-up): the ROCm default, 4.  Round 2 asked for 8 (an own queue for the
+# geometry-prefetch lane); round 3 measured that with more than 4 queues two concurrently active branches of the replayed
+# graph can land on the same hardware pipe, which then time-slices them with 40-70 us stalls at every switch (17-19 instead
+# of 5.8 ms per step with 8 or 16 queues, profiles/r03w_hw_queues.txt).  With 4 queues no branch placement showed it.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
 
 import numpy as np
 import torch

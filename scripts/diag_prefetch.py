@@ -1,6 +1,6 @@
 """Diagnostic (needs GPU): step time, allocator and GC state over a long teacher-forced run with the geometry prefetcher."""
 import os, sys, time, gc
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from sgnn_amd import synth

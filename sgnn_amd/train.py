@@ -732,6 +732,7 @@ class GraphStep(object):
         rt.state[1:2].zero_()                       # status word of THIS step
         self.opt.zero_grad()
         known = st['known'] if masking else None
+        # (the targets were tried on the side lane, under the encoder: no gain, profiles/r03w_hw_queues.txt)
         (tsdf, toccs, thier), weights = loss_util.compute_targets_and_weights(
             st['sdf'], st['hierarchy'], nl, trunc, masking, known, wgeo, st['locs'])
         B = int(st['sdf'].shape[0])

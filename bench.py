@@ -57,10 +57,12 @@ def parse():
                     help='the classic eager step (host read-backs of the level sizes, one launch at a time from Python) '
                          'instead of the capacity-mode step replayed from a HIP graph')
     ap.add_argument('--headroom', type=float, default=1.3, help='capacity = measured rows x headroom (graph mode)')
-    ap.add_argument('--settle', type=int, default=40,
+    ap.add_argument('--settle', type=int, default=250,
                     help='untimed training steps BEFORE the warm-up steps (set-up, like building the model): with the '
-                         'reference\'s masks the per-level row counts of a freshly initialised model change several-fold '
-                         'within the first dozen optimizer steps; the timed region should see a settled workload')
+                         'reference\'s masks the per-level row counts follow the weights — several-fold changes within '
+                         'the first dozen optimizer steps of a fresh model, then +1 %% per step until they reach the '
+                         'data\'s own occupancy (410 k of 424 k final sites) after ~250 steps (scripts/diag_drift.py); '
+                         'the timed region should see that converged workload, not a point on the transient')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='teacher-forced steps build their own geometry (5 read-backs at the head of the step) instead of '
                          'having it built one batch ahead on a second stream (train.GeometryPrefetcher)')
@@ -475,10 +477,17 @@ def main():
             return gs(batches[i % 2], lw)
         for i in range(args.settle):
             step(i)
+        # the masks keep growing while the fresh weights train (310 k -> 430 k final sites over the first 200 steps): give
+        # the plan its full head-room over the CURRENT counts and let the step be captured again before the measurement,
+        # so that no re-plan (a few eager steps + a 0.3 s capture) falls into the W + K steps below
+        gs.replan()
+        extra = 12          # fixed (every rank must take the same number of steps): eager, three stable snapshots, capture
+        for i in range(extra):
+            step(i)
         elapsed = timed(step, args.warmup, args.steps)
         graph_info = dict(gs.stats)
         graph_info['replay_host_ms_per_step'] = round(graph_info.pop('replay_host_ms') / max(gs.stats['replays'], 1), 3)
-        graph_info['preconditioning_steps'] = args.settle
+        graph_info['preconditioning_steps'] = args.settle + extra
         graph_info['capacity'] = gs.capacity.describe()
         graph_info['live_rows'] = gs.capacity.read()
         live = graph_info['live_rows']
@@ -541,6 +550,7 @@ def main():
             gs._drain()
             torch.cuda.synchronize()
             state = dict((k, v.detach().clone()) for k, v in model.state_dict().items())
+            fresh_model = make_model
 
             def make_model():       # every comparison leg starts from the headline leg's weights: the same masks
                 m = GenModel(8, (args.dim,) * 3, 1, 16, 16, 4, True, True, 1, 1).to(dev)
@@ -582,6 +592,22 @@ def main():
                 'generated_sites_per_level': [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live4['gen'][:-1]] +
                                              [live4['gen'][-1][0]], 'stats': dict(g4.stats)}
             del m4, g4
+            # (e) a point on the transient, for comparison with earlier rounds' free-running numbers: fresh weights,
+            #     40 + 12 untimed steps, then k2 timed ones (final level ~260-320 k sites; BENCH_r02: 212 k)
+            if not teacher:
+                m6 = fresh_model()
+                g6 = GraphStep(m6, lr=1e-3, headroom=args.headroom, grad_sync=flat_sync if dist_on else None,
+                               world_size=world)
+                for i in range(40):
+                    g6(batches[i % 2], lw)
+                g6.replan()
+                el = timed(lambda i: g6(batches[i % 2], lw), 12, k2)
+                live6 = g6.capacity.read()
+                legs['graph_free_running_early_in_training'] = {
+                    'steps': k2, 'value': round(args.batch * world * k2 / el, 2), 'ms_per_step': round(1e3 * el / k2, 3),
+                    'generated_sites_per_level': [args.batch * (args.dim // 8) ** 3] + [8 * k for k, _ in live6['gen'][:-1]] +
+                                                 [live6['gen'][-1][0]], 'stats': dict(g6.stats)}
+                del m6, g6
             # (d) the fixed cost of a step: the same graph-replayed step on ONE block per GPU
             if args.batch > 1:
                 b1 = make_batches(1)

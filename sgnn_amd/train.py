@@ -959,7 +959,11 @@ class GraphStep(object):
         self._drain()
         if self.stage < 2:                     # the drain found an overflow and re-planned already
             return
-        grow = 1.25 if tight else 1.0
+        self._resize(live, 1.25 if tight else 1.0)
+
+    def _resize(self, live, grow=1.0):
+        from .scn.capacity import Capacity, ENC0, _round
+        cap = self.capacity
         nn = lambda n: _round(max(int(n * self.headroom * grow), 1024))
         b = cap.gen_base
         self.capacity = Capacity(cap.device, nn(live[0]), [nn(live[ENC0 + l]) for l in range(len(cap.enc))],
@@ -968,6 +972,19 @@ class GraphStep(object):
         self.graphs, self.stage = None, 1
         self._hist = []
         self.stats['replans'] += 1
+
+    def replan(self):
+        """Re-size every capacity to `headroom` x the current live row counts NOW (one synchronisation), e.g. before a
+        phase that should not be interrupted by a re-plan of its own: the following calls run eagerly until the counts
+        are stable again, then the step is re-captured."""
+        if self.capacity is None or self.stage < 2:
+            return
+        self._drain()
+        if self.stage < 2:
+            return
+        torch.cuda.synchronize(self.capacity.device)
+        self._live = None
+        self._resize(self.capacity.counts.tolist())
 
     def _drain(self):
         redo = self._check(0)

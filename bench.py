@@ -596,7 +596,7 @@ def main():
             #     40 + 12 untimed steps, then k2 timed ones (final level ~260-320 k sites; BENCH_r02: 212 k)
             if not teacher:
                 m6 = fresh_model()
-                g6 = GraphStep(m6, lr=1e-3, headroom=args.headroom, grad_sync=flat_sync if dist_on else None,
+                g6 = GraphStep(m6, lr=1e-3, headroom=max(args.headroom, 1.6), grad_sync=flat_sync if dist_on else None,
                                world_size=world)
                 for i in range(40):
                     g6(batches[i % 2], lw)

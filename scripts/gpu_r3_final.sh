@@ -20,7 +20,7 @@ export TMPDIR=/tmp; D=/tmp/prof_$TAG; rm -rf $D; ROOT=$(pwd)
 (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $ROOT/bench.py --no-cpu-baseline --no-traffic > $ROOT/gpurun_out/${TAG}_prof.out 2> $ROOT/gpurun_out/${TAG}_prof.err)
 F=$(find $D -name '*kernel_stats.csv' | head -1); T=$(find $D -name '*kernel_trace.csv' | head -1)
 [ -n "$F" ] && cp $F gpurun_out/${TAG}_bench_kernel_stats.csv && head -12 $F
-[ -n "$T" ] && python scripts/trace_graph.py $T -60 gpurun_out/${TAG}_step_launches.csv > gpurun_out/${TAG}_trace_summary.txt 2>&1
+[ -n "$T" ] && python scripts/trace_graph.py $T 350 gpurun_out/${TAG}_step_launches.csv > gpurun_out/${TAG}_trace_summary.txt 2>&1
 head -8 gpurun_out/${TAG}_trace_summary.txt
 for c in c1 c3 c4; do
   timeout -k 10 300 python -u scripts/memory_report.py $c 2>&1 | grep -v "amdgpu.ids\|UserWarning\|run_backward" >> gpurun_out/${TAG}_memory.txt

@@ -646,6 +646,15 @@ class GraphStep(object):
                       'replay_host_ms': 0.0}
         self._pins, self._npin = None, 0
         self._bound = False
+        try:
+            hwq = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+        except ValueError:
+            hwq = 4
+        if self.use_graph and hwq > 4:
+            import warnings
+            warnings.warn('GPU_MAX_HW_QUEUES=%d: with more than 4 hardware queues two concurrently active branches of the '
+                          'replayed step (training chain / side lane) were measured to share one hardware pipe on MI355X — '
+                          '17-19 ms instead of 6 ms per step (DESIGN.md section 5a).  Leave it at the default of 4.' % hwq)
 
     # -- pieces --------------------------------------------------------------------------------------------
     def _probe(self, batch, loss_weights):

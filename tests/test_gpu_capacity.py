@@ -169,6 +169,47 @@ def test_graph_replay_is_bit_identical_to_eager_capacity_steps():
         assert torch.equal(pa, pb), na
 
 
+def test_pyramid_lane_and_replan_do_not_change_the_training_run():
+    """(a) metadata.SIDE_PYRAMID: the stride-2 pyramids and coarse rulebooks built on the side lane and joined inside
+    sgnn_prog_forward are the same tables — six captured steps give bit-identical losses and parameters with the lane on
+    and off.  (b) GraphStep.replan() re-sizes the capacities from the live counts and re-captures without touching the
+    training run."""
+    from sgnn_amd.scn import metadata as MD
+    lw = np.ones(5, dtype=np.float32)
+    batches = [_batch(3), _batch(4)]
+    runs = []
+    prev = MD.SIDE_PYRAMID
+    try:
+        for on in (True, False):
+            MD.SIDE_PYRAMID = on
+            runs.append(_train(True, 6, batches, lw))
+    finally:
+        MD.SIDE_PYRAMID = prev
+    (ma, ga, la), (mb, gb, lb) = runs
+    assert ga.stats['captures'] == 1 and gb.stats['captures'] == 1
+    assert la == lb, (la, lb)
+    for (na, pa), (nb, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(pa, pb), na
+    # (b) the same run with a re-plan in the middle
+    from sgnn_amd.train import GraphStep
+    m = _model()
+    gs = GraphStep(m, lr=1e-3, headroom=1.4, settle=False)
+    losses = []
+    for i in range(6):
+        if i == 3:
+            old = gs.capacity.describe()
+            gs.replan()
+            assert gs.graphs is None and gs.stats['replans'] == 1
+        losses.append(float(gs(batches[i % 2], lw)))
+    torch.cuda.synchronize()
+    assert gs.stats['captures'] == 2 and gs.stats['overflows'] == 0, gs.stats
+    new = gs.capacity.describe()
+    assert new != old and all(n >= 1024 for n in [new['input']] + new['enc'])
+    assert losses == la, (losses, la)
+    for (na, pa), (nb, pb) in zip(ma.state_dict().items(), m.state_dict().items()):
+        assert torch.equal(pa, pb), na
+
+
 def test_graph_step_follows_the_classic_training_loop():
     """Same batches, same Adam: the losses of graph-replayed steps track train_step's (different reduction partitions
     only: a few 1e-5 relative after a handful of steps)."""

@@ -22,7 +22,7 @@ import time
 # geometry-prefetch lane); round 3 measured that with more than 4 queues two concurrently active branches of the replayed
 # graph can land on the same hardware pipe, which then time-slices them with 40-70 us stalls at every switch (17-19 instead
 # of 5.8 ms per step with 8 or 16 queues, profiles/r03w_hw_queues.txt).  With 4 queues no branch placement showed it.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')
+os.environ['GPU_MAX_HW_QUEUES'] = os.environ.get('SGNN_BENCH_HW_QUEUES', '4')   # (A/B: SGNN_BENCH_HW_QUEUES=8)
 
 import numpy as np
 import torch

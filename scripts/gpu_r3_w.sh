@@ -2,7 +2,7 @@
 TAG=$1
 mkdir -p gpurun_out
 for q in 4 8 2 16; do
-  GPU_MAX_HW_QUEUES=$q timeout -k 10 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-traffic > gpurun_out/${TAG}_q${q}.json 2> gpurun_out/${TAG}_q${q}.err
+  SGNN_BENCH_HW_QUEUES=$q timeout -k 10 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-traffic > gpurun_out/${TAG}_q${q}.json 2> gpurun_out/${TAG}_q${q}.err
   python - <<PY
 import json
 try:

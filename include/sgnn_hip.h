@@ -477,6 +477,11 @@ int sgnn_prog_backward(const int32_t *ops, const float *opf, int nops, const int
  * Process-wide setting; ws2 must be private to the lane and >= the largest sgnn_conv_bwd_weight_ws_bytes of the
  * program (smaller: the lane is silently not used). */
 int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_bytes);
+/* 1: sgnn_prog_backward no longer makes its stream wait for the weight-gradient lane at its end; the CALLER joins the
+ * lane's stream before anything reads parameter gradients (train.GraphStep: once, before Adam).  A program's last weight
+ * gradient — its first, widest convolution — otherwise holds up the next program's dependent chain for as long as it runs.
+ * Returns the previous setting. */
+int sgnn_prog_defer_join(int on);
 
 /* ---------------------------------------------------------------------------
  * Optimizer step (torch/train.py:81 optim.Adam, :264 optimizer.step()) as one launch over flat buffers of all n

@@ -303,12 +303,16 @@ int make_layout(const View &v, const Plan &P, Layout &L, bool infer = false, con
   return 0;
 }
 
+inline int64_t expand_dwc_bytes(int cin, int cout) { return (64 * (int64_t)cin * cout * 4 + 255) & ~int64_t(255); }
+
 int64_t dw_slice(const View &v, int i) {   // workspace slice of op i's weight-gradient partials (256-byte multiple)
   const int32_t *o = v.ops + OPW * i;
   int64_t w = 0;
   if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
   if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
-  if (o[0] == OP_EXPAND) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]);
+  if (o[0] == OP_EXPAND)   // partials + the 64 reduced slices themselves (they must not live in the shared gradient arena:
+                           // with a deferred lane join the next program's backward pass would overwrite them)
+    w = ((sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 64, o[6], o[7]) + 255) & ~int64_t(255)) + expand_dwc_bytes(o[6], o[7]);
   return (w + 255) & ~int64_t(255);
 }
 
@@ -365,6 +369,10 @@ struct SideLane {
 // gradients run on its own stream and workspace — correct, just not overlapped), and sgnn_prog_set_side_stream waits
 // for a call in flight before it swaps the lane.
 std::mutex g_side_mu;
+// sgnn_prog_defer_join(1): a backward call no longer makes its stream wait for the lane at its end — the CALLER joins the
+// lane's stream before anything reads parameter gradients.  A program's last weight gradient (its first, widest
+// convolution) otherwise stalls the dependent chain of the next program for as long as it runs.
+bool g_defer_join = false;
 
 }  // namespace
 
@@ -379,6 +387,12 @@ SGNN_EXPORT int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int6
   g_side.ws = stream2 ? ws2 : nullptr;
   g_side.ws_bytes = stream2 ? ws2_bytes : 0;
   return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_prog_defer_join(int on) {
+  const int prev = g_defer_join ? 1 : 0;
+  g_defer_join = on != 0;
+  return prev;
 }
 
 SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
@@ -834,8 +848,10 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         const float *wc = arena + L.aux_off[i];
         const int32_t *nbr = (const int32_t *)lev_nbr[lev];
-        float *dwc = garena + L.bextra;
-        float *part = dwc + round64(64 * (int64_t)cin * cout);
+        // reduced 64-slice weight gradient: at the tail of this op's weight-gradient workspace slice (lane-owned memory)
+        // (without the lane the slices share `ws` with the BatchNorm kernels: the gradient arena then, as before)
+        float *dwc = side ? (float *)(dw_base + dw_off + dw_slice(v, i) - expand_dwc_bytes(cin, cout)) : garena + L.bextra;
+        float *part = garena + L.bextra + round64(64 * (int64_t)cin * cout);
         const hipStream_t lane = dw_lane();
         SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
         if (wants(in0) && n > 0) {
@@ -887,7 +903,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     for (const PendingExpand &pe : pending_expand)
       PROG_TRY(sgnn_expand_weights_bwd(pe.dwc, pe.cin, pe.cout, pe.dw, (sgnn_stream_t)lane));
   }
-  if (forked) {                                       // parameter gradients are complete once the lane has drained
+  if (forked && !g_defer_join) {                      // parameter gradients are complete once the lane has drained
     SGNN_HIP_TRY(hipEventRecord(g_side.join, g_side.stream));
     SGNN_HIP_TRY(hipStreamWaitEvent(hs, g_side.join, 0));
   }

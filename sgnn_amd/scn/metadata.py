@@ -74,6 +74,8 @@ class _Runtime(object):
             self._side_ws = None
         if self._side_ws is None or self._side_ws.numel() < nbytes or not getattr(self, '_side_on', False):
             if self._side_ws is None or self._side_ws.numel() < nbytes:
+                if self._side_ws is not None:
+                    self._side_stream.synchronize()    # a deferred join: the lane may still be using the old workspace
                 self._side_ws = torch.empty(int(nbytes * 1.5) + 256, dtype=torch.uint8, device=self.device)
             rc = _lib.query('sgnn_prog_set_side_stream', self._side_stream.cuda_stream, self._side_ws.data_ptr(),
                             self._side_ws.numel())
@@ -464,9 +466,10 @@ class Metadata(object):
 
 
 def join_pyramid_lane(device):
-    """The training stream waits for everything issued on the pyramid lane so far (no-op if the lane was never used)."""
+    """The training stream waits for everything issued so far on the side lane's stream — pyramids, dense weight gradients,
+    the weight-gradient lane of sgnn_prog_backward (one stream) — no-op if it was never created."""
     rt = runtime(device)
-    side = getattr(rt, '_pyr_stream', None)
+    side = getattr(rt, '_side_stream', None)
     if side is not None:
         torch.cuda.current_stream(rt.device).wait_stream(side)
 

@@ -32,6 +32,12 @@ ENABLED = True   # False: run the containers layer by layer (one autograd node p
 # same program (fine for a training loop, wrong for code that keeps two forward results alive).
 PERSISTENT_ARENAS = False
 _garenas = {}
+# Deferred lane join (train.GraphStep sets DEFER_JOIN around its backward pass): a program's backward call does not wait
+# for its weight-gradient kernels on the side lane; the caller joins the lane once, before the optimizer, and then clears
+# `_deferred`.  Until then everything those kernels read — the program's forward arena, its gradient arena (its own one:
+# not the shared per-device arena), the incoming output gradients, the level tables — is kept alive here.
+DEFER_JOIN = False
+_deferred = []
 _iarenas = {}      # inference: one forward arena per device, shared by all programs
 
 
@@ -378,7 +384,9 @@ class _ProgramFn(Function):
         rt = runtime(dev)
         ops, opf, bufs = prog.ops_np, prog.opf_np, prog.bufs_np
         nops, nbuf, ncls = ops.shape[0], bufs.shape[0], prog.n_classes
-        if PERSISTENT_ARENAS:      # one gradient arena per device: program backward calls never overlap
+        if PERSISTENT_ARENAS and DEFER_JOIN:   # the lane may still read this program's gradient buffers: an arena of its own
+            garena = _arena(prog.__dict__.setdefault('_arenas', {}), 'bwd', run.total, dev)
+        elif PERSISTENT_ARENAS:    # one gradient arena per device: program backward calls never overlap
             garena = _arena(_garenas, str(dev), run.total, dev)
         else:
             garena = torch.empty(run.total, dtype=torch.float32, device=dev)
@@ -417,13 +425,22 @@ class _ProgramFn(Function):
         geptr = _ptr_array([0 if t is None else t.data_ptr() for t in gext])
         ws = rt.workspace(run.wsb)
         rt.side_lane(run.wsb)
-        _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
-                  run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
-                  run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
-                  run.pptr.ctypes.data, gp.ctypes.data,
-                  len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
-                  arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, run.keep.ctypes.data,
-                  int(run.training), ws.data_ptr(), run.wsb)
+        # deferral needs every parameter gradient to land in a buffer nobody reads before the caller's join (the flat
+        # gradient buffer of train.FlatAdam); gradients handed back to autograd must be complete when this call returns
+        defer = bool(DEFER_JOIN and sum(sizes) == 0)
+        prev_defer = _lib.query('sgnn_prog_defer_join', int(defer))
+        if defer:
+            _deferred.append((arena, garena, held, ext, params, run))
+        try:
+            _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
+                      run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
+                      run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
+                      run.pptr.ctypes.data, gp.ctypes.data,
+                      len(params), run.eptr.ctypes.data, geptr.ctypes.data, run.iptr.ctypes.data, len(run.idx),
+                      arena.data_ptr(), garena.data_ptr(), run.total, gout.ctypes.data, run.keep.ctypes.data,
+                      int(run.training), ws.data_ptr(), run.wsb)
+        finally:
+            _lib.query('sgnn_prog_defer_join', prev_defer)
         return (None,) + tuple(gext) + tuple(views)
 
 

@@ -749,7 +749,19 @@ class GraphStep(object):
                                        teacher=toccs if self.teacher_forced else None)
         loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
                                               st['locs'], masking, known, weights=weights)
-        loss.backward()
+        from .scn import metadata as MD, program as P_
+        # program weight gradients land in the flat buffer nobody reads before Adam: ONE join of the lane at the end of the
+        # backward pass instead of one per program (scn.program.DEFER_JOIN / sgnn_prog_defer_join; a program's last weight
+        # gradient otherwise holds up the next program's chain).  (The dense bottleneck's six weight gradients were tried on
+        # the lane as well: no gain, profiles/r03w_hw_queues.txt.)
+        defer = MD.SIDE_LANE and os.environ.get('SGNN_DEFER_JOIN', '1') != '0'
+        prev_defer, P_.DEFER_JOIN = P_.DEFER_JOIN, defer
+        try:
+            loss.backward()
+        finally:
+            P_.DEFER_JOIN = prev_defer
+            MD.join_pyramid_lane(st['sdf'].device)      # (also after an exception: nothing may outlive the keep-alive list)
+            del P_._deferred[:]
         self.opt.collect()           # gradients autograd delivered (dense bottleneck); program gradients are in flat_g already
         return loss.detach(), losses, rt
 

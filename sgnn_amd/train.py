@@ -502,9 +502,12 @@ class FlatAdam(object):
                 p.grad = None
 
     def collect(self):
-        """After backward: copy the autograd-delivered gradients into flat_g (one multi-tensor launch).  Returns the
-        per-segment "some parameter has a gradient" list (host knowledge, exact mode)."""
-        dst, src, reached = [], [], []
+        """After backward: copy the autograd-delivered gradients into flat_g (one multi-tensor launch) and zero the slices
+        of parameters that received none.  Returns the per-segment "some parameter has a gradient" list (host knowledge,
+        exact mode).  Semantics are per SEGMENT (torch.optim.Adam skips per parameter): a parameter without a gradient
+        inside a reached segment is updated from a zero gradient — its moments decay and weight decay applies; in GenModel
+        a stage's parameters are reached together (torch/model.py:211, 260), so the two rules coincide there."""
+        dst, src, reached, stale = [], [], [], []
         i = 0
         for _, ps in self.segments:
             any_grad = False
@@ -517,10 +520,36 @@ class FlatAdam(object):
                     any_grad = True
                     dst.append(v)
                     src.append(p.grad)
+                else:
+                    stale.append(v)
             reached.append(any_grad)
         if dst:
             torch._foreach_copy_(dst, src)
+        if stale:
+            # a parameter nothing reached this step: its slice of flat_g still holds an EARLIER step's gradient (capacity
+            # mode writes program gradients straight into the buffer).  Nothing may read that: a data-parallel all-reduce
+            # sums the whole buffer, and a segment another rank reached is updated from the sum on every rank.
+            torch._foreach_zero_(stale)
         return reached
+
+    def named_gradients(self, model):
+        """{parameter name: what flat_g holds for it} — the gradients Adam consumes (after collect(): autograd-delivered
+        ones copied in, program gradients written there by the backward kernels) — in the REFERENCE's layout (dense
+        convolutions store (K, Cin, Cout), model.DenseConv).  For tests and tools; clones."""
+        from .model import DenseConv
+        view = dict((id(p), v) for p, v in zip(self.params, self.views_g))
+        owners = {}
+        for mn, mod in model.named_modules():
+            if isinstance(mod, DenseConv):
+                owners[(mn + '.' if mn else '') + 'weight'] = mod
+        out = {}
+        for n, p in model.named_parameters():
+            g = view.get(id(p))
+            if g is not None:
+                g = g.detach().clone()
+                g = owners[n].to_torch(g) if n in owners else g
+            out[n] = g
+        return out
 
     def _seg_table(self, cnts, use_flags):
         seg = np.zeros((len(self.segments), 5), dtype=np.int64)
@@ -626,8 +655,14 @@ class GraphStep(object):
 
     def __init__(self, model, lr=1e-3, weight_decay=0.0, num_hierarchy_levels=4, truncation=3.0, use_log_transform=True,
                  weight_missing_geo=5.0, use_loss_masking=True, teacher_forced=False, headroom=1.3, use_graph=True,
-                 grad_sync=None, world_size=1, optimizer=None, settle=True):
+                 grad_sync=None, world_size=1, optimizer=None, settle=True, keep_outputs=False):
         self.model = model
+        # keep_outputs: `self.outputs` = (output_sdf, output_occs) of the last step, as the model returned them (capacity-
+        # sized tensors whose live prefix is scn.capacity.trim(t); inside a replayed graph they are the graph's own static
+        # tensors, valid until the next call).  teacher_volumes (with teacher_forced): dense occupancy volumes that decide
+        # the generative masks INSTEAD of the batch's target hierarchy (parity tests force the oracle's masks this way);
+        # the loss still uses the batch's targets.
+        self.keep_outputs, self.outputs, self.teacher_volumes = bool(keep_outputs), None, None
         self.opt = optimizer if optimizer is not None else FlatAdam(genmodel_segments(model), lr=lr, weight_decay=weight_decay)
         self.args = (num_hierarchy_levels, truncation, use_log_transform, weight_missing_geo, use_loss_masking)
         self.teacher_forced, self.headroom, self.use_graph = teacher_forced, float(headroom), bool(use_graph)
@@ -657,6 +692,11 @@ class GraphStep(object):
                           '17-19 ms instead of 6 ms per step (DESIGN.md section 5a).  Leave it at the default of 4.' % hwq)
 
     # -- pieces --------------------------------------------------------------------------------------------
+    def _teacher(self, toccs):
+        if not self.teacher_forced:
+            return None
+        return self.teacher_volumes if self.teacher_volumes is not None else toccs
+
     def _probe(self, batch, loss_weights):
         """Classic step (read-backs) that also sizes the capacities."""
         from .scn import metadata as MD
@@ -671,17 +711,25 @@ class GraphStep(object):
             (tsdf, toccs, thier), weights = loss_util.compute_targets_and_weights(
                 batch['sdf'], batch['hierarchy'], nl, trunc, masking, known, wgeo, batch['input'][0])
             B = int(batch['sdf'].shape[0])
-            out_sdf, out_occs = self.model(batch['input'], loss_weights, batch_size=B,
-                                           teacher=toccs if self.teacher_forced else None)
+            out_sdf, out_occs = self.model(batch['input'], loss_weights, batch_size=B, teacher=self._teacher(toccs))
+            if self.keep_outputs:
+                self.outputs = (out_sdf, out_occs)
             loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
                                                   batch['input'][0], masking, known, weights=weights)
             loss.backward()
             reached = self.opt.collect()
             if self.grad_sync is not None:
+                # A probe step takes part in the SAME protocol as a capacity step (one all-reduce of flat_g + flags, merged
+                # overflow bit, status-gated update, status word retired one step late): whatever kind of step a peer runs
+                # in this slot, both ranks issue one collective, apply or skip the same update, and re-run their own batch
+                # if ANY rank overflowed (a probe used to apply its update while an overflowing peer skipped it).
+                rt = MD.runtime(batch['sdf'].device)
                 self.opt.flat_g[self.opt.numel:].zero_()          # flag slots (slot 7: overflow, none on the classic path)
                 self.opt.flags.copy_(torch.tensor([1.0 if r else 0.0 for r in reached], dtype=torch.float32))
                 self.grad_sync(self.opt.flat_g)
-                self.opt.step(flags_in_grads=True, grad_scale=1.0 / self.world_size)
+                self.opt.merge_overflow(rt.status32)
+                self.opt.step(flags_in_grads=True, grad_scale=1.0 / self.world_size, status=rt.status32)
+                self._issue_status(rt, batch, loss_weights, probe=True)
             else:
                 self.opt.step(reached=reached)
             log = MD.COUNT_LOG
@@ -746,7 +794,9 @@ class GraphStep(object):
             st['sdf'], st['hierarchy'], nl, trunc, masking, known, wgeo, st['locs'])
         B = int(st['sdf'].shape[0])
         out_sdf, out_occs = self.model([st['locs'], st['feats']], loss_weights, batch_size=B, capacity=cap,
-                                       teacher=toccs if self.teacher_forced else None)
+                                       teacher=self._teacher(toccs))
+        if self.keep_outputs:
+            self.outputs = (out_sdf, out_occs)
         loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
                                               st['locs'], masking, known, weights=weights)
         from .scn import metadata as MD, program as P_
@@ -803,17 +853,20 @@ class GraphStep(object):
         self._opt_step(loss_weights, rt)
         return loss, losses, rt
 
-    def _issue_status(self, rt, batch, loss_weights):
+    def _issue_status(self, rt, batch, loss_weights, probe=False):
+        """Queue this step's status word (+ the live row counts) for a read one step late.  probe: a classic step under
+        data parallelism — it has no row counts of its own, only the merged overflow bit of its all-reduce slot."""
         if self._pins is None:      # [status word | the capacity's 64 live row counts], per in-flight step
-            self._pins = [torch.zeros(65, dtype=torch.int64).pin_memory() for _ in range(4)]
+            self._pins = [torch.zeros(65, dtype=torch.int64).pin_memory() for _ in range(8)]
         pin = self._pins[self._npin % len(self._pins)]
         self._npin += 1
         pin[0:1].copy_(rt.state[1:2], non_blocking=True)
-        pin[1:].copy_(self.capacity.counts, non_blocking=True)
+        if not probe:
+            pin[1:].copy_(self.capacity.counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(rt.device))
         self._n_issued = getattr(self, '_n_issued', 0) + 1
-        self.pending.append((ev, pin, batch, loss_weights, self.capacity, self._n_issued - 1))
+        self.pending.append((ev, pin, batch, loss_weights, None if probe else self.capacity, self._n_issued - 1))
 
     def _check(self, keep):
         """Retire all but the `keep` newest issued steps; returns the batches whose step overflowed."""
@@ -822,13 +875,13 @@ class GraphStep(object):
             ev, pin, batch, lw, cap, index = self.pending.pop(0)
             ev.synchronize()
             word = int(pin[0]) & 0xFFFFFFFF
-            if cap is self.capacity:
+            if cap is not None and cap is self.capacity:
                 self._live = pin[1:].tolist()
             if word & 4 and not (word & 3):
                 redo.append((batch, lw))
             elif word:
                 from .scn.metadata import runtime
-                runtime(self.static['sdf'].device).raise_status(
+                runtime(batch['sdf'].device).raise_status(
                     word, 'raised by capacity-mode step %d of this GraphStep (0-based), %d step(s) ago; that step\'s '
                           'parameter update was applied' % (index, self._n_issued - 1 - index))
         return redo

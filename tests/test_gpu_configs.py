@@ -191,6 +191,18 @@ def _oracle_runs(dims, batch, cfg, dist, occupancy, train, want_grads=False, dat
     return data, res, masks, lw
 
 
+_ORACLE_CACHE = {}
+
+
+def oracle_runs_cached(dims, batch, cfg, dist, occupancy, train, want_grads=False):
+    """_oracle_runs, computed once per pytest process (the 64^3 batch-4 fp32 + fp64 oracle passes with gradients take about a
+    minute of CPU; two tests hold the HIP paths — classic and GraphStep — to the same run).  Read-only for the callers."""
+    key = (tuple(dims), batch, cfg, dist, occupancy, train, want_grads)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = _oracle_runs(dims, batch, cfg, dist, occupancy, train, want_grads=want_grads)
+    return _ORACLE_CACHE[key]
+
+
 def _model_forward(tag, dims, batch, cfg, dist, occupancy, train=True):
     """(1) The HIP model on its own masks: site lists equal the oracle's except for sites that descend from a decision
     whose reference logit lies within the fp32 error of the threshold.  (2) The HIP model forced onto the oracle's masks
@@ -244,7 +256,7 @@ def test_config1_model_loss_and_gradients_bs4():
     from sgnn_amd.model import GenModel
     from sgnn_amd import loss as L
     dims, batch, cfg = (64, 64, 64), 4, 2
-    data, res, masks, lw = _oracle_runs(dims, batch, cfg, 'surface', 0.05, True, want_grads=True)
+    data, res, masks, lw = oracle_runs_cached(dims, batch, cfg, 'surface', 0.05, True, want_grads=True)
     locs, feats = data['input']
     oocc = res['f32'][1]
     hm = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()

@@ -351,3 +351,31 @@ def test_host_side_size_queries_of_the_c_abi():
     assert cap >= 2 * 366085 and cap & (cap - 1) == 0
     assert _lib.query('sgnn_conv_bwd_weight_ws_bytes', 0, 27, 16, 16) == 0
     assert _lib.query('sgnn_conv_bwd_weight_ws_bytes', 1000, 27, 16, 16) == 4 * 27 * 16 * 16 * 4      # 4 row blocks of 256
+
+
+def test_flat_adam_collect_leaves_no_stale_gradient_behind():
+    """capacity-mode backward writes program gradients straight into FlatAdam.flat_g; a later classic step whose
+    hierarchy stops early (no gradient for a stage, torch/model.py:211) must not leave that stage's OLD gradient in the
+    buffer — a data-parallel all-reduce sums the whole buffer and another rank's "reached" flag would apply it."""
+    from sgnn_amd.train import FlatAdam
+    torch.manual_seed(0)
+    pa = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    pb = [torch.nn.Parameter(torch.randn(2, 2)), torch.nn.Parameter(torch.randn(7))]
+    opt = FlatAdam([('a', pa), ('b', pb)], lr=1e-2)
+    opt.flat_g[:opt.numel].fill_(123.0)                    # what an earlier step left behind
+    for p in pa:
+        p.grad = torch.ones_like(p)
+    pb[0].grad = None
+    pb[1].grad = None
+    reached = opt.collect()
+    assert reached == [True, False]
+    (b0, e0), (b1, e1) = opt.bounds
+    assert torch.equal(opt.flat_g[b0:e0], torch.ones(e0 - b0))
+    assert torch.equal(opt.flat_g[b1:e1], torch.zeros(e1 - b1)), 'unreached segment keeps a stale gradient'
+    # a parameter without a gradient INSIDE a reached segment reads as zero as well
+    opt.flat_g[:opt.numel].fill_(7.0)
+    pa[1].grad = None
+    assert opt.collect() == [True, False]
+    assert torch.equal(opt.views_g[1], torch.zeros(5)) and torch.equal(opt.views_g[0], torch.ones(4, 3))
+    g = opt.named_gradients(torch.nn.ParameterList(pa + pb))
+    assert len(g) == 4 and all(v is not None for v in g.values())

@@ -1,0 +1,54 @@
+"""Gather-instruction micro-benchmark on a real level (needs GPU): scripts/kernels/gather_bench.hip.
+  python scripts/bench_gather.py [--batch 32] [--dim 64] [--iters 20]
+Prints, per lane mapping, the time of one pass over the level's 3x3x3 rulebook and the rate in gathered bytes."""
+import argparse, ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgnn_amd import synth
+from sgnn_amd.scn.metadata import Grid, coords_from_locs
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--dim', type=int, default=64)
+ap.add_argument('--iters', type=int, default=20)
+args = ap.parse_args()
+lib = ctypes.CDLL(os.path.join(ROOT, 'scripts', 'kernels', 'libgather_bench.so'))
+lib.gather_bench.restype = ctypes.c_int
+lib.gather_bench.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+dev = torch.device('cuda')
+data = synth.make_batch(args.batch, (args.dim,) * 3, cfg=2, occupancy=0.05)
+g = Grid(coords_from_locs(data['input'][0], dev))
+tab = g.subm_table()
+rules = int((tab.view(27, g.ld)[:, :g.n] >= 0).sum().item())
+print('sites %d  rules %d (R/N %.2f)' % (g.n, rules, rules / g.n))
+out = torch.zeros(g.ld + 256, device=dev)
+names = {0: '64 B rows, conv (MFMA-operand) mapping, b128', 1: '64 B rows, row-contiguous mapping, b128',
+         2: '64 B rows, row-contiguous + 4 ds_bpermute', 3: '64 B rows, row-contiguous + LDS write/read b128',
+         4: '32 B rows, conv mapping, b64', 5: '32 B rows, row-contiguous mapping, b128 (2 instr / 64 rows)'}
+ref = {}
+xs = {16: torch.randn(g.n, 16, device=dev), 8: torch.randn(g.n, 8, device=dev)}
+for mode in range(6):
+    c = 16 if mode < 4 else 8
+    x = xs[c]
+    stream = torch.cuda.current_stream().cuda_stream
+    call = lambda: lib.gather_bench(x.data_ptr(), g.n, c, tab.data_ptr(), g.ld, 27, g.n, out.data_ptr(), mode, stream)
+    for _ in range(3):
+        assert call() == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / args.iters * 1e3
+    s = float(out.double().sum())
+    key = c
+    if key in ref:
+        assert abs(s - ref[key]) <= 1e-4 * max(1.0, abs(ref[key])), (mode, s, ref[key])   # every mapping loads the same rows
+    ref.setdefault(key, s)
+    print('mode %d  %-62s %7.1f us   %6.2f TB/s gathered (rules only: %6.2f)   %5.1f cycles/gather-instr/CU @2.4GHz'
+          % (mode, names[mode], us, 27.0 * g.n * c * 4 / us / 1e6, rules * c * 4.0 / us / 1e6,
+             us * 1e-6 * 2.4e9 * 256 / (g.ld / 64 * 27 * (4 if mode != 5 else 2))))

@@ -20,154 +20,10 @@
 #include <stdlib.h>
 #include "common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_common.h"
 
-#define CONV_MREP 4                        // 16-row MFMA tiles per wave in the large-grid variant
-#define CONV_ROWS_PER_WAVE (16 * CONV_MREP)
-#define CONV_ROWS_PER_BLOCK (4 * CONV_ROWS_PER_WAVE)   // also the required multiple of the table's ld
 #define CONV_SMALL_GRID g_small_grid       // below this many 256-row workgroups the latency-oriented small-level kernel runs
 static int g_small_grid = 160;             // ~40 k rows (sgnn_conv_set_small_rows: measurements)
-
-template <int CIN, int COUT>
-struct ConvCfg {
-  static constexpr int V = (CIN + 3) / 4;    // channels per lane quarter
-  static constexpr int CINP = 4 * V;         // padded input channels
-  static constexpr int NT = (COUT + 15) / 16;  // 16-wide output column tiles
-  static constexpr int PER_K = NT * 16 * CINP;  // LDS floats per offset
-#ifndef CONV_LDS_FLOATS
-#define CONV_LDS_FLOATS 8192                  // weight tile budget: 32 KiB of LDS
-#endif
-  static constexpr int KC_RAW = CONV_LDS_FLOATS / PER_K;
-  static constexpr int KC = KC_RAW < 1 ? 1 : (KC_RAW > 27 ? 27 : KC_RAW);
-  // widest load that is aligned for every (row, q)
-  static constexpr int ALIGN = ((CIN % 4 == 0) && (V % 4 == 0)) ? 16 : (((CIN % 2 == 0) && (V % 2 == 0)) ? 8 : 4);
-};
-
-// optional generalisation of the rulebook walk (sgnn_conv_*_ex): offset k of group g reads table row
-// kmap[g*K + k] (NULL: k), gathers feature row idx*in_mul + kadd[g*K + k] (NULL: +0) and group g owns output rows
-// row*groups + g and the weight block g.  Plain convolutions use {NULL, NULL, 1, 1}.
-struct ConvEx {
-  const int32_t *kmap;
-  const int32_t *kadd;
-  int in_mul;
-  int groups;
-  int table_rows;   // rows of `table` (K unless kmap selects rows of a larger table)
-};
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-
-// V consecutive floats at byte offset `off` of a raw buffer; an out-of-range offset (rule entry -1 maps to
-// 0xFFFFFFxx) returns zeros, so missing neighbours need neither a branch nor a select.  Multi-dword
-// buffer loads only need dword alignment on gfx950.
-template <int V>
-__device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint32_t off, float (&a)[V]) {
-  int s = 0;
-#pragma unroll
-  for (; s + 4 <= V; s += 4) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 4 * s, 0, 0);
-    a[s] = __uint_as_float(v.x); a[s + 1] = __uint_as_float(v.y);
-    a[s + 2] = __uint_as_float(v.z); a[s + 3] = __uint_as_float(v.w);
-  }
-  if constexpr (V % 4 == 3) {
-    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off + 4 * (V - 3), 0, 0);
-    a[V - 3] = __uint_as_float(v.x); a[V - 2] = __uint_as_float(v.y); a[V - 1] = __uint_as_float(v.z);
-  } else if constexpr (V % 4 == 2) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 4 * (V - 2), 0, 0);
-    a[V - 2] = __uint_as_float(v.x); a[V - 1] = __uint_as_float(v.y);
-  } else if constexpr (V % 4 == 1) {
-    a[V - 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * (V - 1), 0, 0));
-  }
-}
-
-// Shared epilogue of the MFMA kernels: optional residual addend, strided store, optional BatchNorm statistics
-// (see ConvEpi).  acc[m][nt] holds the wave's rows row0 + m*16 + (lane>>4)*4 + i, column nt*16 + (lane&15).
-// Contains barriers when statistics are on: call it from all threads.  sred: >= 4*2*NT*16 doubles of LDS.
-template <int COUT, int M, int NT>
-__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0, int64_t n_out, unsigned groups,
-                                              unsigned grp, float *y, const ConvEpi &epi, int stats, double *sred,
-                                              const float *any_ptr, size_t pblock) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const uint32_t ldy4 = (uint32_t)epi.ldy * 4u;
-  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(((n_out * groups - 1) * epi.ldy + COUT) * 4));
-  const bool has_add = epi.addend != nullptr;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      make_rsrc(has_add ? epi.addend : any_ptr, has_add ? (uint32_t)(((n_out * groups - 1) * epi.ld_add + COUT) * 4) : 0u);
-  const uint32_t lda4 = (uint32_t)epi.ld_add * 4u;
-  const __amdgpu_buffer_rsrc_t rs_b =
-      make_rsrc(stats == 2 ? epi.bn_x : any_ptr, stats == 2 ? (uint32_t)(((n_out - 1) * epi.ld_bnx + COUT) * 4) : 0u);
-  const uint32_t ldb4 = (uint32_t)epi.ld_bnx * 4u;
-  double s1[NT], s2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = nt * 16 + r;
-    float cm = 0.f, ci = 0.f, cg = 1.f, cb = 0.f;
-    if (stats == 2 && col < COUT) {
-      cm = epi.mean[col];
-      ci = epi.invstd[col];
-      cg = epi.gamma ? epi.gamma[col] : 1.f;
-      cb = epi.beta ? epi.beta[col] : 0.f;
-    }
-    // fp64 from the first addition on: E[x^2] - E[x]^2 downstream must stay exact to fp32 resolution
-    double f1 = 0.0, f2 = 0.0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t row = row0 + m * 16 + q * 4 + i;
-        const bool ok = col < COUT && row < n_out;
-        const uint32_t orow = (uint32_t)(row * groups + grp);
-        float v = acc[m][nt][i];
-        if (has_add) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, ok ? orow * lda4 + col * 4u : 0xFFFFFFFFu, 0, 0));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_y, ok ? orow * ldy4 + col * 4u : 0xFFFFFFFFu, 0, 0);
-        if (stats == 1) {
-          const double vm = ok ? (double)v : 0.0;
-          f1 += vm;
-          f2 = fma(vm, vm, f2);
-        } else if (stats == 2) {
-          const float xb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, ok ? orow * ldb4 + col * 4u : 0xFFFFFFFFu, 0, 0));
-          const float xh = (xb - cm) * ci;
-          const float t = fmaf(xh, cg, cb);
-          const float dz = ok ? (t > 0.f ? v : v * epi.leak) : 0.f;
-          f1 += (double)dz;
-          f2 = fma((double)dz, (double)xh, f2);
-        }
-      }
-    }
-    s1[nt] = f1;
-    s2[nt] = f2;
-  }
-  if (stats) {
-    // lanes r, r+16, r+32, r+48 hold the same column: fold them, then the four waves in fixed order through LDS
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      double a = s1[nt], b = s2[nt];
-      a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-      a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-      if (q == 0) {
-        sred[(wave * 2 + 0) * NT * 16 + nt * 16 + r] = a;
-        sred[(wave * 2 + 1) * NT * 16 + nt * 16 + r] = b;
-      }
-    }
-    __syncthreads();
-    for (int o = tid; o < 2 * NT * 16; o += 256) {
-      const int which = o / (NT * 16), col = o % (NT * 16);
-      if (col < COUT) {
-        double t = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) t += sred[(wv * 2 + which) * NT * 16 + col];
-        epi.partial[(pblock * 2 + which) * COUT + col] = t;
-      }
-    }
-  }
-}
 
 // EX = false: plain rulebook walk (ex is ignored; keeps the register budget of the hot instantiations)
 template <int CIN, int COUT, int M, bool EX>

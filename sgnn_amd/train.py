@@ -657,7 +657,7 @@ class GraphStep(object):
                  weight_missing_geo=5.0, use_loss_masking=True, teacher_forced=False, headroom=1.3, use_graph=True,
                  grad_sync=None, world_size=1, optimizer=None, settle=True, keep_outputs=False):
         self.model = model
-        # keep_outputs: `self.outputs` = (output_sdf, output_occs) of the last step, as the model returned them (capacity-
+        # keep_outputs: `self.outputs` = (output_sdf, output_occs) of the last step, detached, as the model returned them (capacity-
         # sized tensors whose live prefix is scn.capacity.trim(t); inside a replayed graph they are the graph's own static
         # tensors, valid until the next call).  teacher_volumes (with teacher_forced): dense occupancy volumes that decide
         # the generative masks INSTEAD of the batch's target hierarchy (parity tests force the oracle's masks this way);
@@ -692,6 +692,21 @@ class GraphStep(object):
                           '17-19 ms instead of 6 ms per step (DESIGN.md section 5a).  Leave it at the default of 4.' % hwq)
 
     # -- pieces --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _detached(out_sdf, out_occs):
+        """The model's outputs without their autograd graph (same storage, live-count attribute kept).  A caller that holds
+        the graph of an earlier step across a capturing call makes autograd re-use AccumulateGrad nodes created on another
+        stream — a cross-stream synchronisation inside the capture, which HIP answers with a crash in hipStreamEndCapture."""
+        def d(t):
+            if not torch.is_tensor(t):
+                return t
+            u = t.detach()
+            for a in ('_sgnn_cnt', '_sgnn_cnt8'):
+                if hasattr(t, a):
+                    setattr(u, a, getattr(t, a))
+            return u
+        return [d(t) for t in out_sdf], [[d(t) for t in o] for o in out_occs]
+
     def _teacher(self, toccs):
         if not self.teacher_forced:
             return None
@@ -713,7 +728,7 @@ class GraphStep(object):
             B = int(batch['sdf'].shape[0])
             out_sdf, out_occs = self.model(batch['input'], loss_weights, batch_size=B, teacher=self._teacher(toccs))
             if self.keep_outputs:
-                self.outputs = (out_sdf, out_occs)
+                self.outputs = self._detached(out_sdf, out_occs)
             loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
                                                   batch['input'][0], masking, known, weights=weights)
             loss.backward()
@@ -796,7 +811,7 @@ class GraphStep(object):
         out_sdf, out_occs = self.model([st['locs'], st['feats']], loss_weights, batch_size=B, capacity=cap,
                                        teacher=self._teacher(toccs))
         if self.keep_outputs:
-            self.outputs = (out_sdf, out_occs)
+            self.outputs = self._detached(out_sdf, out_occs)
         loss, losses = loss_util.compute_loss(out_sdf, out_occs, tsdf, toccs, thier, loss_weights, trunc, use_log, wgeo,
                                               st['locs'], masking, known, weights=weights)
         from .scn import metadata as MD, program as P_
@@ -920,6 +935,7 @@ class GraphStep(object):
                 self._opt_step(loss_weights, rt)
             self.graphs = (g1, g2)
         self._graph_out = (loss, losses)
+        self._graph_outputs = self.outputs       # (keep_outputs) the graph's own static output tensors
         # everything the captured kernels touch outside the graph's own pool must outlive the graph
         self._keep = (rt.ws, getattr(rt, '_side_ws', None), getattr(rt, '_volume', None), self.capacity, self.static)
         self.stats['captures'] += 1
@@ -935,11 +951,13 @@ class GraphStep(object):
             self.graphs[1].replay()
         self.stats['replay_host_ms'] += 1e3 * (time.perf_counter() - t0)     # host time inside hipGraphLaunch
         self.stats['replays'] += 1
+        self.outputs = self._graph_outputs
         return self._graph_out
 
     # -- the step -------------------------------------------------------------------------------------------
     def __call__(self, batch, loss_weights):
         loss_weights = np.asarray(loss_weights, dtype=np.float32)
+        self.outputs = None
         key = (tuple(bool(w > 0) for w in loss_weights), tuple(batch['sdf'].shape))
         wkey = tuple(float(w) for w in loss_weights)
         if key != self.key:                          # new curriculum stage / batch shape: re-size and re-capture

@@ -215,6 +215,10 @@ int64_t sgnn_conv_stats_blocks(int64_t n_out);
 int sgnn_conv_set_small(int on);
 /* row count below which the small-level kernel is used (default ~41 k); returns the previous threshold */
 int64_t sgnn_conv_set_small_rows(int64_t rows);
+/* levels above that threshold run the plain rulebook walk (K = 27 / 8) as straight-line code (conv_unrolled.hip: exact
+ * s_waitcnt counts, rule entries loaded up front); 0 = the looped kernel everywhere (A/B measurements).  Same arithmetic and
+ * summation order: bit-identical results.  Returns the previous setting. */
+int sgnn_conv_set_unrolled(int on);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,

@@ -23,14 +23,22 @@ g = Grid(coords_from_locs(data['input'][0], dev))
 tab = g.subm_table()
 rules = int((tab.view(27, g.ld)[:, :g.n] >= 0).sum().item())
 print('sites %d  rules %d (R/N %.2f)' % (g.n, rules, rules / g.n))
-out = torch.zeros(g.ld + 256, device=dev)
+out = torch.zeros(17 * (g.ld + 512) + 1024, device=dev)
 names = {0: '64 B rows, conv (MFMA-operand) mapping, b128', 1: '64 B rows, row-contiguous mapping, b128',
          2: '64 B rows, row-contiguous + 4 ds_bpermute', 3: '64 B rows, row-contiguous + LDS write/read b128',
-         4: '32 B rows, conv mapping, b64', 5: '32 B rows, row-contiguous mapping, b128 (2 instr / 64 rows)'}
+         4: '32 B rows, conv mapping, b64', 5: '32 B rows, row-contiguous mapping, b128 (2 instr / 64 rows)',
+         6: '64 B rows, row-contiguous LDS-DMA + ds_read_b128, 4 waves/WG', 7: 'the same, 8 waves/WG',
+         10: 'conv loop: 1 offset in flight, no MFMA, 20 waves/CU', 11: 'conv loop: 2 offsets in flight, no MFMA',
+         12: 'conv loop: 3 offsets in flight, no MFMA', 13: 'conv loop: 1 offset in flight + 16 MFMA/offset',
+         14: 'conv loop: 2 offsets in flight + 16 MFMA/offset', 15: 'conv loop: 3 offsets in flight + 16 MFMA/offset',
+         16: 'conv loop: 4 offsets in flight + 16 MFMA/offset',
+         17: 'conv loop: 1 in flight + 16 MFMA + weights staged in LDS', 18: 'conv loop: 1 in flight + 16 MFMA + 64 B/row store',
+         19: 'conv loop: 1 in flight + 16 MFMA + LDS weights + store',
+         8: '64 B rows, conv mapping, offsets walked dx-major (no shared lines in flight)'}
 ref = {}
 xs = {16: torch.randn(g.n, 16, device=dev), 8: torch.randn(g.n, 8, device=dev)}
-for mode in range(6):
-    c = 16 if mode < 4 else 8
+for mode in (10, 13, 17, 18, 19):
+    c = 8 if mode in (4, 5) else 16
     x = xs[c]
     stream = torch.cuda.current_stream().cuda_stream
     call = lambda: lib.gather_bench(x.data_ptr(), g.n, c, tab.data_ptr(), g.ld, 27, g.n, out.data_ptr(), mode, stream)
@@ -46,7 +54,7 @@ for mode in range(6):
     us = e0.elapsed_time(e1) / args.iters * 1e3
     s = float(out.double().sum())
     key = c
-    if key in ref:
+    if key in ref and mode < 10:
         assert abs(s - ref[key]) <= 1e-4 * max(1.0, abs(ref[key])), (mode, s, ref[key])   # every mapping loads the same rows
     ref.setdefault(key, s)
     print('mode %d  %-62s %7.1f us   %6.2f TB/s gathered (rules only: %6.2f)   %5.1f cycles/gather-instr/CU @2.4GHz'

@@ -422,6 +422,17 @@ SGNN_EXPORT int64_t sgnn_conv_set_small_rows(int64_t rows) {
   return prev;
 }
 
+// conv_unrolled.hip: the large-level kernel as straight-line code (plain rulebook walk, K = 27 / 8)
+bool sgnn_conv_u_supported(int cin, int cout, int K);
+bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                        int64_t n_out, int cout, float *y, int flags, int in_shift, const ConvEpi &epi, hipStream_t s);
+static int g_unrolled_kernel = 1;   // sgnn_conv_set_unrolled: 0 = the looped kernel on every level (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_unrolled(int on) {
+  const int prev = g_unrolled_kernel;
+  g_unrolled_kernel = on ? 1 : 0;
+  return prev;
+}
+
 static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
 SGNN_EXPORT int sgnn_conv_set_small(int on) {
   const int prev = g_small_kernel;
@@ -489,6 +500,8 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                          w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
     done = true;                                                                                        \
   } while (0)
+  if (plain && !small && g_unrolled_kernel && sgnn_conv_u_supported(cin, cout, K))
+    done = sgnn_conv_u_launch(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, epi, s);
 #define X(CI, CO) \
   if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)

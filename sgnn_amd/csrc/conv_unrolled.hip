@@ -1,0 +1,160 @@
+// Sparse convolution, large levels, plain rulebook walk: the output-stationary MFMA kernel of conv.hip (k_conv_fwd) as
+// STRAIGHT-LINE code — K (27 or 8 offsets) is a template parameter and the offset loop is fully unrolled.
+//
+// Serves scn.SubmanifoldConvolution / scn.Convolution forward and both data gradients on levels above ~40 k rows
+// (torch/model.py:32,38,40,44,179,186,254).  Same arithmetic, same summation order as k_conv_fwd: bit-identical results.
+//
+// Why a second form of the same kernel (profiles/r04b_gather3.txt, scripts/kernels/gather_bench.hip k_loop): the looped
+// kernel spends 68-75 us on the 366 k-row <16,16> level although its gathers alone take 42-46 us and its MFMAs 28-32 us,
+// and a loop that does nothing but those gathers and 16 MFMAs per offset runs in 49 us.  What the loop form adds:
+//  * every loop back-edge is a merge point for hipcc's s_waitcnt insertion: the first load use after it waits vmcnt(0), i.e.
+//    the rows gathered for the NEXT offsets are drained once per trip (2 offsets);
+//  * the wave's rule entries are loaded inside the loop, three offsets ahead, interleaved with the gathers they feed;
+//  * tail handling (clamped offsets, dropped gathers) costs loads that are thrown away.
+// Straight-line code has no merge points: every wait is a counted vmcnt(n) that covers exactly the register set about to
+// be used.  The wave's K rule entries are loaded up front (K VGPRs, one coalesced 256-byte load each), the rows of offset
+// k + 1 are gathered while the MFMAs of offset k run.  Weights are staged KC offsets at a time (<= 32 KiB of LDS) between
+// two barriers at compile-time positions of the unrolled sequence; ordinary loads in flight survive a barrier.
+#include "conv_common.h"
+
+template <int CIN, int COUT, int K>
+__global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
+                                                   const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
+                                                   int flags, int in_shift, ConvEpi epi) {
+  using C = ConvCfg<CIN, COUT>;
+  constexpr int V = C::V, CINP = C::CINP, NT = C::NT, M = 4;
+  constexpr int KC = C::KC < K ? C::KC : K;            // offsets per staged weight chunk
+  __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  unsigned nwg = gridDim.x;
+  if (epi.n_dev) {   // capacity mode (see k_conv_fwd): the live workgroups share the tiles like an exact-size launch
+    n_out = sgnn_dyn_n(n_out, epi.n_dev);
+    nwg = (unsigned)((n_out + 255) / 256);
+    if (blockIdx.x >= nwg) {
+      if (epi.stats)
+        for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
+      return;
+    }
+  }
+  const unsigned tile = sgnn_xcd_tile(blockIdx.x, nwg);
+  const int64_t row0 = ((int64_t)tile * 4 + wave) * 64;
+  const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
+
+  const uint32_t ldx4 = (uint32_t)epi.ldx * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u, ld4 = (uint32_t)ld * 4u;
+
+  int32_t idx[K];      // the wave's rule entries of every offset, loaded up front (padding rows of the table hold -1)
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    idx[k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
+
+  int perm[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) perm[m] = (m * 16 + r) * 4;
+  f32x4 acc[M][NT];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float a[2][M][V];    // ping-pong register sets: rows of offset k in a[k & 1]
+  auto gather = [&](int k) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], idx[k]);
+      buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[k & 1][m]);
+    }
+  };
+  auto stage = [&](int k0) {   // weight slices k0 .. k0 + KC - 1 as wl[kk][n][c]
+    __syncthreads();           // every wave is done with the previous chunk
+    const int kc = (K - k0) < KC ? (K - k0) : KC;
+    for (int e = tid; e < kc * C::PER_K; e += 256) {
+      const int c = e % CINP, n = (e / CINP) % (NT * 16), ko = e / C::PER_K;
+      float v = 0.f;
+      if (c < CIN && n < COUT) {
+        const int ks = flip ? (K - 1 - (k0 + ko)) : (k0 + ko);
+        v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
+      }
+      wl[e] = v;
+    }
+    __syncthreads();
+  };
+  auto mma = [&](int k) {
+    const int kk = k % KC;
+    float b[NT][V];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
+#pragma unroll
+      for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
+    }
+#pragma unroll
+    for (int s = 0; s < V; ++s)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        float av = a[k & 1][m][s];
+        if constexpr (CINP != CIN)       // the last quarter reads past the row end: those slots must be exact zeros
+          if (3 * V + s >= CIN) av = (q == 3) ? 0.f : av;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt][s], acc[m][nt], 0, 0, 0);
+      }
+  };
+
+  gather(0);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k % KC == 0) stage(k);               // compile-time positions (the loop is fully unrolled)
+    if (k + 1 < K) gather(k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  static_assert(sizeof(wl) >= 4 * 2 * NT * 16 * sizeof(double), "weight tile too small for the statistics scratch");
+  conv_epilogue<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, reinterpret_cast<double *>(wl), x, blockIdx.x);
+}
+
+// Shapes: where the straight-line form wins on the 366 k-row level (profiles/r04c_conv_ab.txt, same box, bit-identical
+// outputs): the wide-row layers <26,16> 132 -> 114 us, <16,26> 142 -> 119 us (and their 30 / 34-channel siblings), every
+// stride-2 (8-offset) walk 5-10 %.  It LOSES on the narrow square layers (<16,16> 63-75 -> 72-90 us, <8,8>, <12,12>) whatever
+// the register budget (K rule registers: 4 waves per SIMD; a rolling window: 5 waves, slower still) — those keep the looped kernel.
+#define CONV_U_CASES_27(X) X(34, 16) X(16, 34) X(30, 16) X(16, 30) X(26, 16) X(16, 26)
+#define CONV_U_CASES_8(X) X(8, 8) X(8, 12) X(12, 8) X(12, 12) X(12, 16) X(16, 12) X(16, 16)
+
+bool sgnn_conv_u_supported(int cin, int cout, int K) {
+#define X(CI, CO) \
+  if (K == 27 && cin == CI && cout == CO) return true;
+  CONV_U_CASES_27(X)
+#undef X
+#define X(CI, CO) \
+  if (K == 8 && cin == CI && cout == CO) return true;
+  CONV_U_CASES_8(X)
+#undef X
+  return false;
+}
+
+// launch over n_out rows (256-row workgroups; capacity mode through epi.n_dev); false: shape not compiled
+bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
+                        int64_t n_out, int cout, float *y, int flags, int in_shift, const ConvEpi &epi, hipStream_t s) {
+  const unsigned grid = (unsigned)((n_out + 255) / 256);
+#define X(CI, CO)                                                                                                        \
+  if (K == 27 && cin == CI && cout == CO) {                                                                              \
+    SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    return true;                                                                                                         \
+  }
+  CONV_U_CASES_27(X)
+#undef X
+#define X(CI, CO)                                                                                                        \
+  if (K == 8 && cin == CI && cout == CO) {                                                                               \
+    SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);  \
+    return true;                                                                                                         \
+  }
+  CONV_U_CASES_8(X)
+#undef X
+  return false;
+}

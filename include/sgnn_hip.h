@@ -445,6 +445,18 @@ int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, c
  * setting.
  * ------------------------------------------------------------------------- */
 int sgnn_prog_set_fusion(int on);
+/* BatchNormReLU -> convolution (torch/model.py:37-42, 181, 187, 256: every scn.BatchNormReLU in front of a
+ * SubmanifoldConvolution / Convolution).  sgnn_prog_set_bn_fold(1): when the convolution is the only reader of the
+ * BatchNorm output, the executor launches no apply pass — the convolution (forward, and its weight gradient in backward)
+ * reads the BatchNorm's INPUT rows and applies (x - mean) * invstd * gamma + beta and the ReLU in its gather, rows of missing
+ * rules staying zero.  2 = the exact A/B reference of 1: the same statistics (finalised by the same kernel), an apply pass
+ * and the convolution on the stored rows — bit-identical results.  0 (DEFAULT) = every BatchNorm applies itself (on small
+ * levels its apply kernel also finalises the statistics).  The fold is built and tested but measured neutral (it moves an
+ * HBM streaming pass into the VALU work of two gather-bound kernels), hence not the default.
+ * Returns the previous setting. */
+int sgnn_prog_set_bn_fold(int on);
+/* rows class size from which the fold applies (default 0 = every level); returns the previous value */
+int64_t sgnn_prog_set_bn_fold_rows(int64_t rows);
 /* mode 0: floats of the gradient arena sgnn_prog_backward needs (buffers + per-op areas + backward scratch);
  * mode 1: floats of the arena sgnn_prog_forward needs (buffers + per-op areas);
  * mode 2: the same for an INFERENCE call (sgnn_prog_forward with training = 2): no backward pass may follow, so a

@@ -13,6 +13,9 @@
 
 #define BN_MAX_BLOCKS 2048
 #define BN_FLUSH 2
+#define BN_U 2            // row groups a thread of the apply passes loads before it uses the first one
+#define BN_FUSE_BLOCKS 4096
+#define BN_FUSE_MAXC 64
 
 struct BnGeom {
   int vec;   // 4 or 1 floats per thread-column
@@ -243,9 +246,6 @@ __global__ __launch_bounds__(256) void k_bn_eval_stats(const float *__restrict__
 // Small levels (few block partials, C <= BN_FUSE_MAXC): the apply kernels finalise the statistics themselves — every
 // workgroup sums the short partial table in the same fixed order into LDS, workgroup 0 also stores the results the
 // later passes / the caller need — and the separate finalize launch disappears.
-#define BN_U 2            // row groups a thread loads before it uses the first one
-#define BN_FUSE_BLOCKS 4096
-#define BN_FUSE_MAXC 64
 
 struct BnFuse {
   const double *partial;   // NULL: statistics come from the mean/invstd (or coef) arrays
@@ -360,11 +360,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
       if (r >= n) break;
       float yv[VEC];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const float xh = (xv[u][v] - km[v]) * ki[v];
-        const float t = fmaf(xh, kg[v], kb[v]);
-        yv[v] = t > 0.f ? t : t * leak;
-      }
+      for (int v = 0; v < VEC; ++v) yv[v] = sgnn_bn_act(xv[u][v], km[v], ki[v], kg[v], kb[v], leak);
       store_vec<VEC>(y + r * ldy + col * VEC, yv);
     }
   }
@@ -462,6 +458,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 // Finalising inside the apply kernels makes EVERY apply workgroup re-sum the partial table (L2-resident): worth it as
 // long as that re-read stays small next to a separate launch (~5 us of GPU time + ~3 us of host time per finalize, ~70
 // of them per training step).  Budget: 48 MB of partial reads per apply launch.
+// (A finalise kernel made of ONE 1024-thread workgroup that reads the partial table in coalesced rows was measured against
+//  the c single-channel workgroups of k_bn_finalize_fwd / _bwd: +3.8 us per launch inside the step, 6.64 vs 6.51 ms per step
+//  — one CU cannot pull a 366 KB table as fast as 16 can; dropped.)
 static bool bn_fuse_ok(int64_t nblk, int c, int apply_grid) {
   return c <= BN_FUSE_MAXC && nblk <= BN_FUSE_BLOCKS && nblk * (int64_t)apply_grid * 2 * c * (int64_t)sizeof(double) <= (48ll << 20);
 }
@@ -478,8 +477,12 @@ static int bn_apply_grid(int64_t n, const BnGeom &g) {
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
                      float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
-                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev,
+                     int skip_apply) {
+  // skip_apply bit 0: statistics only — the consuming convolution normalises the rows in its gather (BnPre); bit 1: finalise
+  // in the separate kernel even where the apply pass could (the exact A/B reference of the folded path: same statistics)
   hipStream_t s = (hipStream_t)stream;
+  const bool no_apply = (skip_apply & 1) != 0, own_finalize = skip_apply != 0;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
   if (ldx <= 0) ldx = c;
@@ -507,7 +510,7 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
                            g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
       partial = (const double *)ws;
     }
-    if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
+    if (!own_finalize && bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
       fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
       SGNN_LAUNCH(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
@@ -519,7 +522,7 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
     SGNN_LAUNCH(k_bn_eval_stats, dim3(1), dim3(256), 0, s, (const float *)running_mean,
                        (const float *)running_var, c, eps, save_mean, save_invstd);
   }
-  if (n > 0) {
+  if (n > 0 && !no_apply) {
     SGNN_CHECK_ARG(x && y);
     const int grid = bn_apply_grid(n, g);
     if (g.vec == 4)

@@ -26,7 +26,7 @@
 static int g_small_grid = 160;             // ~40 k rows (sgnn_conv_set_small_rows: measurements)
 
 // EX = false: plain rulebook walk (ex is ignored; keeps the register budget of the hot instantiations)
-template <int CIN, int COUT, int M, bool EX>
+template <int CIN, int COUT, int M, bool EX, bool PRE = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *y, int flags,
@@ -92,16 +92,29 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
       return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
     }
   };
-  auto gather = [&](int32_t iv, float(&a)[M][V]) {
+  // BatchNormReLU of the producing layer folded into this gather (ConvEpi.pre): the lane's V channels' constants
+  // (PRE is a template parameter: the constants and the per-tile flags cost 4 V + M registers, which the plain
+  //  instantiations — every launch whose input is not a folded BatchNorm — must not pay in occupancy)
+  constexpr int PV = PRE ? V : 1, PM = PRE ? M : 1;
+  float pm[PV], pi[PV], pg[PV], pb[PV];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+      const int c = q * V + s;
+      const bool okc = c < CIN;
+      pm[s] = okc ? epi.pre.mean[c] : 0.f;
+      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
+      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
+      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
+    }
+  }
+  // ok[m]: 1.0 where tile m's rule exists (a missing rule's row must stay zero after the normalisation)
+  auto gather = [&](int32_t iv, float(&a)[M][V], float(&ok)[PM]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
+      if constexpr (PRE) ok[m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[m]);
-      if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
-#pragma unroll
-        for (int s = 0; s < V; ++s)
-          if (3 * V + s >= CIN) a[m][s] = (q == 3) ? 0.f : a[m][s];
-      }
     }
   };
   auto stage = [&](int k) {  // (re)stage KC weight slices as wl[kk][n][c]; in-flight global loads stay in flight
@@ -120,13 +133,26 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     }
     __syncthreads();
   };
-  auto mma = [&](int kk, const float(&a)[M][V]) {
+  auto mma = [&](int kk, float(&a)[M][V], const float(&ok)[PM]) {
     float b[NT][V];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
 #pragma unroll
       for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
+    }
+    if constexpr (PRE) {
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int s = 0; s < V; ++s) a[m][s] = sgnn_bn_act(a[m][s], pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * ok[m];
+    }
+    if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+          if (3 * V + s >= CIN) a[m][s] = (q == 3) ? 0.f : a[m][s];
     }
 #pragma unroll
     for (int s = 0; s < V; ++s)
@@ -148,57 +174,57 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   if constexpr (V <= 4 && (NT >= 2 || M == 1)) {
     // narrow rows, several output tiles (long MFMA phase per offset): three register sets, rows gathered TWO offsets
     // ahead of their MFMAs.  Measured at N = 366 k: <16,48> 228 -> 187 us; <16,16> (NT = 1) is 3 % faster with two sets
-    float a0[M][V], a1[M][V], a2[M][V];
+    float a0[M][V], a1[M][V], a2[M][V], o0[PM], o1[PM], o2[PM];
     for (int k0 = 0; k0 < K; k0 += KC) {      // one pass per staged weight chunk (a single one for the 3x3x3 16->16 layers)
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       stage(k0);
-      gather(idx_at(k0), a0);
-      gather(idx_at(k0 + 1), a1);
+      gather(idx_at(k0), a0, o0);
+      gather(idx_at(k0 + 1), a1, o1);
       int32_t iv2 = idx_at(k0 + 2), iv3 = idx_at(k0 + 3), iv4 = idx_at(k0 + 4);
       int kk = 0;
       for (; kk + 2 < kc; kk += 3) {
         // sched_barrier: the machine scheduler otherwise sinks the gathers to half an offset before their use
-        gather(iv2, a2);                        // rows of offset k0+kk+2
+        gather(iv2, a2, o2);                    // rows of offset k0+kk+2
         iv2 = idx_at(k0 + kk + 5);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk, a0);
+        mma(kk, a0, o0);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv3, a0);                        // rows of offset k0+kk+3 (dropped if that is past this chunk)
+        gather(iv3, a0, o0);                    // rows of offset k0+kk+3 (dropped if that is past this chunk)
         iv3 = idx_at(k0 + kk + 6);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 1, a1);
+        mma(kk + 1, a1, o1);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv4, a1);                        // rows of offset k0+kk+4
+        gather(iv4, a1, o1);                    // rows of offset k0+kk+4
         iv4 = idx_at(k0 + kk + 7);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 2, a2);
+        mma(kk + 2, a2, o2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < kc) mma(kk, a0);
-      if (kk + 1 < kc) mma(kk + 1, a1);
+      if (kk < kc) mma(kk, a0, o0);
+      if (kk + 1 < kc) mma(kk + 1, a1, o1);
     }
   } else {
-    float a0[M][V], a1[M][V];
+    float a0[M][V], a1[M][V], o0[PM], o1[PM];
     for (int k0 = 0; k0 < K; k0 += KC) {
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       stage(k0);
       int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
-      gather(idx_at(k0), a0);
+      gather(idx_at(k0), a0, o0);
       int kk = 0;
       for (; kk + 1 < kc; kk += 2) {
-        gather(iv1, a1);                        // rows of offset k0+kk+1
+        gather(iv1, a1, o1);                    // rows of offset k0+kk+1
         const int32_t iv3 = idx_at(k0 + kk + 3);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk, a0);
+        mma(kk, a0, o0);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv2, a0);                        // rows of offset k0+kk+2 (dropped if that is past this chunk)
+        gather(iv2, a0, o0);                    // rows of offset k0+kk+2 (dropped if that is past this chunk)
         iv1 = iv3;
         iv2 = idx_at(k0 + kk + 4);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 1, a1);
+        mma(kk + 1, a1, o1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < kc) mma(kk, a0);
+      if (kk < kc) mma(kk, a0, o0);
     }
   }
 
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 // accumulators, and the four partial tiles are summed through LDS.  Same arithmetic per (row, offset); the summation
 // order over offsets differs from the big kernel (fp32 round-off only).  Plain rulebook walk only.
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool PRE = false>
 __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x, int64_t n_in,
                                                    const float *__restrict__ w, const int32_t *__restrict__ table,
                                                    int64_t ld, int K, int64_t n_out, float *y, int flags, int in_shift,
@@ -259,12 +285,18 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
   // second round trip: every gathered row quarter + (independent of the rules) the weight fragments of these offsets
   float a[KW][V];
 #pragma unroll
-  for (int kk = 0; kk < KW; ++kk) {
-    buf_load_floats<V>(rs_x, (uint32_t)id[kk] * ldx4 + (uint32_t)(q * V * 4), a[kk]);
-    if constexpr (CINP != CIN) {
+  for (int kk = 0; kk < KW; ++kk) buf_load_floats<V>(rs_x, (uint32_t)id[kk] * ldx4 + (uint32_t)(q * V * 4), a[kk]);
+  constexpr int PV = PRE ? V : 1;     // PRE: BatchNormReLU of the producing layer folded into the gather (BnPre)
+  float pm[PV], pi[PV], pg[PV], pb[PV];
+  if constexpr (PRE) {
 #pragma unroll
-      for (int s = 0; s < V; ++s)
-        if (3 * V + s >= CIN) a[kk][s] = (q == 3) ? 0.f : a[kk][s];
+    for (int s = 0; s < V; ++s) {
+      const int c = q * V + s;
+      const bool okc = c < CIN;
+      pm[s] = okc ? epi.pre.mean[c] : 0.f;
+      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
+      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
+      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
     }
   }
   float b[KW][NT][V];
@@ -284,6 +316,21 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
         b[kk][nt][s] = v;
       }
     }
+  }
+  if constexpr (PRE) {
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      const float okr = id[kk] >= 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int s = 0; s < V; ++s) a[kk][s] = sgnn_bn_act(a[kk][s], pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * okr;
+    }
+  }
+  if constexpr (CINP != CIN) {
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+      for (int s = 0; s < V; ++s)
+        if (3 * V + s >= CIN) a[kk][s] = (q == 3) ? 0.f : a[kk][s];
   }
   f32x4 acc[2][NT];
 #pragma unroll
@@ -373,7 +420,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
                                                          const float *__restrict__ w, int K,
                                                          const int32_t *__restrict__ table, int64_t ld,
                                                          int64_t n_out, int cout, float *__restrict__ y,
-                                                         int flags, int in_shift, ConvEx ex, const int64_t *n_dev) {
+                                                         int flags, int in_shift, ConvEx ex, const int64_t *n_dev,
+                                                         BnPre pre) {
   n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_out * ex.groups * cout) return;
@@ -391,7 +439,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
     const int ks = flip ? (K - 1 - k) : k;
     for (int c = 0; c < cin; ++c) {
       const float wv = transpose ? w[((int64_t)ks * cout + n) * cin + c] : w[((int64_t)ks * cin + c) * cout + n];
-      acc = fmaf(xr[c], wv, acc);
+      float xv = xr[c];
+      if (pre.mean) xv = sgnn_bn_act(xv, pre.mean[c], pre.invstd[c], pre.gamma ? pre.gamma[c] : 1.f, pre.beta ? pre.beta[c] : 0.f, pre.leak);
+      acc = fmaf(xv, wv, acc);
     }
   }
   y[t] = acc;
@@ -467,6 +517,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   if (epi.ld_bnx <= 0) epi.ld_bnx = cout;
   const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
   const bool has_epi = epi.ldx != cin || epi.ldy != cout || epi.addend || epi.stats;
+  SGNN_CHECK_ARG(!epi.pre.mean || epi.pre.invstd);
   SGNN_CHECK_ARG(epi.ldx >= cin && epi.ldx <= 1024 && epi.ldy >= cout && epi.ldy <= 1024 && epi.ld_add >= cout &&
                  epi.ld_add <= 1024 && epi.ld_bnx >= cout && epi.ld_bnx <= 1024);
   SGNN_CHECK_ARG(epi.stats >= 0 && epi.stats <= 2 && (!epi.stats || (plain && epi.partial)));
@@ -487,29 +538,47 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   const bool small = grid4 < CONV_SMALL_GRID;   // too few 256-row workgroups for 256 CUs: 64-row workgroups
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
-#define LAUNCH_FWD(CI, CO, EXV)                                                                         \
+#define LAUNCH_FWD_P(CI, CO, EXV, PREV)                                                                 \
   do {                                                                                                  \
     if (small && !EXV && K <= 28 && (g_small_kernel || epi.stats))                                      \
-      SGNN_LAUNCH((k_conv_small<CI, CO>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,  \
+      SGNN_LAUNCH((k_conv_small<CI, CO, PREV>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,   \
                          x, n_in, w, table, ld, K, n_out, y, flags, in_shift, epi);                     \
     else if (small)                                                                                     \
-      SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table, \
+      SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV, PREV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table,  \
                          ld, K, n_out, y, flags, in_shift, ex, epi);                                    \
     else                                                                                                \
-      SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in,   \
+      SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>), dim3(grid4), dim3(256), 0, s, x, n_in,    \
                          w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
     done = true;                                                                                        \
   } while (0)
+// (the BatchNorm-folding instantiations exist for the shapes the planner folds: BN_FOLD_* lists below)
+#define LAUNCH_FWD(CI, CO, EXV)                  \
+  do {                                           \
+    LAUNCH_FWD_P(CI, CO, EXV, false);            \
+  } while (0)
   if (plain && !small && g_unrolled_kernel && sgnn_conv_u_supported(cin, cout, K))
     done = sgnn_conv_u_launch(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, epi, s);
-#define X(CI, CO) \
-  if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
+  const bool has_pre = epi.pre.mean != nullptr;
+#define X(CI, CO)                                                  \
+  if (!done && plain && cin == CI && cout == CO) {                 \
+    if (has_pre)                                                   \
+      LAUNCH_FWD_P(CI, CO, false, true);                           \
+    else                                                           \
+      LAUNCH_FWD_P(CI, CO, false, false);                          \
+  }
   CONV_FWD_CASES(X)
 #undef X
 #define X(CI, CO) \
-  if (!done && !plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, true);
+  if (!done && !plain && !has_pre && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, true);
   CONV_EX_CASES(X)
 #undef X
+  // the up-sampling convolution behind a folded BatchNormReLU (prog.hip expand_shape_ok)
+  if (!done && !plain && has_pre && cin == 48 && cout == 16) LAUNCH_FWD_P(48, 16, true, true);
+  if (!done && !plain && has_pre && cin == 24 && cout == 8) LAUNCH_FWD_P(24, 8, true, true);
+  if (!done && !plain && has_pre) {
+    sgnn_set_error("sgnn_conv_fwd: no BatchNorm-folding kernel for the grouped (%d, %d) walk", cin, cout);
+    return SGNN_EINVAL;
+  }
   if (!done) {
     if (has_epi) {
       sgnn_set_error("sgnn_conv_fwd_epi: strided / fused epilogues need one of the compiled (cin, cout) shapes, got (%d, %d)", cin, cout);
@@ -517,7 +586,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
     }
     const int64_t total = n_out * groups * cout;
     SGNN_LAUNCH(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
-                       table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev);
+                       table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev, epi.pre);
   }
   sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
@@ -654,12 +723,12 @@ struct DwCfg {
   static constexpr int KPB = (MT * NT == 1) ? 9 : ((MT * NT <= 3) ? 5 : 3);
 };
 
-template <int CIN, int COUT, bool EX, int KPBT = 0>
+template <int CIN, int COUT, bool EX, int KPBT = 0, bool PRE = false>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift, ConvEx ex, int64_t ldx,
-                                                int64_t ld_dy, const int64_t *n_dev) {
+                                                int64_t ld_dy, const int64_t *n_dev, BnPre pre) {
   if (n_dev) {   // capacity mode: spread the LIVE rows over all row blocks of the (capacity-sized) launch
     n_out = sgnn_dyn_n(n_out, n_dev);
     const int64_t per = (n_out + gridDim.x - 1) / gridDim.x;
@@ -710,16 +779,43 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
   // wide (16 B / lane) gathers like the forward kernel, transposed through LDS so that the site index lands on
   // the MFMA contraction axis: A[i = ci][kslot = j] = x[table[k][R + j]][ci], B[kslot = j][co] = dy[R + j][co]
-  auto gather = [&](int32_t iv, float(&g)[4][V]) {
+  // the convolution's input rows may be the INPUT of a folded BatchNormReLU (BnPre): the gather then normalises them, with
+  // the rows of missing rules kept at zero (ok[m]); applied where the rows are written to LDS (norm_rows), not at the load
+  // (PRE is a template parameter: the plain instantiations do not pay its registers)
+  constexpr int PV = PRE ? V : 1, PM = PRE ? 4 : 1;
+  float pm[PV], pi[PV], pg[PV], pb[PV];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+      const int c = q * V + s;
+      const bool okc = c < CIN;
+      pm[s] = okc ? pre.mean[c] : 0.f;
+      pi[s] = okc ? pre.invstd[c] : 0.f;
+      pg[s] = okc ? (pre.gamma ? pre.gamma[c] : 1.f) : 0.f;
+      pb[s] = okc ? (pre.beta ? pre.beta[c] : 0.f) : 0.f;
+    }
+  }
+  auto gather = [&](int32_t iv, float(&g)[4][V], float(&ok)[PM]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute((m * 16 + i16) * 4, iv);
+      if constexpr (PRE) ok[m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), g[m]);
-      if constexpr (CINP != CIN) {
+    }
+  };
+  auto norm_rows = [&](float(&g)[4][V], const float(&ok)[PM]) {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < V; ++s) g[m][s] = sgnn_bn_act(g[m][s], pm[s], pi[s], pg[s], pb[s], pre.leak) * ok[m];
+    }
+    if constexpr (CINP != CIN) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int s = 0; s < V; ++s)
           if (3 * V + s >= CIN) g[m][s] = (q == 3) ? 0.f : g[m][s];
-      }
     }
   };
   auto mma_chunk = [&](int kk, const float(&b)[16][NT]) {
@@ -793,12 +889,13 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
     if constexpr (MT * NT == 1) {
       // narrow layers: little MFMA work per gather -> prefetch the next offset's rows (ping-pong registers)
-      float g0[4][V], g1[4][V];
-      gather(idxv[0], g0);
+      float g0[4][V], g1[4][V], k0_[PM], k1_[PM];
+      gather(idxv[0], g0, k0_);
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; kk += 2) {
-        if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1);          // compile-time conditions only
+        if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1, k1_);          // compile-time conditions only
         __builtin_amdgcn_sched_barrier(0);
+        norm_rows(g0, k0_);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           float *p = xs + (m * 16 + i16) * CINP + q * V;
@@ -808,8 +905,9 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
         mma_chunk(kk, b);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < DW_KPB) {
-          if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0);
+          if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0, k0_);
           __builtin_amdgcn_sched_barrier(0);
+          norm_rows(g1, k1_);
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             float *p = xs + (m * 16 + i16) * CINP + q * V;
@@ -822,10 +920,11 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       }
     } else {
       // wide layers: 3+ MFMA tiles per gathered row hide the latency; one register set keeps occupancy up
-      float g0[4][V];
+      float g0[4][V], k0_[PM];
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; ++kk) {
-        gather(idxv[kk], g0);
+        gather(idxv[kk], g0, k0_);
+        norm_rows(g0, k0_);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           float *p = xs + (m * 16 + i16) * CINP + q * V;
@@ -930,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
                                                         const float *__restrict__ dy, int cout,
                                                         const int32_t *__restrict__ table, int64_t ld, int K,
                                                         int64_t n_out, float *__restrict__ dw, int in_shift,
-                                                        ConvEx ex, const int64_t *n_dev) {
+                                                        ConvEx ex, const int64_t *n_dev, BnPre pre) {
   n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)ex.groups * K * cin * cout) return;
@@ -939,9 +1038,11 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
   float s = 0.f;
   for (int64_t j = 0; j < n_out; ++j) {
     const int32_t id = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + j];
-    if (id >= 0)
-      s = fmaf(x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin + ci],
-               dy[(j * ex.groups + grp) * cout + co], s);
+    if (id >= 0) {
+      float xv = x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin + ci];
+      if (pre.mean) xv = sgnn_bn_act(xv, pre.mean[ci], pre.invstd[ci], pre.gamma ? pre.gamma[ci] : 1.f, pre.beta ? pre.beta[ci] : 0.f, pre.leak);
+      s = fmaf(xv, dy[(j * ex.groups + grp) * cout + co], s);
+    }
   }
   dw[e] = s;
 }
@@ -986,8 +1087,10 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
 int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
                               const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
-                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
+                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev, const BnPre *pre_in) {
   SGNN_CHECK_ARG(ldx >= cin && ldx <= 1024 && ld_dy >= cout && ld_dy <= 1024);
+  const BnPre pre = pre_in ? *pre_in : BnPre{nullptr, nullptr, nullptr, nullptr, 0.f};
+  SGNN_CHECK_ARG(!pre.mean || pre.invstd);
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
                  in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
                  table_rows <= 64 && (kmap || table_rows >= K));
@@ -1009,7 +1112,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
   const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
-#define LAUNCH_DW(CI, CO, EXV)                                                                             \
+#define LAUNCH_DW(CI, CO, EXV, PREV)                                                                       \
   do {                                                                                                     \
     if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, groups * K, cin, cout)) {                   \
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
@@ -1021,16 +1124,16 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       /* small level of a narrow layer: 256 rows x 9 offsets per workgroup leaves most CUs idle and makes */ \
       /* every wave walk 9 dependent gather rounds -> one offset per workgroup (same sums, same order)     */ \
       if (n_out < DW_FINE_ROWS && g_small_kernel)                                                          \
-        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
-                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 1, PREV>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
+                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev, pre); \
       else                                                                                                 \
-        SGNN_LAUNCH((k_conv_dw<CI, CO, false>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 0, PREV>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
                            dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift,  \
-                           ex, ldx, ld_dy, n_dev);                                                         \
+                           ex, ldx, ld_dy, n_dev, pre);                                                    \
     } else {                                                                                               \
-      SGNN_LAUNCH((k_conv_dw<CI, CO, EXV>),                                                         \
+      SGNN_LAUNCH((k_conv_dw<CI, CO, EXV, 0, PREV>),                                                \
                          dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, \
-                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
+                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev, pre); \
     }                                                                                                      \
     sgnn_prof_end_launch(prof, s);                                                                         \
     if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
@@ -1041,19 +1144,32 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     }                                                                                                      \
     done = true;                                                                                           \
   } while (0)
-#define X(CI, CO) \
-  if (!done && plain && cin == CI && cout == CO) LAUNCH_DW(CI, CO, false);
+  const bool has_pre = pre.mean != nullptr;
+#define X(CI, CO)                                  \
+  if (!done && plain && cin == CI && cout == CO) { \
+    if (has_pre)                                   \
+      LAUNCH_DW(CI, CO, false, true);              \
+    else                                           \
+      LAUNCH_DW(CI, CO, false, false);             \
+  }
   CONV_DW_CASES(X)
 #undef X
-  if (!done && !plain && cin == 48 && cout == 16) LAUNCH_DW(48, 16, true);
-  if (!done && !plain && cin == 24 && cout == 8) LAUNCH_DW(24, 8, true);
+#define X(CI, CO)                                   \
+  if (!done && !plain && cin == CI && cout == CO) { \
+    if (has_pre)                                    \
+      LAUNCH_DW(CI, CO, true, true);                \
+    else                                            \
+      LAUNCH_DW(CI, CO, true, false);               \
+  }
+  X(48, 16) X(24, 8)
+#undef X
   if (!done) {
     if (ldx != cin || ld_dy != cout) {
       sgnn_set_error("sgnn_conv_bwd_weight: strided rows need one of the compiled (cin, cout) shapes, got (%d, %d)", cin, cout);
       return SGNN_EINVAL;
     }
     SGNN_LAUNCH(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
-                       cout, table, ld, K, n_out, dw, in_shift, ex, n_dev);
+                       cout, table, ld, K, n_out, dw, in_shift, ex, n_dev, pre);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -17,7 +17,7 @@
 // two barriers at compile-time positions of the unrolled sequence; ordinary loads in flight survive a barrier.
 #include "conv_common.h"
 
-template <int CIN, int COUT, int K>
+template <int CIN, int COUT, int K, bool PRE>
 __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
                                                    const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
                                                    int flags, int in_shift, ConvEpi epi) {
@@ -61,11 +61,27 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float a[2][M][V];    // ping-pong register sets: rows of offset k in a[k & 1]
+  // BatchNormReLU of the producing layer folded into the gather (ConvEpi.pre, see BnPre): the lane's V channels' constants
+  // (a template parameter: the plain instantiations do not pay the 4 V + 2 M registers)
+  constexpr int PV = PRE ? V : 1, PM = PRE ? M : 1;
+  float pm[PV], pi[PV], pg[PV], pb[PV];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+      const int c = q * V + s;
+      const bool okc = c < CIN;
+      pm[s] = okc ? epi.pre.mean[c] : 0.f;
+      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
+      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
+      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
+    }
+  }
+  float a[2][M][V], ok[2][PM];    // ping-pong register sets: rows of offset k in a[k & 1]; ok = 1.0 where the rule exists
   auto gather = [&](int k) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], idx[k]);
+      if constexpr (PRE) ok[k & 1][m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[k & 1][m]);
     }
   };
@@ -97,6 +113,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         float av = a[k & 1][m][s];
+        if constexpr (PRE) av = sgnn_bn_act(av, pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * ok[k & 1][m];
         if constexpr (CINP != CIN)       // the last quarter reads past the row end: those slots must be exact zeros
           if (3 * V + s >= CIN) av = (q == 3) ? 0.f : av;
 #pragma unroll
@@ -144,14 +161,20 @@ bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, i
   const unsigned grid = (unsigned)((n_out + 255) / 256);
 #define X(CI, CO)                                                                                                        \
   if (K == 27 && cin == CI && cout == CO) {                                                                              \
-    SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    if (epi.pre.mean)                                                                                                    \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    else                                                                                                                 \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
     return true;                                                                                                         \
   }
   CONV_U_CASES_27(X)
 #undef X
 #define X(CI, CO)                                                                                                        \
   if (K == 8 && cin == CI && cout == CO) {                                                                               \
-    SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);  \
+    if (epi.pre.mean)                                                                                                    \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    else                                                                                                                 \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
     return true;                                                                                                         \
   }
   CONV_U_CASES_8(X)

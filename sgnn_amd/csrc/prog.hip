@@ -57,6 +57,16 @@ std::vector<int> count_readers(const View &v) {
 }
 
 bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
+// sgnn_prog_set_bn_fold(1): BatchNormReLU layers whose only reader is a convolution launch no apply pass — the convolution
+// normalises the rows in its gather (BnPre).  2 = its exact A/B reference: the same statistics (finalised in the same
+// kernel), an apply pass, the convolution on the stored rows — bit-identical results.  0 (default) = the round-3 path: the
+// apply kernel of a small level also finalises the statistics.  Measured (profiles/r04d_ab3*.txt, same box): folding all 39
+// eligible layers 6.63 vs 6.64 ms per step, folding the 9 on levels >= 40 k rows 6.61 vs 6.57 — the apply pass it removes is
+// an 8 TB/s streaming pass (8-12 us at 366 k rows) and comes back as five VALU operations per gathered value in TWO
+// gather-bound kernels (the forward convolution +4-10 us, its weight gradient), while the finalise launch stays.  Not a win:
+// built, bit-identical, tested (tests/test_gpu_bn_fold.py), off by default.
+int g_bn_fold = 0;    // 0 (default): every BatchNorm applies itself; 1: folded into the consumer's gather; 2: exact reference of 1
+int64_t g_bn_fold_min_rows = 0;           // fold only rows classes of at least this size (sgnn_prog_set_bn_fold_rows)
 
 // What the executor decides once per call, identically in forward and backward:
 //  * add_dst[i] >= 0: convolution i writes straight into the output of the AddTable right behind it (fused add);
@@ -68,13 +78,20 @@ struct Plan {
   std::vector<int> root, col;    // per buffer: storage owner and column offset inside it
   std::vector<int64_t> ld;       // per buffer: row stride in floats
   std::vector<char> join_view;   // per op: this JoinTable is in place
+  std::vector<int> bn_fold;      // per op: a BatchNorm folded into the gather of convolution bn_fold[j] (-1: applies itself)
+  std::vector<int> pre_bn;       // per op: the BatchNorm folded into this convolution's gather (-1: none)
 };
+
+// shapes of the grouped / remapped walk the up-sampling convolution uses (conv.hip CONV_EX_CASES) with a compiled weight gradient
+inline bool expand_shape_ok(int cin, int cout) { return (cin == 48 && cout == 16) || (cin == 24 && cout == 8); }
 
 
 void make_plan(const View &v, const int32_t *keep, Plan &P) {
   P.add_dst.assign(v.nops, -1);
   P.skip.assign(v.nops, 0);
   P.join_view.assign(v.nops, 0);
+  P.bn_fold.assign(v.nops, -1);
+  P.pre_bn.assign(v.nops, -1);
   P.root.resize(v.nbuf);
   P.col.assign(v.nbuf, 0);
   P.ld.resize(v.nbuf);
@@ -145,6 +162,33 @@ void make_plan(const View &v, const int32_t *keep, Plan &P) {
     P.root[o[2]] = o[3];
     P.col[o[2]] = o[6];        // cin = channels of in0
   }
+  // BatchNormReLU -> convolution: the normalise + ReLU pass moves into the convolution's gather when the convolution is the
+  // only reader of the BatchNorm output (forward: rows read once; backward: the weight gradient re-reads them the same way,
+  // the data gradient's statistics epilogue and the BatchNorm backward pass read the BatchNorm INPUT anyway)
+  // (planned whatever sgnn_prog_set_bn_fold says: with the fold switched off these layers run as its exact reference)
+  for (int j = 0; j < v.nops; ++j) {
+      const int32_t *bo = v.ops + OPW * j;
+      if (bo[0] != OP_BN) continue;
+      const int o = bo[3];
+      if (o < v.n_ext || (keep && keep[o]) || readers[o] != 1 || P.root[o] != o || last_reader[o] <= j) continue;
+      // Large levels only (the rows class runs the 256-row kernels): there the apply pass is a full read + write of the level
+      // (12-20 us at 366-600 k rows) behind a finalise launch that exists anyway.  On a small level the apply kernel finalises
+      // the statistics itself — folding would swap one launch for another (the finalise kernel) and charge the convolution and
+      // its weight gradient five VALU operations per gathered value for it: measured neutral to slightly negative
+      // (profiles/r04d_ab3b.txt), so small levels keep their apply pass.
+      if (v.lev_n && v.lev_n[bo[5]] < g_bn_fold_min_rows) continue;
+      const int i = last_reader[o];
+      const int32_t *co = v.ops + OPW * i;
+      if (P.skip[i] || co[1] != o || co[6] != bo[6]) continue;
+      bool ok = false;
+      if (co[0] == OP_CONV_SUBM || co[0] == OP_CONV_DOWN)
+        ok = sgnn_conv_epi_supported(co[6], co[7]) && dw_shape_ok(co[6], co[7]);
+      else if (co[0] == OP_EXPAND)
+        ok = expand_shape_ok(co[6], co[7]);
+      if (!ok) continue;
+      P.bn_fold[j] = i;
+      P.pre_bn[i] = j;
+    }
   for (int b = 0; b < v.nbuf; ++b) {   // nested joins: resolve to the outermost storage
     int r = b, c = 0;
     while (P.root[r] != r) {
@@ -186,6 +230,7 @@ int make_layout_infer(const View &v, const Plan &P, const int32_t *keep, Layout 
     if (o[0] == OP_CONCAT_IN) touch(o[8], i);
     if (P.add_dst[i] >= 0) touch(P.add_dst[i], i);   // fused AddTable: the convolution writes the sum buffer itself
     else touch(o[3], i);
+    if (g_bn_fold == 1 && P.pre_bn[i] >= 0) touch(v.ops[OPW * P.pre_bn[i] + 1], i);   // reads the folded BatchNorm's INPUT rows
   }
   for (int b = v.n_ext; b < v.nbuf; ++b)
     if (keep && keep[b]) last[P.root[b]] = never;
@@ -395,6 +440,18 @@ SGNN_EXPORT int sgnn_prog_defer_join(int on) {
   return prev;
 }
 
+SGNN_EXPORT int sgnn_prog_set_bn_fold(int on) {
+  const int prev = g_bn_fold;
+  g_bn_fold = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return prev;
+}
+
+SGNN_EXPORT int64_t sgnn_prog_set_bn_fold_rows(int64_t rows) {
+  const int64_t prev = g_bn_fold_min_rows;
+  g_bn_fold_min_rows = rows < 0 ? 0 : rows;
+  return prev;
+}
+
 SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
   const int prev = g_fuse ? 1 : 0;
   g_fuse = on != 0;
@@ -518,7 +575,16 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         epi.ldx = LD(in0);
         epi.ldy = LD(dst_buf);
         epi.n_dev = CNT(down ? lev + 1 : lev);
-        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
+        const float *xin = B(in0);
+        if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {     // the BatchNormReLU in front of this convolution lives in its gather: read the raw rows
+          const int jb = PL.pre_bn[i];
+          const int32_t *bo = ops + OPW * jb;
+          const float *save = arena + L.aux_off[jb];
+          epi.pre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
+          xin = B(bo[1]);
+          epi.ldx = LD(bo[1]);
+        }
+        PROG_TRY(sgnn_conv_fwd_impl(xin, n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
                                     nullptr, 1, 1, down ? 8 : 27, &epi, stream));
         break;
       }
@@ -528,9 +594,11 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       case OP_BN: {
         float *save = arena + L.aux_off[i];
+        // folded into its consumer's gather: statistics only; fold switched off: the exact A/B reference (own finalise kernel)
+        const int mode = (PL.bn_fold[i] >= 0 && g_bn_fold) ? (g_bn_fold == 1 ? 3 : 2) : 0;
         PROG_TRY(sgnn_bn_fwd_impl(B(in0), LD(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
                                   opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), LD(out), pre[i],
-                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev)));
+                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev), mode));
         break;
       }
       case OP_ADD:
@@ -549,14 +617,23 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       }
       case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
-        SGNN_CHECK_ARG(ROWS(out) == 8 * n && LD(in0) == cin && LD(out) == cout);
+        SGNN_CHECK_ARG(ROWS(out) == 8 * n && (LD(in0) == cin || (g_bn_fold == 1 && PL.pre_bn[i] >= 0)) && LD(out) == cout);
         const int32_t *S, *ST, *PAR;
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         float *wc = arena + L.aux_off[i];
         PROG_TRY(sgnn_expand_weights(P(par), cin, cout, wc, stream));
         ConvEpi xepi{};
         xepi.n_dev = CNT(lev);
-        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
+        const float *xin = B(in0);
+        if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {
+          const int jb = PL.pre_bn[i];
+          const int32_t *bo = ops + OPW * jb;
+          const float *save = arena + L.aux_off[jb];
+          xepi.pre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
+          xin = B(bo[1]);
+          xepi.ldx = LD(bo[1]);
+        }
+        PROG_TRY(sgnn_conv_fwd_impl(xin, n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
                                     0, S, nullptr, 1, 8, 27, &xepi, stream));
         break;
       }
@@ -757,9 +834,22 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             PROG_TRY(commit(in0, t));
           }
         }
-        PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, LD(in0), dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
-                                           nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
-                                           (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev)));
+        {
+          const float *xw = X(in0);
+          int64_t ldxw = LD(in0);
+          BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
+          if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {       // the rows this convolution saw = BatchNormReLU of the stored rows: recomputed in the gather
+            const int jb = PL.pre_bn[i];
+            const int32_t *bo = ops + OPW * jb;
+            const float *save = arena + L.aux_off[jb];
+            bpre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
+            xw = X(bo[1]);
+            ldxw = LD(bo[1]);
+          }
+          PROG_TRY(sgnn_conv_bwd_weight_impl(xw, n, cin, ldxw, dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
+                                             nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
+                                             (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev), &bpre));
+        }
         dw_off += dw_slice(v, i);
         break;
       }
@@ -853,7 +943,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         float *dwc = side ? (float *)(dw_base + dw_off + dw_slice(v, i) - expand_dwc_bytes(cin, cout)) : garena + L.bextra;
         float *part = garena + L.bextra + round64(64 * (int64_t)cin * cout);
         const hipStream_t lane = dw_lane();
-        SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
+        SGNN_CHECK_ARG(ld_dy == cout && (LD(in0) == cin || (g_bn_fold == 1 && PL.pre_bn[i] >= 0)));
         if (wants(in0) && n > 0) {
           // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
           const int Gs = EXPAND_DX_SPLIT;
@@ -865,8 +955,21 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           PROG_TRY(sgnn_sum_groups_dn(part, cin, n, Gs, t, stream, CNT(lev)));
           PROG_TRY(commit(in0, t));
         }
-        PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, cin, dy, cout, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1,
-                                           8, 27, dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane, CNT(lev)));
+        {
+          const float *xw = X(in0);
+          int64_t ldxw = cin;
+          BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
+          if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {
+            const int jb = PL.pre_bn[i];
+            const int32_t *bo = ops + OPW * jb;
+            const float *save = arena + L.aux_off[jb];
+            bpre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
+            xw = X(bo[1]);
+            ldxw = LD(bo[1]);
+          }
+          PROG_TRY(sgnn_conv_bwd_weight_impl(xw, n, cin, ldxw, dy, cout, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1,
+                                             8, 27, dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane, CNT(lev), &bpre));
+        }
         dw_off += dw_slice(v, i);
         pending_expand.push_back(PendingExpand{dwc, cin, cout, PG(par)});   // dwc is final after the batched reduce
         break;

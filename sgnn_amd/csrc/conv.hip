@@ -782,12 +782,21 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   // the convolution's input rows may be the INPUT of a folded BatchNormReLU (BnPre): the gather then normalises them, with
   // the rows of missing rules kept at zero (ok[m]); applied where the rows are written to LDS (norm_rows), not at the load
   // (PRE is a template parameter: the plain instantiations do not pay its registers)
-  constexpr int PV = PRE ? V : 1, PM = PRE ? 4 : 1;
+  // Row-contiguous gathers (round 4, scripts/kernels/gather_bench.hip): a gather instruction whose 16-lane quarter-waves
+  // each touch 16 different rows (the MFMA-fragment mapping: lane (row = lane & 15, quarter = lane >> 4)) costs the texture
+  // path 41 cycles per KiB; with lanes 4g .. 4g+3 covering one whole 64-byte row it costs 28 (32-byte rows: 2 lanes per
+  // row, 17 instead of 25 us per pass over the 366 k-row level).  The weight gradient stages its rows through LDS anyway
+  // (the site index must land on the MFMA contraction axis), so for 8- and 16-channel rows the gathers use that mapping:
+  // instruction j covers rows j*RPI + lane / LPR, lane % LPR is the 16-byte chunk; the LDS image is the same.
+  constexpr bool RCX = (CIN == 16 || CIN == 8);
+  constexpr int LPR = RCX ? CIN / 4 : 1, RPI = 64 / LPR, NI = RCX ? LPR : 4, GW = RCX ? 4 : V;   // NI loads of GW floats
+  const int rc_row = lane / LPR, rc_chunk = lane % LPR;
+  constexpr int PV = PRE ? GW : 1, PM = PRE ? NI : 1;
   float pm[PV], pi[PV], pg[PV], pb[PV];
   if constexpr (PRE) {
 #pragma unroll
-    for (int s = 0; s < V; ++s) {
-      const int c = q * V + s;
+    for (int s = 0; s < GW; ++s) {
+      const int c = RCX ? rc_chunk * 4 + s : q * V + s;
       const bool okc = c < CIN;
       pm[s] = okc ? pre.mean[c] : 0.f;
       pi[s] = okc ? pre.invstd[c] : 0.f;
@@ -795,27 +804,35 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       pb[s] = okc ? (pre.beta ? pre.beta[c] : 0.f) : 0.f;
     }
   }
-  auto gather = [&](int32_t iv, float(&g)[4][V], float(&ok)[PM]) {
+  auto gather = [&](int32_t iv, float(&g)[NI][GW], float(&ok)[PM]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int32_t id = __builtin_amdgcn_ds_bpermute((m * 16 + i16) * 4, iv);
+    for (int m = 0; m < NI; ++m) {
+      const int32_t id = __builtin_amdgcn_ds_bpermute((RCX ? m * RPI + rc_row : m * 16 + i16) * 4, iv);
       if constexpr (PRE) ok[m] = id >= 0 ? 1.f : 0.f;
-      buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), g[m]);
+      buf_load_floats<GW>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(RCX ? rc_chunk * 16 : q * V * 4), g[m]);
     }
   };
-  auto norm_rows = [&](float(&g)[4][V], const float(&ok)[PM]) {
+  auto norm_rows = [&](float(&g)[NI][GW], const float(&ok)[PM]) {
     if constexpr (PRE) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NI; ++m)
 #pragma unroll
-        for (int s = 0; s < V; ++s) g[m][s] = sgnn_bn_act(g[m][s], pm[s], pi[s], pg[s], pb[s], pre.leak) * ok[m];
+        for (int s = 0; s < GW; ++s) g[m][s] = sgnn_bn_act(g[m][s], pm[s], pi[s], pg[s], pb[s], pre.leak) * ok[m];
     }
     if constexpr (CINP != CIN) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < NI; ++m)
 #pragma unroll
-        for (int s = 0; s < V; ++s)
+        for (int s = 0; s < GW; ++s)
           if (3 * V + s >= CIN) g[m][s] = (q == 3) ? 0.f : g[m][s];
+    }
+  };
+  auto store_rows = [&](const float(&g)[NI][GW]) {   // the wave's 64 gathered rows -> xs[row][CINP]
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      float *p = RCX ? xs + (m * RPI + rc_row) * CINP + rc_chunk * 4 : xs + (m * 16 + i16) * CINP + q * V;
+#pragma unroll
+      for (int s = 0; s < GW; ++s) p[s] = g[m][s];
     }
   };
   auto mma_chunk = [&](int kk, const float(&b)[16][NT]) {
@@ -854,7 +871,23 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       idxv[kk] = (kk < kc) ? id : -1;
     }
     // dy tile -> LDS -> B fragments kept in registers for all offsets (rows >= n_out read as zeros)
-    {
+    if constexpr (COUT == 16 || COUT == 8) {   // row-contiguous (see RCX above): COUT / 4 lanes per row, 16-byte chunks
+      constexpr int LY = COUT / 4, RY = 64 / LY;
+      const int yr = lane / LY, yc = lane % LY;
+      float g[LY][4];
+#pragma unroll
+      for (int m = 0; m < LY; ++m) {
+        const int64_t row = base + m * RY + yr;
+        const uint32_t off = (row < blk_row1) ? (uint32_t)((row * groups + grp) * ld_dy + yc * 4) * 4u : 0xFFFFF800u;
+        buf_load_floats<4>(rs_dy, off, g[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < LY; ++m) {
+        float *p = ys + (m * RY + yr) * COUTP + yc * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) p[s] = g[m][s];
+      }
+    } else {
       float g[4][W];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -889,48 +922,33 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
     if constexpr (MT * NT == 1) {
       // narrow layers: little MFMA work per gather -> prefetch the next offset's rows (ping-pong registers)
-      float g0[4][V], g1[4][V], k0_[PM], k1_[PM];
+      float g0[NI][GW], g1[NI][GW], k0_[PM], k1_[PM];
       gather(idxv[0], g0, k0_);
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; kk += 2) {
         if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1, k1_);          // compile-time conditions only
         __builtin_amdgcn_sched_barrier(0);
         norm_rows(g0, k0_);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float *p = xs + (m * 16 + i16) * CINP + q * V;
-#pragma unroll
-          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
-        }
+        store_rows(g0);
         mma_chunk(kk, b);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < DW_KPB) {
           if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0, k0_);
           __builtin_amdgcn_sched_barrier(0);
           norm_rows(g1, k1_);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            float *p = xs + (m * 16 + i16) * CINP + q * V;
-#pragma unroll
-            for (int s = 0; s < V; ++s) p[s] = g1[m][s];
-          }
+          store_rows(g1);
           mma_chunk(kk + 1, b);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else {
       // wide layers: 3+ MFMA tiles per gathered row hide the latency; one register set keeps occupancy up
-      float g0[4][V], k0_[PM];
+      float g0[NI][GW], k0_[PM];
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; ++kk) {
         gather(idxv[kk], g0, k0_);
         norm_rows(g0, k0_);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float *p = xs + (m * 16 + i16) * CINP + q * V;
-#pragma unroll
-          for (int s = 0; s < V; ++s) p[s] = g0[m][s];
-        }
+        store_rows(g0);
         mma_chunk(kk, b);
       }
     }

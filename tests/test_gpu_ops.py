@@ -274,3 +274,43 @@ def test_registered_levels_use_the_dense_rulebook_and_match():
     ref = MD.Grid(g.coords).subm_table()       # unregistered: hash path
     assert torch.equal(tab, ref)
     assert int((MD.runtime(locs.device).index_volume() != -1).sum()) == 0
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (8, 8), (8, 12), (26, 16), (1, 8), (48, 16)])
+@pytest.mark.parametrize('batch,dim', [(2, 24), (5, 64)])     # one-offset-per-workgroup variant / 256-row blocks x offset groups
+def test_convolution_kernels_never_read_outside_their_slabs(cin, cout, batch, dim):
+    """the weight-gradient kernel once issued dy tail loads whose 32-bit offsets wrapped INTO the buffer
+    (harmless only while the matching x rows were exact zeros).  Here x, dy and the forward output live in the middle of
+    NaN-filled allocations — the table's padding entries are -1, the row count is not a multiple of the 256-row blocks — so
+    any load that leaves its slab (rows >= n, the row tail, a wrapped offset) poisons the result.  Forward, data gradient
+    and weight gradient must be finite and equal to the same calls on clean, exactly-sized tensors."""
+    from sgnn_amd.scn import functions as F_
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    locs = random_sites(batch, dim, 0.1, 5, surface=True)
+    g = Grid(coords_from_locs(locs, torch.device('cuda')))
+    tab, n = g.subm_table(), g.n
+    assert n % 256 != 0
+    gen = torch.Generator(device='cuda').manual_seed(cin + 100 * cout)
+    x = torch.randn(n, cin, device='cuda', generator=gen)
+    dy = torch.randn(n, cout, device='cuda', generator=gen)
+    w = torch.randn(27, cin, cout, device='cuda', generator=gen) * 0.2
+    pad = 4096
+
+    def poisoned(t):
+        big = torch.full((t.numel() + 2 * pad,), float('nan'), device='cuda')
+        big[pad:pad + t.numel()] = t.reshape(-1)
+        return big, big[pad:pad + t.numel()].view_as(t)
+    bx, px = poisoned(x)
+    bdy, pdy = poisoned(dy)
+    want_y = F_.conv_fwd_raw(x, cin, w, 27, tab, g.ld, n, cout)
+    got_y = F_.conv_fwd_raw(px, cin, w, 27, tab, g.ld, n, cout)
+    assert torch.isfinite(got_y).all() and torch.equal(got_y, want_y)
+    flags = F_.CONV_TRANSPOSE_W | F_.CONV_FLIP_K
+    want_dx = F_.conv_fwd_raw(dy, cout, w, 27, tab, g.ld, n, cin, flags)
+    got_dx = F_.conv_fwd_raw(pdy, cout, w, 27, tab, g.ld, n, cin, flags)
+    assert torch.isfinite(got_dx).all() and torch.equal(got_dx, want_dx)
+    want_dw = F_.conv_dw_raw(x, cin, dy, cout, tab, g.ld, 27, n)
+    got_dw = F_.conv_dw_raw(px, cin, pdy, cout, tab, g.ld, 27, n)
+    assert torch.isfinite(got_dw).all(), 'weight gradient read outside its slabs'
+    assert torch.equal(got_dw, want_dw)
+    assert torch.isnan(bx[:pad]).all() and torch.isnan(bdy[-pad:]).all()      # (the guard regions are intact)

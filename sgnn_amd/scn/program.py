@@ -67,6 +67,13 @@ def arena_bytes():
     return {'gradient': f(_garenas), 'inference': f(_iarenas)}
 
 
+def release_arenas():
+    """Drop the shared persistent arenas (gradient arenas, inference arenas); they are re-allocated on demand.  Forward
+    arenas belong to their programs and go with the model."""
+    _garenas.clear()
+    _iarenas.clear()
+
+
 class Unsupported(Exception):
     pass
 

@@ -1,0 +1,99 @@
+"""BASELINE.json configs[3] and configs[4] at their FULL sizes (the suite only ran (64,256,256) / one 128^3
+block; an out-of-memory or 4 GiB-slab regression at full size would have passed):
+  configs[3]  one (128,512,512) scene, ~1.5 M input sites, eval-style forward as torch/test_scene.py:72-95 drives it
+  configs[4]  8 blocks of 128^3 at 20 % i.i.d. occupancy (~2.6 M input sites), ONE training step (torch/train.py:245-268)
+The oracle cannot run these sizes in seconds, so they are held to size-independent properties: no duplicate
+site on any generated level, every level = the 8 children (model.py:195 order) of exactly the sites kept above, in order,
+finite values, and a peak-memory bar (8 GB / 32 GB allocated).  Slow (~20 s + ~25 s on an MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+from sgnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+GB = 2.0 ** 30
+
+
+def _check_hierarchy(occ, sdf, dims, batch):
+    """occ[h] = [sites (N,4) int64 [z,y,x,b], logits (N,2)] per level, sdf = [sites, values]: the generative invariants."""
+    prev_kept = None
+    for h in range(4):
+        sites, vals = occ[h][0].cpu().numpy(), occ[h][1].detach().cpu().numpy()
+        f = 8 >> h
+        lim = np.array([dims[0] // f, dims[1] // f, dims[2] // f])
+        assert sites.shape[0] > 0 and (sites[:, :3] >= 0).all() and (sites[:, :3] < lim).all()
+        assert (sites[:, 3] >= 0).all() and (sites[:, 3] < batch).all()
+        keys = ((sites[:, 3] * lim[0] + sites[:, 0]) * lim[1] + sites[:, 1]) * lim[2] + sites[:, 2]
+        assert np.unique(keys).shape[0] == keys.shape[0], 'level %d holds duplicate sites' % h
+        assert np.isfinite(vals).all()
+        if prev_kept is not None:      # children of exactly the kept parents, 8 per parent, in order
+            par = sites[:, :3] // 2
+            assert sites.shape[0] == 8 * prev_kept.shape[0]
+            assert np.array_equal(par, np.repeat(prev_kept[:, :3], 8, 0)) and np.array_equal(sites[:, 3], np.repeat(prev_kept[:, 3], 8))
+            assert np.array_equal(sites[:8, :3] - 2 * par[:8], np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)]))
+        v32 = vals[:, 0].astype(np.float32)
+        prev_kept = sites[(np.float32(1) / (np.float32(1) + np.exp(-v32))) > np.float32(0.5)]   # the reference's predicate, in fp32
+    assert np.array_equal(sdf[0].cpu().numpy(), prev_kept)        # final sites == last kept set, same order
+    assert torch.isfinite(sdf[1]).all()
+    return [int(o[0].shape[0]) for o in occ] + [int(sdf[0].shape[0])]
+
+
+def test_config3_full_scene_forward():
+    from sgnn_amd.model import GenModel
+    dims = (128, 512, 512)
+    locs, feats = synth.make_scene(dims, cfg=4, occupancy=0.05)
+    assert locs.shape[0] > 1200000
+    torch.manual_seed(1234)
+    m = GenModel(8, (128, 128, 128), 1, 16, 16, 4, True, True, 1, 1).cuda()
+    m.update_sizes(np.array(dims), np.array(dims) // 8)
+    lw = np.ones(5, dtype=np.float32)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        m.train()                       # batch statistics of this scene (random weights: the running ones mean nothing)
+        sdf, occ = m([locs, feats.cuda()], lw)       # coordinates may stay on the host (test_scene.py:80-82)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / GB
+    levels = _check_hierarchy(occ, sdf, dims, 1)
+    print('configs[3] (128,512,512): %d input sites, sites per level %s, peak allocated %.2f GB' % (locs.shape[0], levels, peak))
+    assert peak <= 8.0, 'peak allocated %.2f GB' % peak
+    from sgnn_amd.scn import program as P_
+    del m, sdf, occ
+    P_.release_arenas()
+    torch.cuda.empty_cache()
+
+
+def test_config4_bs8_training_step():
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.scn import program as P_
+    from sgnn_amd.train import train_step, to_device, make_optimizer
+    B, D = 8, 128
+    prev = P_.PERSISTENT_ARENAS
+    P_.PERSISTENT_ARENAS = True
+    try:
+        batch = to_device(synth.make_batch(B, (D,) * 3, cfg=5, occupancy=0.2, dist='iid'), 'cuda')
+        n_in = int(batch['input'][0].shape[0])
+        assert 2400000 < n_in < 2900000
+        torch.manual_seed(1234)
+        m = GenModel(8, (D,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda()
+        opt = make_optimizer(m.parameters())
+        before = [p.detach().clone() for p in m.parameters()]
+        lw = np.ones(5, dtype=np.float32)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        loss, losses, (sdf, occ) = train_step(m, opt, batch, lw)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() / GB
+        assert np.isfinite(float(loss))
+        levels = _check_hierarchy(occ, sdf, (D, D, D), B)
+        changed = sum(1 for a, p in zip(before, m.parameters()) if not torch.equal(a, p))
+        assert all(torch.isfinite(p).all() for p in m.parameters()) and changed == len(before), (changed, len(before))
+        print('configs[4] 8 x 128^3 @20 %%: %d input sites, sites per level %s, loss %.4f, peak allocated %.2f GB'
+              % (n_in, levels, float(loss), peak))
+        assert peak <= 32.0, 'peak allocated %.2f GB' % peak
+    finally:
+        P_.PERSISTENT_ARENAS = prev
+        del m, opt, batch
+        P_.release_arenas()
+        torch.cuda.empty_cache()

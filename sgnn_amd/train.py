@@ -774,12 +774,14 @@ class GraphStep(object):
               'feats': torch.zeros(cap.input_rows, feats.shape[1], dtype=torch.float32, device=dev),
               'sdf': torch.empty_like(batch['sdf']),
               'known': torch.empty_like(batch['known']) if batch.get('known') is not None else None,
-              'hierarchy': [torch.empty_like(h) for h in batch['hierarchy']]}
+              'hierarchy': [torch.empty_like(h) for h in (batch.get('hierarchy') or [])]}
         st['locs']._sgnn_cnt = cap.input_cnt()
         self.static = st
 
     def buffers(self):
-        """The graph's static input buffers (a loader may write batches straight into them, then call step(None))."""
+        """The graph's static input buffers (read-only view for tools and tests: a step always takes its batch as an
+        argument and copies it in — `_load` also publishes the live input row count, which a writer into these buffers could
+        not do)."""
         return self.static
 
     def _load(self, batch):
@@ -792,7 +794,7 @@ class GraphStep(object):
         st['sdf'].copy_(batch['sdf'], non_blocking=True)
         if st['known'] is not None:
             st['known'].copy_(batch['known'], non_blocking=True)
-        for d, s_ in zip(st['hierarchy'], batch['hierarchy']):
+        for d, s_ in zip(st['hierarchy'], batch.get('hierarchy') or []):
             d.copy_(s_, non_blocking=True)
 
     def _fwd_bwd(self, loss_weights):

@@ -114,16 +114,17 @@ def test_bench_gpus_2_starts_two_ranks():
         env['SGNN_BENCH_SHARE_GPU'] = '1'
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '2',
            '--dim', '32', '--no-cpu-baseline']
-    # two ranks SHARING one device is a functional stand-in, not a supported layout: both processes replay multi-branch
-    # graphs on the same GPU, and one such run in ~10 died inside the HIP runtime (never seen with one process per GPU) —
-    # one retry, the first failure's stderr stays in the message
-    first = ''
-    for attempt in range(2 if 'SGNN_BENCH_SHARE_GPU' in env else 1):
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        if p.returncode == 0:
-            break
-        first = first or p.stderr[-1500:]
-    assert p.returncode == 0, (first, p.stderr[-1500:])
+    # Two ranks SHARING one device is a functional stand-in, not a supported layout.  Round 3 saw one such run in ~10 die
+    # inside the HIP runtime and retried; round 4 ran this command 69 times in a row without a failure
+    # (profiles/r04k_flake_hunt.txt, scripts/flake_hunt.sh) after GraphStep stopped carrying autograd graphs across a capture
+    # — no retry any more: a failure leaves its stderr behind for diagnosis.
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        d = os.path.join(ROOT, 'gpurun_out', 'flake')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'test_bench_gpus_2.err'), 'w') as f:
+            f.write(p.stderr)
+    assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
     assert res['n_gpus'] == 2 and res['config']['ranks_in_process_group'] == 2

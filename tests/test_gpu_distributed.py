@@ -116,8 +116,8 @@ def test_bench_gpus_2_starts_two_ranks():
            '--dim', '32', '--no-cpu-baseline']
     # Two ranks SHARING one device is a functional stand-in, not a supported layout.  Round 3 saw one such run in ~10 die
     # inside the HIP runtime and retried; round 4 ran this command 69 times in a row without a failure
-    # (profiles/r04k_flake_hunt.txt, scripts/flake_hunt.sh) after GraphStep stopped carrying autograd graphs across a capture
-    # — no retry any more: a failure leaves its stderr behind for diagnosis.
+    # (profiles/r04k_flake_hunt.txt, scripts/flake_hunt.sh) — no retry any more: a failure leaves its stderr behind for
+    # diagnosis.
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     if p.returncode != 0:
         d = os.path.join(ROOT, 'gpurun_out', 'flake')

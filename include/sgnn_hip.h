@@ -272,6 +272,11 @@ int sgnn_bn_bwd_ex(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, 
 /* ---------------------------------------------------------------------------
  * Row movement (all pure copies / sums, fp32 rows of c floats)
  * ------------------------------------------------------------------------- */
+/* Up to 8 device-to-device copies as one launch: dst[k] <- src[k], bytes[k] bytes each (host arrays of device pointers /
+ * sizes; regions must not overlap each other).  train.GraphStep loads a batch into the replayed graph's static input
+ * buffers with it (torch/train.py:256-262 uploads the batch there): one kernel instead of seven copies per step. */
+int sgnn_copy_multi(void *const *dst, const void *const *src, const int64_t *bytes, int nregions, sgnn_stream_t stream);
+
 /* dst[r] = src[idx[r]]  (UnPooling fwd: idx = parent; mask compaction: idx = sel) */
 int sgnn_gather_rows(const float *src, int c, const int32_t *idx, int64_t m, float *dst,
                      sgnn_stream_t stream);

@@ -51,6 +51,7 @@ PROTOTYPES = {
     'sgnn_bn_bwd_add': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_bn_fwd_ex': (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_bn_bwd_ex': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'sgnn_copy_multi': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
     'sgnn_gather_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_gather_rows_dn': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_scatter_rows': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),

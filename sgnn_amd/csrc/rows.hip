@@ -104,6 +104,52 @@ int sgnn_copy_words(void *dst, const void *src, int64_t words, hipStream_t s) {
   return SGNN_OK;
 }
 
+// Up to 8 device-to-device copies as ONE launch (train.GraphStep: a batch's seven tensors into the replayed graph's static
+// input buffers — as separate copy_ calls they are seven 6 us kernels in front of every step).  16-byte units where source
+// and destination are 16-byte aligned, bytes otherwise.
+struct CopyRegions {
+  uint8_t *d[8];
+  const uint8_t *s[8];
+  int64_t bytes[8];
+  int64_t start[9];   // first 16-byte unit of region k in the launch's flat unit index
+};
+
+__global__ __launch_bounds__(256) void k_copy_multi(CopyRegions r, int n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < r.start[n]; g += stride) {
+    int k = 0;
+    while (k + 1 < n && g >= r.start[k + 1]) ++k;
+    const int64_t b = (g - r.start[k]) * 16;
+    uint8_t *q = r.d[k] + b;
+    const uint8_t *p = r.s[k] + b;
+    if (b + 16 <= r.bytes[k] && ((((uintptr_t)r.d[k]) | ((uintptr_t)r.s[k])) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(q) = *reinterpret_cast<const uint4 *>(p);
+    } else {
+      for (int t = 0; t < 16 && b + t < r.bytes[k]; ++t) q[t] = p[t];
+    }
+  }
+}
+
+SGNN_EXPORT int sgnn_copy_multi(void *const *dst, const void *const *src, const int64_t *bytes, int nregions,
+                                sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(nregions >= 0 && nregions <= 8 && (nregions == 0 || (dst && src && bytes)));
+  CopyRegions r{};
+  int n = 0;
+  for (int k = 0; k < nregions; ++k) {
+    if (bytes[k] <= 0 || dst[k] == src[k]) continue;
+    SGNN_CHECK_ARG(dst[k] && src[k]);
+    r.d[n] = (uint8_t *)dst[k];
+    r.s[n] = (const uint8_t *)src[k];
+    r.bytes[n] = bytes[k];
+    r.start[n + 1] = r.start[n] + (bytes[k] + 15) / 16;
+    ++n;
+  }
+  if (n == 0) return SGNN_OK;
+  SGNN_LAUNCH(k_copy_multi, dim3(sgnn_grid_for(r.start[n], 256, 8192)), dim3(256), 0, (hipStream_t)stream, r, n);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 // dst[r] = src[idx[r]]  (idx < 0 -> zeros)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ src, int cq,

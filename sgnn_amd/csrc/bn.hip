@@ -13,7 +13,10 @@
 
 #define BN_MAX_BLOCKS 2048
 #define BN_FLUSH 2
-#define BN_U 2            // row groups a thread of the apply passes loads before it uses the first one
+#ifndef BN_U
+#define BN_U 2
+#endif
+//            // row groups a thread of the apply passes loads before it uses the first one
 #define BN_FUSE_BLOCKS 4096
 #define BN_FUSE_MAXC 64
 

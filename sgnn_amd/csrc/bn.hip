@@ -14,9 +14,8 @@
 #define BN_MAX_BLOCKS 2048
 #define BN_FLUSH 2
 #ifndef BN_U
-#define BN_U 2
+#define BN_U 2            // row groups a thread of the apply passes loads before it uses the first one (4 / 8: measured, no gain)
 #endif
-//            // row groups a thread of the apply passes loads before it uses the first one
 #define BN_FUSE_BLOCKS 4096
 #define BN_FUSE_MAXC 64
 

@@ -118,20 +118,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     }
   };
   auto stage = [&](int k) {  // (re)stage KC weight slices as wl[kk][n][c]; in-flight global loads stay in flight
-    const int kc = (K - k) < KC ? (K - k) : KC;
-    __syncthreads();
-    for (int e = tid; e < kc * C::PER_K; e += 256) {
-      const int c = e % CINP;
-      const int n = (e / CINP) % (NT * 16);
-      const int ko = e / C::PER_K;
-      float v = 0.f;
-      if (c < CIN && n < COUT) {
-        const int ks = flip ? (K - 1 - (k + ko)) : (k + ko);
-        v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
-      }
-      wl[e] = v;
-    }
-    __syncthreads();
+    conv_stage_weights<CIN, COUT>(wl, w, K, k, (K - k) < KC ? (K - k) : KC, transpose, flip);
   };
   auto mma = [&](int kk, float(&a)[M][V], const float(&ok)[PM]) {
     float b[NT][V];

@@ -65,6 +65,47 @@ __device__ __forceinline__ void buf_load_floats(__amdgpu_buffer_rsrc_t rs, uint3
   }
 }
 
+// Weight slices k0 .. k0 + kc - 1 into LDS as wl[kk][n][c] (the B-fragment layout: n = output column, c = input channel,
+// NT*16 x CINP floats per offset, padding zero).  The global tensor is (K, CIN, COUT) — or (K, COUT, CIN) for the data
+// gradient (transpose) — so a slice is one contiguous run: 16-byte loads in global order (coalesced; dword alignment
+// suffices for raw-buffer loads), four LDS writes each.  Round 4: the element-wise form before walked the LDS image and
+// read the forward layout with a stride of COUT floats per thread, 27 dependent iterations for a 16 x 16 x 27 tile
+// (scripts/kernels/gather_bench.hip: the weight tile was +7 us of a 62 us launch).  Contains the barriers around the tile.
+template <int CIN, int COUT>
+__device__ __forceinline__ void conv_stage_weights(float *wl, const float *__restrict__ w, int K, int k0, int kc,
+                                                   bool transpose, bool flip) {
+  using C = ConvCfg<CIN, COUT>;
+  constexpr int CINP = C::CINP, NT = C::NT, SL = CIN * COUT;
+  const int tid = threadIdx.x;
+  __syncthreads();                                   // every wave is done with the previous contents
+  if constexpr (CINP != CIN || NT * 16 != COUT) {    // padded image: zero it first (LDS only)
+    for (int e = tid; e < kc * C::PER_K; e += 256) wl[e] = 0.f;
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w, (uint32_t)((int64_t)K * SL * 4));
+  auto put = [&](int ko, int idx, float v) {         // idx: element of the slice in global order
+    const int c = transpose ? idx % CIN : idx / COUT, n = transpose ? idx / CIN : idx % COUT;
+    wl[(ko * NT * 16 + n) * CINP + c] = v;
+  };
+  if constexpr (SL % 4 == 0) {
+    for (int g = tid; g < kc * (SL / 4); g += 256) {
+      const int ko = g / (SL / 4), r = (g - ko * (SL / 4)) * 4;
+      const int ks = flip ? (K - 1 - (k0 + ko)) : (k0 + ko);
+      float v[4];
+      buf_load_floats<4>(rs_w, (uint32_t)(ks * SL + r) * 4u, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put(ko, r + j, v[j]);
+    }
+  } else {
+    for (int g = tid; g < kc * SL; g += 256) {
+      const int ko = g / SL, r = g - ko * SL;
+      const int ks = flip ? (K - 1 - (k0 + ko)) : (k0 + ko);
+      put(ko, r, w[(int64_t)ks * SL + r]);
+    }
+  }
+  __syncthreads();
+}
+
 // Shared epilogue of the MFMA kernels: optional residual addend, strided store, optional BatchNorm statistics
 // (see ConvEpi).  acc[m][nt] holds the wave's rows row0 + m*16 + (lane>>4)*4 + i, column nt*16 + (lane&15).
 // Contains barriers when statistics are on: call it from all threads.  sred: >= 4*2*NT*16 doubles of LDS.

@@ -86,18 +86,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
     }
   };
   auto stage = [&](int k0) {   // weight slices k0 .. k0 + KC - 1 as wl[kk][n][c]
-    __syncthreads();           // every wave is done with the previous chunk
-    const int kc = (K - k0) < KC ? (K - k0) : KC;
-    for (int e = tid; e < kc * C::PER_K; e += 256) {
-      const int c = e % CINP, n = (e / CINP) % (NT * 16), ko = e / C::PER_K;
-      float v = 0.f;
-      if (c < CIN && n < COUT) {
-        const int ks = flip ? (K - 1 - (k0 + ko)) : (k0 + ko);
-        v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
-      }
-      wl[e] = v;
-    }
-    __syncthreads();
+    conv_stage_weights<CIN, COUT>(wl, w, K, k0, (K - k0) < KC ? (K - k0) : KC, transpose, flip);
   };
   auto mma = [&](int k) {
     const int kk = k % KC;

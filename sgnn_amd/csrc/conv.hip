@@ -120,14 +120,15 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   auto stage = [&](int k) {  // (re)stage KC weight slices as wl[kk][n][c]; in-flight global loads stay in flight
     conv_stage_weights<CIN, COUT>(wl, w, K, k, (K - k) < KC ? (K - k) : KC, transpose, flip);
   };
-  auto mma = [&](int kk, float(&a)[M][V], const float(&ok)[PM]) {
-    float b[NT][V];
+  auto load_b = [&](int kk, float(&b)[NT][V]) {     // B fragments of staged offset kk: W[kk][q*V .. q*V+V-1][n = nt*16 + r]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
 #pragma unroll
       for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
     }
+  };
+  auto mma_b = [&](float(&a)[M][V], const float(&ok)[PM], const float(&b)[NT][V]) {
     if constexpr (PRE) {
 #pragma unroll
       for (int m = 0; m < M; ++m)
@@ -148,6 +149,11 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
+  };
+  auto mma = [&](int kk, float(&a)[M][V], const float(&ok)[PM]) {
+    float b[NT][V];
+    load_b(kk, b);
+    mma_b(a, ok, b);
   };
 
   // software pipeline, unrolled by two with ping-pong registers: rule entries run three offsets ahead, gathered rows
@@ -191,27 +197,32 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
       if (kk + 1 < kc) mma(kk + 1, a1, o1);
     }
   } else {
-    float a0[M][V], a1[M][V], o0[PM], o1[PM];
+    // (round 4: the B fragments run one offset ahead too — their ds_read is issued before the MFMAs of the current offset
+    //  instead of right in front of its own, where every offset paid the LDS latency behind an lgkmcnt(0))
+    float a0[M][V], a1[M][V], o0[PM], o1[PM], b0[NT][V], b1[NT][V];
     for (int k0 = 0; k0 < K; k0 += KC) {
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       stage(k0);
       int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
       gather(idx_at(k0), a0, o0);
+      load_b(0, b0);
       int kk = 0;
       for (; kk + 1 < kc; kk += 2) {
         gather(iv1, a1, o1);                    // rows of offset k0+kk+1
         const int32_t iv3 = idx_at(k0 + kk + 3);
+        load_b(kk + 1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk, a0, o0);
+        mma_b(a0, o0, b0);
         __builtin_amdgcn_sched_barrier(0);
         gather(iv2, a0, o0);                    // rows of offset k0+kk+2 (dropped if that is past this chunk)
         iv1 = iv3;
         iv2 = idx_at(k0 + kk + 4);
+        load_b(kk + 2 < kc ? kk + 2 : kc - 1, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 1, a1, o1);
+        mma_b(a1, o1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < kc) mma(kk, a0, o0);
+      if (kk < kc) mma_b(a0, o0, b0);
     }
   }
 

@@ -109,6 +109,9 @@ __device__ __forceinline__ void conv_stage_weights(float *wl, const float *__res
 // Shared epilogue of the MFMA kernels: optional residual addend, strided store, optional BatchNorm statistics
 // (see ConvEpi).  acc[m][nt] holds the wave's rows row0 + m*16 + (lane>>4)*4 + i, column nt*16 + (lane&15).
 // Contains barriers when statistics are on: call it from all threads.  sred: >= 4*2*NT*16 doubles of LDS.
+// (Round 4: passing each 16-row tile through LDS to store whole 64-byte rows per four lanes — 4x fewer, full-line store
+//  instructions — was built and measured: 6.34 / 6.35 / 6.41 ms per step without / on launches with statistics / on every
+//  launch; the barrier it needs before re-using the weight tile costs more than the scattered 4-byte stores.  Dropped.)
 template <int COUT, int M, int NT>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0, int64_t n_out, unsigned groups,
                                               unsigned grp, float *y, const ConvEpi &epi, int stats, double *sred,

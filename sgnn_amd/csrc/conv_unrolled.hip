@@ -88,15 +88,18 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
   auto stage = [&](int k0) {   // weight slices k0 .. k0 + KC - 1 as wl[kk][n][c]
     conv_stage_weights<CIN, COUT>(wl, w, K, k0, (K - k0) < KC ? (K - k0) : KC, transpose, flip);
   };
-  auto mma = [&](int k) {
+  float bf[2][NT][V];          // B fragments, one offset ahead like the rows (bf[k & 1])
+  auto load_b = [&](int k) {
     const int kk = k % KC;
-    float b[NT][V];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const float *bp = wl + (kk * NT * 16 + nt * 16 + r) * CINP + q * V;
 #pragma unroll
-      for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
+      for (int s = 0; s < V; ++s) bf[k & 1][nt][s] = bp[s];
     }
+  };
+  auto mma = [&](int k) {
+    const float(&b)[NT][V] = bf[k & 1];
 #pragma unroll
     for (int s = 0; s < V; ++s)
 #pragma unroll
@@ -114,8 +117,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
   gather(0);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (k % KC == 0) stage(k);               // compile-time positions (the loop is fully unrolled)
+    if (k % KC == 0) {                        // compile-time positions (the loop is fully unrolled)
+      stage(k);
+      load_b(k);                              // first offset of a freshly staged chunk: nothing to prefetch from
+    }
     if (k + 1 < K) gather(k + 1);
+    if (k + 1 < K && (k + 1) % KC != 0) load_b(k + 1);
     __builtin_amdgcn_sched_barrier(0);
     mma(k);
     __builtin_amdgcn_sched_barrier(0);

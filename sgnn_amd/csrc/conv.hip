@@ -298,20 +298,42 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
     }
   }
   float b[KW][NT][V];
+  if (transpose) {
+    // data gradient: the weights are read as (K, COUT, CIN), so a lane's V channels are CONTIGUOUS — one wide load per
+    // (offset, column tile) instead of V four-byte loads (round 4: the weight fragments were 28 of the 35 memory instructions
+    // a wave of the <16,16> kernel issues, each as expensive for the texture path as a gather)
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w, (uint32_t)((int64_t)K * CIN * COUT * 4));
 #pragma unroll
-  for (int kk = 0; kk < KW; ++kk) {
-    const int k = k0 + kk;
-    const int ks = flip ? (K - 1 - k) : k;
+    for (int kk = 0; kk < KW; ++kk) {
+      const int k = k0 + kk;
+      const int ks = flip ? (K - 1 - k) : k;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + r;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + r;
+        const bool okw = kk < nk && n < COUT;
+        buf_load_floats<V>(rs_w, okw ? (uint32_t)((ks * COUT + n) * CIN + q * V) * 4u : 0xFFFFF800u, b[kk][nt]);
+        if constexpr (CINP != CIN) {   // the last quarter runs into the next column's weights: those slots are zero
 #pragma unroll
-      for (int s = 0; s < V; ++s) {
-        const int c = q * V + s;
-        float v = 0.f;
-        if (kk < nk && c < CIN && n < COUT)
-          v = transpose ? w[((int64_t)ks * COUT + n) * CIN + c] : w[((int64_t)ks * CIN + c) * COUT + n];
-        b[kk][nt][s] = v;
+          for (int s = 0; s < V; ++s)
+            if (3 * V + s >= CIN) b[kk][nt][s] = (q == 3) ? 0.f : b[kk][nt][s];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      const int k = k0 + kk;
+      const int ks = flip ? (K - 1 - k) : k;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + r;
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+          const int c = q * V + s;
+          float v = 0.f;
+          if (kk < nk && c < CIN && n < COUT) v = w[((int64_t)ks * CIN + c) * COUT + n];
+          b[kk][nt][s] = v;
+        }
       }
     }
   }

@@ -219,6 +219,15 @@ int64_t sgnn_conv_set_small_rows(int64_t rows);
  * s_waitcnt counts, rule entries loaded up front); 0 = the looped kernel everywhere (A/B measurements).  Same arithmetic and
  * summation order: bit-identical results.  Returns the previous setting. */
 int sgnn_conv_set_unrolled(int on);
+/* row blocks a weight-gradient launch aims for (default 256; the launch is row blocks x offset groups workgroups, every
+ * workgroup walks its rows in 256-row rounds).  Same per-block sums in the same order for a given setting; the partial sums
+ * of the blocks are added in block order.  Returns the previous setting. */
+int sgnn_conv_set_dw_blocks(int blocks);
+/* large levels: every workgroup of the rulebook walk takes as many consecutive 256-row tiles as it needs for ALL live
+ * workgroups to be resident at once (no partial second round of workgroups; default on).  0 = one tile per workgroup.
+ * Outputs are bit-identical either way; BatchNorm statistics partials are summed per workgroup, so their grouping
+ * (fp64) differs.  Returns the previous setting. */
+int sgnn_conv_set_one_round(int on);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,

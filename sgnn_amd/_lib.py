@@ -42,6 +42,8 @@ PROTOTYPES = {
     'sgnn_conv_set_small': (c_i32, [c_i32]),
     'sgnn_conv_set_small_rows': (c_i64, [c_i64]),
     'sgnn_conv_set_unrolled': (c_i32, [c_i32]),
+    'sgnn_conv_set_dw_blocks': (c_i32, [c_i32]),
+    'sgnn_conv_set_one_round': (c_i32, [c_i32]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
@@ -153,6 +155,13 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # measurements only: SGNN_TUNE="sgnn_conv_set_dw_blocks=341,sgnn_prog_set_bn_fold=1" calls the listed integer
+        # switches once (scripts/ab_env2.sh SGNN_TUNE a=1 a=2 compares two settings on one box)
+        for item in filter(None, os.environ.get('SGNN_TUNE', '').split(',')):
+            name, _, val = item.partition('=')
+            if name not in PROTOTYPES or '_set_' not in name:
+                raise SgnnError('SGNN_TUNE: %r is not a switch of the library' % name)
+            getattr(lib, name)(int(val))
         _lib = lib
     return _lib
 

@@ -30,23 +30,39 @@ template <int CIN, int COUT, int M, bool EX, bool PRE = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *y, int flags,
-                                                 int in_shift, ConvEx ex, ConvEpi epi) {
+                                                 int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
   constexpr int RPW = 16 * M;   // rows per wave: M = 4 normally, 1 when the level is too small to fill the chip
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
+  __shared__ double sred[4 * 2 * NT * 16];     // statistics scratch (the weight tile stays live across row tiles)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   // all groups of a row tile run next to each other on one XCD (they gather the same feature rows)
   const unsigned groups = EX ? (unsigned)ex.groups : 1u;
   unsigned nwg = gridDim.x;
-  if (epi.n_dev) {   // capacity mode: the launch covers the level's capacity, the live row count is on the device
-    n_out = sgnn_dyn_n(n_out, epi.n_dev);
+  if (epi.n_dev) n_out = sgnn_dyn_n(n_out, epi.n_dev);   // capacity mode: the live row count is on the device
+  // One round of workgroups (round 4).  A workgroup walks all K offsets of its rows serially, so a launch with MORE
+  // workgroups than the chip holds at once (wg_cap = resident workgroups of this instantiation x CUs) ends in a partial
+  // second round whose workgroups run almost alone, at the latency of 27 dependent gather round trips instead of at MFMA
+  // rate: 1641 workgroups on 1280 slots took 58 us where the MFMA work is 37 us.  Instead every live workgroup takes J
+  // consecutive 256-row tiles, J the smallest count for which all of them are resident together; the weight tile is staged
+  // once for all J.  The decomposition depends on the LIVE row count and wg_cap only, so a capacity-sized launch and an
+  // exact one produce the same statistics partials.
+  int J = 1;
+  if constexpr (!EX) {
+    if (wg_cap > 0) {
+      const int64_t w1 = (n_out + 4 * RPW - 1) / (4 * RPW);
+      J = (int)((w1 + wg_cap - 1) / wg_cap);
+      if (J < 1) J = 1;
+    }
+  }
+  if (epi.n_dev || J > 1) {
     // the LIVE workgroups are the first nwg in dispatch order (round robin over the XCDs) and share the tiles among
-    // themselves exactly as an exact-size launch would: every XCD stays busy whatever the capacity's head-room, and the
-    // statistics partial a block writes is the one the exact launch writes
-    nwg = (unsigned)((n_out + 4 * RPW - 1) / (4 * RPW)) * groups;
+    // themselves exactly as an exact-size launch would: every XCD stays busy whatever the capacity's head-room
+    const int64_t rows_wg = (int64_t)4 * RPW * J;
+    nwg = (unsigned)((n_out + rows_wg - 1) / rows_wg) * groups;
     if (blockIdx.x >= nwg) {   // workgroup past the end: nothing to compute, zero statistics partials
       if (!EX && epi.stats)
         for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
@@ -55,7 +71,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   }
   const unsigned lin = sgnn_xcd_tile(blockIdx.x, nwg);
   const unsigned tile = lin / groups, grp = lin % groups;
-  const int64_t row0 = ((int64_t)tile * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
+  int64_t row0 = ((int64_t)tile * J * 4 + wave) * RPW;  // < ld (ld is a multiple of 256)
   const int32_t *kmap = nullptr, *kadd_g = nullptr;
   if constexpr (EX) {
     w += (int64_t)grp * K * CIN * COUT;
@@ -68,17 +84,16 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   const uint32_t ldx4 = (uint32_t)epi.ldx * 4u;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)table_rows * ld * 4));
-  const uint32_t lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;   // this lane's rule entry in an offset row
+  uint32_t lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;   // this lane's rule entry in an offset row
   const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];                                               // ds_bpermute byte address of tile m's entry
 #pragma unroll
   for (int m = 0; m < M; ++m) perm[m] = (m * 16 + r) * 4;
 
   f32x4 acc[M][NT];
+  double s1[NT], s2[NT];
 #pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
 
   // one coalesced load fetches the wave's rule entries of an offset; lanes pick theirs with ds_bpermute
   // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
@@ -164,13 +179,25 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   // of the next offset in every second step.
   const int klast = K - 1;
   auto idx_at = [&](int k) { return load_idx(k < klast ? k : klast); };
+  for (int j = 0; j < J; ++j) {
+  if (j > 0) {
+    const int64_t wg_row0 = ((int64_t)tile * J + j) * 4 * RPW;
+    if (wg_row0 >= n_out) break;               // uniform over the workgroup
+    row0 = wg_row0 + wave * RPW;
+    lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;
+  }
+  const bool restage = j == 0 || K > KC;       // a weight tile that holds all K offsets is staged once
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (V <= 4 && (NT >= 2 || M == 1)) {
     // narrow rows, several output tiles (long MFMA phase per offset): three register sets, rows gathered TWO offsets
     // ahead of their MFMAs.  Measured at N = 366 k: <16,48> 228 -> 187 us; <16,16> (NT = 1) is 3 % faster with two sets
     float a0[M][V], a1[M][V], a2[M][V], o0[PM], o1[PM], o2[PM];
     for (int k0 = 0; k0 < K; k0 += KC) {      // one pass per staged weight chunk (a single one for the 3x3x3 16->16 layers)
       const int kc = (K - k0) < KC ? (K - k0) : KC;
-      stage(k0);
+      if (restage) stage(k0);
       gather(idx_at(k0), a0, o0);
       gather(idx_at(k0 + 1), a1, o1);
       int32_t iv2 = idx_at(k0 + 2), iv3 = idx_at(k0 + 3), iv4 = idx_at(k0 + 4);
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     float a0[M][V], a1[M][V], o0[PM], o1[PM], b0[NT][V], b1[NT][V];
     for (int k0 = 0; k0 < K; k0 += KC) {
       const int kc = (K - k0) < KC ? (K - k0) : KC;
-      stage(k0);
+      if (restage) stage(k0);
       int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
       gather(idx_at(k0), a0, o0);
       load_b(0, b0);
@@ -226,9 +253,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     }
   }
 
-  // the weight tile is dead by now: its LDS serves as the statistics scratch
-  static_assert(sizeof(wl) >= 4 * 2 * NT * 16 * sizeof(double), "weight tile too small for the statistics scratch");
-  conv_epilogue<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, EX ? 0 : epi.stats, reinterpret_cast<double *>(wl), x, blockIdx.x);
+  conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, EX ? 0 : epi.stats, x, s1, s2);
+  }
+  conv_epilogue_stats<COUT, NT>(s1, s2, epi, EX ? 0 : epi.stats, sred, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -503,6 +530,12 @@ SGNN_EXPORT int sgnn_conv_set_unrolled(int on) {
   return prev;
 }
 
+int g_conv_one_round = 1;   // sgnn_conv_set_one_round: 0 = one 256-row tile per workgroup on every level (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_one_round(int on) {
+  const int prev = g_conv_one_round;
+  g_conv_one_round = on ? 1 : 0;
+  return prev;
+}
 static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
 SGNN_EXPORT int sgnn_conv_set_small(int on) {
   const int prev = g_small_kernel;
@@ -565,10 +598,11 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                          x, n_in, w, table, ld, K, n_out, y, flags, in_shift, epi);                     \
     else if (small)                                                                                     \
       SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV, PREV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table,  \
-                         ld, K, n_out, y, flags, in_shift, ex, epi);                                    \
+                         ld, K, n_out, y, flags, in_shift, ex, epi, 0);                                 \
     else                                                                                                \
       SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>), dim3(grid4), dim3(256), 0, s, x, n_in,    \
-                         w, table, ld, K, n_out, y, flags, in_shift, ex, epi);                          \
+                         w, table, ld, K, n_out, y, flags, in_shift, ex, epi,                           \
+                         (EXV || !g_conv_one_round) ? 0 : conv_wg_capacity<k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>>()); \
     done = true;                                                                                        \
   } while (0)
 // (the BatchNorm-folding instantiations exist for the shapes the planner folds: BN_FOLD_* lists below)
@@ -1086,8 +1120,14 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
 }
 
 #define DW_FINE_ROWS 16384   // below: one offset per weight-gradient workgroup
+static int g_dw_blocks = 256;       // sgnn_conv_set_dw_blocks: row blocks a weight-gradient launch aims for (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_dw_blocks(int blocks) {
+  const int prev = g_dw_blocks;
+  if (blocks >= 1 && blocks <= 4096) g_dw_blocks = blocks;
+  return prev;
+}
 static int64_t dw_rows_per_block(int64_t n_out) {
-  int64_t rpb = (n_out + 255) / 256;           // <= 256 row blocks
+  int64_t rpb = (n_out + g_dw_blocks - 1) / g_dw_blocks;   // <= g_dw_blocks row blocks
   rpb = ((rpb + 255) / 256) * 256;             // whole 256-row wave rounds
   if (rpb < 256) rpb = 256;
   return rpb;

@@ -34,6 +34,22 @@ struct ConvEx {
   int table_rows;   // rows of `table` (K unless kmap selects rows of a larger table)
 };
 
+// resident workgroups of a 256-thread kernel on the whole device (occupancy x CUs), cached per instantiation: the large-level
+// kernels size their row tiles so that ONE round of workgroups covers the level (k_conv_fwd; sgnn_conv_set_one_round)
+template <auto KERNEL>
+static int conv_wg_capacity() {
+  static int cap = -1;
+  if (cap < 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      per_cu = cus = 0;
+    cap = per_cu * cus;
+  }
+  return cap;
+}
+extern int g_conv_one_round;
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -113,10 +129,10 @@ __device__ __forceinline__ void conv_stage_weights(float *wl, const float *__res
 //  instructions — was built and measured: 6.34 / 6.35 / 6.41 ms per step without / on launches with statistics / on every
 //  launch; the barrier it needs before re-using the weight tile costs more than the scattered 4-byte stores.  Dropped.)
 template <int COUT, int M, int NT>
-__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0, int64_t n_out, unsigned groups,
-                                              unsigned grp, float *y, const ConvEpi &epi, int stats, double *sred,
-                                              const float *any_ptr, size_t pblock) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[M][NT], int64_t row0, int64_t n_out, unsigned groups,
+                                                   unsigned grp, float *y, const ConvEpi &epi, int stats,
+                                                   const float *any_ptr, double (&s1)[NT], double (&s2)[NT]) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const uint32_t ldy4 = (uint32_t)epi.ldy * 4u;
   const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(((n_out * groups - 1) * epi.ldy + COUT) * 4));
@@ -127,7 +143,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0,
   const __amdgpu_buffer_rsrc_t rs_b =
       make_rsrc(stats == 2 ? epi.bn_x : any_ptr, stats == 2 ? (uint32_t)(((n_out - 1) * epi.ld_bnx + COUT) * 4) : 0u);
   const uint32_t ldb4 = (uint32_t)epi.ld_bnx * 4u;
-  double s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = nt * 16 + r;
@@ -164,9 +179,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0,
         }
       }
     }
-    s1[nt] = f1;
-    s2[nt] = f2;
+    s1[nt] += f1;
+    s2[nt] += f2;
   }
+}
+
+// the workgroup's statistics partial from the lanes' running sums (conv_epilogue_rows, one or several row tiles)
+template <int COUT, int NT>
+__device__ __forceinline__ void conv_epilogue_stats(const double (&s1)[NT], const double (&s2)[NT], const ConvEpi &epi,
+                                                    int stats, double *sred, size_t pblock) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
   if (stats) {
     // lanes r, r+16, r+32, r+48 hold the same column: fold them, then the four waves in fixed order through LDS
     __syncthreads();
@@ -193,3 +216,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0,
   }
 }
 
+template <int COUT, int M, int NT>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0, int64_t n_out, unsigned groups,
+                                              unsigned grp, float *y, const ConvEpi &epi, int stats, double *sred,
+                                              const float *any_ptr, size_t pblock) {
+  double s1[NT], s2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+  conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, stats, any_ptr, s1, s2);
+  conv_epilogue_stats<COUT, NT>(s1, s2, epi, stats, sred, pblock);
+}

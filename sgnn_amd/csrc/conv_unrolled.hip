@@ -20,18 +20,25 @@
 template <int CIN, int COUT, int K, bool PRE>
 __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
                                                    const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
-                                                   int flags, int in_shift, ConvEpi epi) {
+                                                   int flags, int in_shift, ConvEpi epi, int wg_cap) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, M = 4;
   constexpr int KC = C::KC < K ? C::KC : K;            // offsets per staged weight chunk
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
+  __shared__ double sred[4 * 2 * NT * 16];             // statistics scratch (the weight tile stays live across row tiles)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   unsigned nwg = gridDim.x;
-  if (epi.n_dev) {   // capacity mode (see k_conv_fwd): the live workgroups share the tiles like an exact-size launch
-    n_out = sgnn_dyn_n(n_out, epi.n_dev);
-    nwg = (unsigned)((n_out + 255) / 256);
+  if (epi.n_dev) n_out = sgnn_dyn_n(n_out, epi.n_dev);   // capacity mode (see k_conv_fwd)
+  // one round of workgroups: J consecutive 256-row tiles per live workgroup (k_conv_fwd explains)
+  int J = 1;
+  if (wg_cap > 0) {
+    J = (int)(((n_out + 255) / 256 + wg_cap - 1) / wg_cap);
+    if (J < 1) J = 1;
+  }
+  if (epi.n_dev || J > 1) {   // the live workgroups share the tiles like an exact-size launch
+    nwg = (unsigned)((n_out + 256 * (int64_t)J - 1) / (256 * (int64_t)J));
     if (blockIdx.x >= nwg) {
       if (epi.stats)
         for (int o = tid; o < 2 * COUT; o += 256) epi.partial[(size_t)blockIdx.x * 2 * COUT + o] = 0.0;
@@ -39,27 +46,20 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
     }
   }
   const unsigned tile = sgnn_xcd_tile(blockIdx.x, nwg);
-  const int64_t row0 = ((int64_t)tile * 4 + wave) * 64;
   const bool transpose = flags & SGNN_CONV_TRANSPOSE_W, flip = flags & SGNN_CONV_FLIP_K;
 
   const uint32_t ldx4 = (uint32_t)epi.ldx * 4u;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * epi.ldx + CIN) * 4));
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
-  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u, ld4 = (uint32_t)ld * 4u;
-
-  int32_t idx[K];      // the wave's rule entries of every offset, loaded up front (padding rows of the table hold -1)
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    idx[k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
-
+  const uint32_t ld4 = (uint32_t)ld * 4u;
   int perm[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) perm[m] = (m * 16 + r) * 4;
+  double s1[NT], s2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+  int32_t idx[K];
   f32x4 acc[M][NT];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // BatchNormReLU of the producing layer folded into the gather (ConvEpi.pre, see BnPre): the lane's V channels' constants
   // (a template parameter: the plain instantiations do not pay the 4 V + 2 M registers)
@@ -114,11 +114,24 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
       }
   };
 
+  for (int j = 0; j < J; ++j) {
+  const int64_t wg_row0 = ((int64_t)tile * J + j) * 256;
+  if (j > 0 && wg_row0 >= n_out) break;       // uniform over the workgroup
+  const int64_t row0 = wg_row0 + wave * 64;
+  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u;
+  // the wave's rule entries of every offset, loaded up front (padding rows of the table hold -1)
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    idx[k] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   gather(0);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (k % KC == 0) {                        // compile-time positions (the loop is fully unrolled)
-      stage(k);
+      if (KC < K || j == 0) stage(k);         // a tile that holds all K offsets is staged once
       load_b(k);                              // first offset of a freshly staged chunk: nothing to prefetch from
     }
     if (k + 1 < K) gather(k + 1);
@@ -128,8 +141,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  static_assert(sizeof(wl) >= 4 * 2 * NT * 16 * sizeof(double), "weight tile too small for the statistics scratch");
-  conv_epilogue<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, reinterpret_cast<double *>(wl), x, blockIdx.x);
+  conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, x, s1, s2);
+  }
+  conv_epilogue_stats<COUT, NT>(s1, s2, epi, epi.stats, sred, blockIdx.x);
 }
 
 // Shapes: where the straight-line form wins on the 366 k-row level (profiles/r04c_conv_ab.txt, same box, bit-identical
@@ -158,9 +172,11 @@ bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, i
 #define X(CI, CO)                                                                                                        \
   if (K == 27 && cin == CI && cout == CO) {                                                                              \
     if (epi.pre.mean)                                                                                                    \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
+                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 27, true>>() : 0); \
     else                                                                                                                 \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
+                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 27, false>>() : 0); \
     return true;                                                                                                         \
   }
   CONV_U_CASES_27(X)
@@ -168,9 +184,11 @@ bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, i
 #define X(CI, CO)                                                                                                        \
   if (K == 8 && cin == CI && cout == CO) {                                                                               \
     if (epi.pre.mean)                                                                                                    \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
+                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 8, true>>() : 0); \
     else                                                                                                                 \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
+                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 8, false>>() : 0); \
     return true;                                                                                                         \
   }
   CONV_U_CASES_8(X)

@@ -143,3 +143,45 @@ def test_epilogue_rejects_uncompiled_shapes():
     with pytest.raises(_lib.SgnnError, match='compiled'):
         _lib.call('sgnn_conv_fwd_epi', x.data_ptr(), g.n, 5, 0, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, 7,
                   y.data_ptr(), 0, 0, y.data_ptr(), 0, 0, None, None, 0, None, None, None, None, 0.0)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (26, 16)])
+def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
+    """Large levels run as ONE round of workgroups, each taking J consecutive 256-row tiles (sgnn_conv_set_one_round,
+    k_conv_fwd / k_conv_fwd_u).  Against one tile per workgroup on a level large enough for J = 2: output rows bit-identical
+    (same arithmetic per row), BatchNorm statistics equal to fp64 round-off (the partial rows are grouped differently), and
+    the partial blocks past the live workgroups hold exact zeros."""
+    from sgnn_amd import synth, _lib
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    DEV = torch.device('cuda')
+    data = synth.make_batch(32, (64, 64, 64), cfg=2, occupancy=0.05)
+    g = Grid(coords_from_locs(data['input'][0], DEV))
+    tab, n = g.subm_table(), g.n
+    assert n > 1280 * 256, 'the level must exceed one round of 256-row workgroups (5 resident per CU)'
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(n, cin, device=DEV, generator=gen)
+    w = torch.randn(27, cin, cout, device=DEV, generator=gen) * 0.2
+    nblk = _lib.query('sgnn_conv_stats_blocks', n)
+    lib = _lib.load()
+
+    def run(one_round):
+        prev = lib.sgnn_conv_set_one_round(one_round)
+        try:
+            y = torch.empty(n, cout, device=DEV)
+            partial = torch.full((nblk, 2, cout), float('nan'), dtype=torch.float64, device=DEV)
+            _lib.call('sgnn_conv_fwd_epi', x.data_ptr(), n, cin, cin, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, cout,
+                      y.data_ptr(), cout, 0, None, 0, 1, partial.data_ptr(), None, 0, None, None, None, None, 0.0)
+            torch.cuda.synchronize()
+        finally:
+            lib.sgnn_conv_set_one_round(prev)
+        return y, partial
+    y1, p1 = run(1)
+    y0, p0 = run(0)
+    assert torch.equal(y1, y0)
+    assert torch.isfinite(p1).all() and torch.isfinite(p0).all()
+    live1 = int((p1.abs().sum(dim=(1, 2)) > 0).sum().item())
+    assert live1 < nblk and (p1[live1:] == 0).all(), 'workgroups past the live ones must write zero partials'
+    s1, s0 = p1.sum(0), p0.sum(0)
+    assert ((s1 - s0).abs() <= 1e-12 * s0.abs().clamp_min(1.0)).all()
+    want = torch.stack([y0.double().sum(0), (y0.double() ** 2).sum(0)])
+    assert ((s1 - want).abs() <= 1e-9 * want.abs().clamp_min(1.0)).all()

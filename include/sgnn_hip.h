@@ -223,6 +223,9 @@ int sgnn_conv_set_unrolled(int on);
  * workgroup walks its rows in 256-row rounds).  Same per-block sums in the same order for a given setting; the partial sums
  * of the blocks are added in block order.  Returns the previous setting. */
 int sgnn_conv_set_dw_blocks(int blocks);
+/* weight gradient of a one-channel input (1 -> 8, the network's first convolution): 1 (default) = the register-accumulating
+ * VALU kernel, 0 = the MFMA kernel of the other shapes.  Different summation order (fp32 round-off).  Returns the previous setting. */
+int sgnn_conv_set_dw_c1(int on);
 /* large levels: every workgroup of the rulebook walk takes as many consecutive 256-row tiles as it needs for ALL live
  * workgroups to be resident at once (no partial second round of workgroups; default on).  0 = one tile per workgroup.
  * Outputs are bit-identical either way; BatchNorm statistics partials are summed per workgroup, so their grouping

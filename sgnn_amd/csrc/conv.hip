@@ -1089,6 +1089,88 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   }
 }
 
+// Weight gradient of a ONE-channel input (the network's first convolution, 1 -> 8: `model.py:178`), round 4.  The MFMA kernel
+// above spends a 16 x 16 x 4 tile per four rows on a 1 x 8 outer product and pushes the single input channel through the same
+// LDS transposition as a 16-channel row: 75 us on the 380 k-row input level, as long as the <16,16> gradient.  Here a thread
+// owns rows (row block base + tid, + 256, ...) and keeps the KP x COUT sums of its offset group in registers:
+// dw[k][0][co] += x[table[k][j]] * dy[j][co] — coalesced rule entries, 4-byte gathers that mostly hit neighbouring rows, two
+// 16-byte dy loads per row.  Same workspace layout and reduce kernel as k_conv_dw; the workgroup's sum is formed in a fixed
+// order (waves 0..3, then lanes 0..63): deterministic for a given launch.
+template <int COUT, int KP>
+__global__ __launch_bounds__(256) void k_conv_dw_c1(const float *__restrict__ x, int64_t n_in, const float *__restrict__ dy,
+                                                   const int32_t *__restrict__ table, int64_t ld, int K, int64_t n_out,
+                                                   float *__restrict__ partial, int64_t rows_per_block, int in_shift,
+                                                   int64_t ldx, int64_t ld_dy, const int64_t *n_dev) {
+  static_assert(COUT % 4 == 0, "dy rows are loaded 16 bytes at a time");
+  if (n_dev) {   // capacity mode: spread the LIVE rows over all row blocks of the (capacity-sized) launch (as k_conv_dw)
+    n_out = sgnn_dyn_n(n_out, n_dev);
+    const int64_t per = (n_out + gridDim.x - 1) / gridDim.x;
+    rows_per_block = ((per + 255) / 256) * 256;
+    if (rows_per_block < 256) rows_per_block = 256;
+  }
+  constexpr int NV = KP * COUT;
+  __shared__ float red[NV][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lin = sgnn_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const unsigned bx = lin / gridDim.y, by = lin % gridDim.y;
+  const int k0 = by * KP;
+  const int kc = (K - k0) < KP ? (K - k0) : KP;
+  const int64_t blk_row0 = (int64_t)bx * rows_per_block;
+  int64_t blk_row1 = blk_row0 + rows_per_block;
+  if (blk_row1 > n_out) blk_row1 = n_out;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(((n_in - 1) * ldx + 1) * 4));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)K * ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(((n_out - 1) * ld_dy + COUT) * 4));
+  const uint32_t ld4 = (uint32_t)ld * 4u, ldx4 = (uint32_t)ldx * 4u;
+  float acc[KP][COUT];
+#pragma unroll
+  for (int kk = 0; kk < KP; ++kk)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[kk][c] = 0.f;
+  for (int64_t row = blk_row0 + tid; row < blk_row1; row += 256) {
+    int32_t id[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {   // offsets past the group's end: a clamped entry, dropped below
+      const int ko = k0 + (kk < kc ? kk : kc - 1);
+      id[kk] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, (uint32_t)row * 4u, ko * ld4, 0) >> in_shift;
+    }
+    float g[COUT];
+    buf_load_floats<COUT>(rs_dy, (uint32_t)(row * ld_dy) * 4u, g);
+    float xv[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)     // rule -1 -> offset 0xFFFFFFFC * ldx -> out of range -> 0
+      xv[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, (uint32_t)id[kk] * ldx4, 0, 0));
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      const float v = (kk < kc) ? xv[kk] : 0.f;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[kk][c] = fmaf(v, g[c], acc[kk][c]);
+    }
+  }
+  // the four waves in fixed order into red[value][lane], then the 64 lanes of every value in order
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int kk = 0; kk < KP; ++kk)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+          float *p = &red[kk * COUT + c][lane];
+          if (wv == 0)
+            *p = acc[kk][c];
+          else
+            *p += acc[kk][c];
+        }
+    }
+    __syncthreads();
+  }
+  float *out = partial + ((int64_t)bx * K + k0) * COUT;
+  if (tid < kc * COUT) {
+    float t = 0.f;
+    for (int l = 0; l < 64; ++l) t += red[tid][l];
+    out[tid] = t;
+  }
+}
+
 // dw[e] = sum_b partial[b][e]: 32 consecutive elements per workgroup x 8 interleaved partial streams,
 // combined in fixed order through LDS (deterministic)
 __global__ __launch_bounds__(256) void k_dw_reduce(const float *__restrict__ partial, int64_t nblk,
@@ -1171,6 +1253,12 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
 }
 
 #define DW_FINE_ROWS 16384   // below: one offset per weight-gradient workgroup
+static int g_dw_c1_kernel = 1;   // sgnn_conv_set_dw_c1: 0 = the MFMA kernel for one-channel inputs too (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_dw_c1(int on) {
+  const int prev = g_dw_c1_kernel;
+  g_dw_c1_kernel = on ? 1 : 0;
+  return prev;
+}
 static int g_dw_blocks = 256;       // sgnn_conv_set_dw_blocks: row blocks a weight-gradient launch aims for (A/B measurements)
 SGNN_EXPORT int sgnn_conv_set_dw_blocks(int blocks) {
   const int prev = g_dw_blocks;
@@ -1274,6 +1362,21 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     done = true;                                                                                           \
   } while (0)
   const bool has_pre = pre.mean != nullptr;
+  if (plain && !has_pre && cin == 1 && cout == 8 && g_dw_c1_kernel) {   // one-channel input: the VALU kernel (k_conv_dw_c1)
+    if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, K, cin, cout)) {
+      sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");
+      return SGNN_ENOWS;
+    }
+    const int prof = sgnn_prof_begin_launch(1, n_out, cin, cout, K, 0, s);
+    SGNN_LAUNCH((k_conv_dw_c1<8, 9>), dim3((unsigned)nblk, (unsigned)((K + 8) / 9)), dim3(256), 0, s, x, n_in, dy, table, ld,
+                K, n_out, (float *)ws, rpb, in_shift, ldx, ld_dy, n_dev);
+    sgnn_prof_end_launch(prof, s);
+    if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX)
+      sgnn_dw_batch->d[sgnn_dw_batch->n++] = DwDesc{(const float *)ws, dw, nblk, elems, 0};
+    else
+      SGNN_LAUNCH(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, (const float *)ws, nblk, elems, dw);
+    done = true;
+  }
 #define X(CI, CO)                                  \
   if (!done && plain && cin == CI && cout == CO) { \
     if (has_pre)                                   \

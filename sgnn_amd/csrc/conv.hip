@@ -828,6 +828,9 @@ struct DwCfg {
   static constexpr int KPB = (MT * NT == 1) ? 9 : ((MT * NT <= 3) ? 5 : 3);
 };
 
+#ifndef DW_PAIR
+#define DW_PAIR 1
+#endif
 template <int CIN, int COUT, bool EX, int KPBT = 0, bool PRE = false>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
@@ -845,8 +848,14 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   constexpr int V = (CIN + 3) / 4, CINP = 4 * V;        // x quarter-row width (as in the forward kernel)
   constexpr int W = (COUT + 3) / 4, COUTP = 4 * W;      // dy quarter-row width
   constexpr int XS = 64 * CINP, YS = 64 * COUTP;        // per-wave LDS tiles (64 rows)
+  // PAIR (round 4): rows of at most 8 channels fill half of the 16 A rows of an MFMA tile — two offsets share one tile
+  // (A rows 0..7 = the channels of offset 2p, rows 8..15 = those of offset 2p+1, from two LDS tiles; B = dy for both):
+  // half the MFMAs and half the fragment reads for the <8,8> / <8,12> gradients.  Same products, same order of
+  // additions per (offset, channel pair): bit-identical to the unpaired form.
+  constexpr bool PAIR = DW_PAIR && MT * NT == 1 && CIN == 8 && KPBT == 0 && !EX && !PRE;
+  constexpr int XT = PAIR ? 2 : 1;                       // x tiles per wave
   constexpr int RED = DW_KPB * MT * 16 * NT * 16;
-  constexpr int LDS_FLOATS = (4 * (XS + YS) > RED) ? 4 * (XS + YS) : RED;
+  constexpr int LDS_FLOATS = (4 * (XT * XS + YS) > RED) ? 4 * (XT * XS + YS) : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -871,9 +880,13 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)((int64_t)table_rows * ld * 4));
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dy, (uint32_t)(((n_out * groups - 1) * ld_dy + COUT) * 4));
   const uint32_t ld4 = (uint32_t)ld * 4u;
-  float *xs = lds + wave * (XS + YS);   // [64][CINP]  gathered feature rows of the current offset
-  float *ys = xs + XS;                  // [64][COUTP] output-gradient rows of the chunk
+  float *xs = lds + wave * (XT * XS + YS);   // [64][CINP]  gathered feature rows of the current offset (PAIR: of two offsets)
+  float *ys = xs + XT * XS;                  // [64][COUTP] output-gradient rows of the chunk
 
+  constexpr int NP = (DW_KPB + 1) / 2;                   // PAIR: offset pairs (the last one may be half empty)
+  f32x4 accp[PAIR ? NP : 1];
+#pragma unroll
+  for (int p = 0; p < (PAIR ? NP : 1); ++p) accp[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc[DW_KPB][MT][NT];
 #pragma unroll
   for (int kk = 0; kk < DW_KPB; ++kk)
@@ -938,6 +951,22 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       float *p = RCX ? xs + (m * RPI + rc_row) * CINP + rc_chunk * 4 : xs + (m * 16 + i16) * CINP + q * V;
 #pragma unroll
       for (int s = 0; s < GW; ++s) p[s] = g[m][s];
+    }
+  };
+  auto store_rows_to = [&](const float(&g)[NI][GW], float *tile) {   // RCX shapes only (PAIR)
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      float *p = tile + (m * RPI + rc_row) * CINP + rc_chunk * 4;
+#pragma unroll
+      for (int s = 0; s < GW; ++s) p[s] = g[m][s];
+    }
+  };
+  auto mma_pair = [&](int p, const float(&b)[16][NT]) {   // lanes i16 < 8: tile 0 (offset 2p), i16 >= 8: tile 1 (offset 2p+1)
+    const float *src = xs + (i16 >> 3) * XS + (i16 & 7);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float a = ((i16 & 7) < CINP) ? src[(4 * t + q) * CINP] : 0.f;
+      accp[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t][0], accp[p], 0, 0, 0);
     }
   };
   auto mma_chunk = [&](int kk, const float(&b)[16][NT]) {
@@ -1025,7 +1054,26 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
         b[t][nt] = (co < COUTP) ? ys[(4 * t + q) * COUTP + co] : 0.f;
       }
 
-    if constexpr (MT * NT == 1) {
+    if constexpr (PAIR) {
+      static_assert(RCX, "the paired path stores row-contiguous gathers");
+      // two offsets per MFMA tile; the rows of the next pair are gathered before the MFMA block of the current one
+      float ga[2][NI][GW], gb[2][NI][GW], kd[PM];
+      auto idx_of = [&](int kk) { return kk < DW_KPB ? idxv[kk < DW_KPB ? kk : 0] : -1; };   // past the group: no rule
+      gather(idx_of(0), ga[0], kd);
+      gather(idx_of(1), gb[0], kd);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (p + 1 < NP) {
+          gather(idx_of(2 * p + 2), ga[(p + 1) & 1], kd);
+          gather(idx_of(2 * p + 3), gb[(p + 1) & 1], kd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_rows_to(ga[p & 1], xs);
+        store_rows_to(gb[p & 1], xs + XS);
+        mma_pair(p, b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (MT * NT == 1) {
       // narrow layers: little MFMA work per gather -> prefetch the next offset's rows (ping-pong registers)
       float g0[NI][GW], g1[NI][GW], k0_[PM], k1_[PM];
       gather(idxv[0], g0, k0_);
@@ -1063,7 +1111,23 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   __syncthreads();
   float *red = lds;
   for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
+    if constexpr (PAIR) {
+      if (wave == wv) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = q * 4 + i, kk = 2 * p + (row >> 3), ci = row & 7, co = i16;   // A row -> (offset, channel)
+            if (kk < DW_KPB) {
+              float *pr = &red[(kk * MT * 16 + ci) * NT * 16 + co];
+              if (wv == 0)
+                *pr = accp[p][i];
+              else
+                *pr += accp[p][i];
+            }
+          }
+      }
+    } else if (wave == wv) {
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; ++kk)
 #pragma unroll

@@ -462,6 +462,10 @@ int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, c
  * setting.
  * ------------------------------------------------------------------------- */
 int sgnn_prog_set_fusion(int on);
+/* a per-site linear head that is the only reader of a BatchNormReLU (the surface head): 1 (default) = its data gradient
+ * dy w is formed inside the two BatchNorm backward passes instead of being written and read back (bit-identical values);
+ * 0 = k_linear_bwd writes it.  Applies to programs planned after the call.  Returns the previous setting. */
+int sgnn_prog_set_lin_bn(int on);
 /* BatchNormReLU -> convolution (torch/model.py:37-42, 181, 187, 256: every scn.BatchNormReLU in front of a
  * SubmanifoldConvolution / Convolution).  sgnn_prog_set_bn_fold(1): when the convolution is the only reader of the
  * BatchNorm output, the executor launches no apply pass — the convolution (forward, and its weight gradient in backward)

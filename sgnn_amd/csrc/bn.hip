@@ -77,14 +77,14 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
 //   MODE 0 (forward stats):  a = x,            b = x*x
 //   MODE 1 (backward):       a = dz,           b = dz * xhat      (dz = dy masked by the ReLU/leak)
 // ldx / ld_dy: row strides in floats (>= c; rows of a column range of a wider buffer)
-template <int VEC, int MODE>
+template <int VEC, int MODE, bool LIN = false>
 __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x, int64_t ldx,
                                                    const float *__restrict__ dy, int64_t ld_dy, int64_t n, int c,
                                                    int cq, int rpb, const float *__restrict__ mean,
                                                    const float *__restrict__ invstd,
                                                    const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float leak,
-                                                   double *__restrict__ partial, const int64_t *n_dev) {
+                                                   double *__restrict__ partial, const int64_t *n_dev, BnLin lin) {
   extern __shared__ double sh[];  // [rpb][2][c] would be large; reduce per column group instead
   const int tid = threadIdx.x;
   unsigned nblk = gridDim.x;
@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
 #pragma unroll
   for (int v = 0; v < VEC; ++v) sa[v] = sb[v] = 0.0;
   float m_[VEC], is_[VEC], g_[VEC], b_[VEC];
+  float lw[2][VEC];        // LIN: the head's weight rows for this thread's channels (BnLin)
+  if constexpr (LIN) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) lw[o][v] = (active && o < lin.nout) ? lin.w[o][col * VEC + v] : 0.f;
+  }
   if (MODE == 1 && active) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -131,7 +138,19 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float *__restrict__ x,
         keep[it] = rr < n;
         const int64_t rc = rr < n ? rr : row;
         load_vec<VEC>(x + rc * ldx + col * VEC, xv[it]);
-        if (MODE == 1) load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[it]);
+        if constexpr (LIN) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) dv[it][v] = 0.f;
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+            if (o < lin.nout) {
+              const float gv = lin.g[rc * lin.ldg + o];
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) dv[it][v] = fmaf(gv, lw[o][v], dv[it][v]);
+            }
+        } else if (MODE == 1) {
+          load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[it]);
+        }
       }
 #pragma unroll
       for (int it = 0; it < BN_FLUSH; ++it) {
@@ -399,7 +418,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restric
   }
 }
 
-template <int VEC>
+template <int VEC, bool LIN = false>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, int64_t ldx,
                                                      const float *__restrict__ dy, int64_t ld_dy, int64_t n, int c,
                                                      int cq, int rpb, const float *__restrict__ mean,
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                      const float *__restrict__ beta, float leak, int training,
                                                      const float *__restrict__ coef, float *dx, int64_t ld_dx,
                                                      BnFuse fuse, const float *addend, int64_t ld_add,
-                                                     const int64_t *n_dev) {
+                                                     const int64_t *n_dev, BnLin lin) {
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   n = sgnn_dyn_n(n, n_dev);
@@ -440,6 +459,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     k4[v] = training ? coef[ch] : 0.f;
     k5[v] = training ? coef[c + ch] : 0.f;
   }
+  float lw[2][VEC];
+  if constexpr (LIN) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) lw[o][v] = o < lin.nout ? lin.w[o][col * VEC + v] : 0.f;
+  }
   const int64_t step = (int64_t)gridDim.x * rpb;
   for (int64_t r0 = (int64_t)blockIdx.x * rpb + rloc; r0 < n; r0 += step * BN_U) {
     float xv[BN_U][VEC], dv[BN_U][VEC], av[BN_U][VEC];
@@ -447,7 +473,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     for (int u = 0; u < BN_U; ++u) {
       const int64_t r = r0 + u * step, rc = (r < n ? r : r0);
       load_vec<VEC>(x + rc * ldx + col * VEC, xv[u]);
-      load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[u]);
+      if constexpr (LIN) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dv[u][v] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+          if (o < lin.nout) {
+            const float gv = lin.g[rc * lin.ldg + o];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) dv[u][v] = fmaf(gv, lw[o][v], dv[u][v]);
+          }
+      } else {
+        load_vec<VEC>(dy + rc * ld_dy + col * VEC, dv[u]);
+      }
       if (addend) load_vec<VEC>(addend + rc * ld_add + col * VEC, av[u]);      // uniform over the launch
     }
 #pragma unroll
@@ -519,10 +557,10 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
       const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
       if (g.vec == 4)
         SGNN_LAUNCH((k_bn_partial<4, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
-                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev, BnLin{});
       else
         SGNN_LAUNCH((k_bn_partial<1, 0>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, nullptr, 0, n, c,
-                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev);
+                           g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev, BnLin{});
       partial = (const double *)ws;
     }
     if (!own_finalize && bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
@@ -599,15 +637,16 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
                      const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
                      const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream,
-                     const int64_t *n_dev) {
+                     const int64_t *n_dev, const BnLin *lin) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
+  SGNN_CHECK_ARG(!lin || (lin->g && lin->nout >= 1 && lin->nout <= 2 && lin->w[0] && (lin->nout < 2 || lin->w[1]) && !pre_partial));
   if (n == 0) {
     if (dgamma) SGNN_HIP_TRY(hipMemsetAsync(dgamma, 0, c * sizeof(float), s));
     if (dbeta) SGNN_HIP_TRY(hipMemsetAsync(dbeta, 0, c * sizeof(float), s));
     return SGNN_OK;
   }
-  SGNN_CHECK_ARG(x && dy && dx);
+  SGNN_CHECK_ARG(x && (dy || lin) && dx);
   if (ldx <= 0) ldx = c;
   if (ld_dy <= 0) ld_dy = c;
   if (ld_dx <= 0) ld_dx = c;
@@ -628,12 +667,18 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
   if (!partial) {
     nblk = bn_blocks(n, g);
     const size_t shbytes = (size_t)g.rpb * g.cq * 2 * g.vec * sizeof(double);
-    if (g.vec == 4)
+    if (lin && g.vec == 4)
+      SGNN_LAUNCH((k_bn_partial<4, 1, true>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev, *lin);
+    else if (lin)
+      SGNN_LAUNCH((k_bn_partial<1, 1, true>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev, *lin);
+    else if (g.vec == 4)
       SGNN_LAUNCH((k_bn_partial<4, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
-                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev, BnLin{});
     else
       SGNN_LAUNCH((k_bn_partial<1, 1>), dim3((unsigned)nblk), dim3(256), shbytes, s, x, ldx, dy, ld_dy, n, c, g.cq,
-                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev);
+                         g.rpb, save_mean, save_invstd, gamma, beta, leak, (double *)ws, n_dev, BnLin{});
     partial = (const double *)ws;
   }
   BnFuse fuse{nullptr, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -642,12 +687,18 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
   else
     SGNN_LAUNCH(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef, n_dev);
   const int grid = bn_apply_grid(n, g);
-  if (g.vec == 4)
+  if (lin && g.vec == 4)
+    SGNN_LAUNCH((k_bn_bwd_apply<4, true>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, *lin);
+  else if (lin)
+    SGNN_LAUNCH((k_bn_bwd_apply<1, true>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, *lin);
+  else if (g.vec == 4)
     SGNN_LAUNCH((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, BnLin{});
   else
     SGNN_LAUNCH((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev);
+                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, BnLin{});
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -55,6 +55,15 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
                        const int32_t *kadd, int in_mul, int groups, int table_rows, const ConvEpi *epi,
                        sgnn_stream_t stream);
 int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K);
+// BatchNorm backward whose incoming gradient is the data gradient of a per-site linear head that nobody else reads (the
+// surface head, model.py:433-447): dy[r][ch] = sum_o g[r*ldg + o] * w[o][ch] is formed in the two BatchNorm passes instead of
+// being written (k_linear_bwd) and read back twice — the same fmaf chain, bit-identical values.
+struct BnLin {
+  const float *g;
+  int64_t ldg;
+  const float *w[2];
+  int nout;
+};
 // bn.hip internals used by prog.hip (strided rows, statistics partials supplied by a convolution epilogue)
 // n_dev (every internal entry point below, default NULL): device row count, clamped to the host value n, which then
 // is the capacity the launch is sized for
@@ -67,7 +76,7 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
                      const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
                      const double *pre_partial, int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream,
-                     const int64_t *n_dev = nullptr);
+                     const int64_t *n_dev = nullptr, const struct BnLin *lin = nullptr);
 bool sgnn_conv_epi_supported(int cin, int cout);
 bool dw_shape_ok(int cin, int cout);   // conv.hip: compiled weight-gradient shapes (strided rows need one)
 // deferred weight-gradient reduces (conv.hip): partial[nblk][elems] -> dw[elems], many tensors in one launch

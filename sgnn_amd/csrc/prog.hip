@@ -57,6 +57,7 @@ std::vector<int> count_readers(const View &v) {
 }
 
 bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
+bool g_lin_bn = true; // sgnn_prog_set_lin_bn: the head's data gradient formed inside the BatchNorm backward passes (BnLin)
 // sgnn_prog_set_bn_fold(1): BatchNormReLU layers whose only reader is a convolution launch no apply pass — the convolution
 // normalises the rows in its gather (BnPre).  2 = its exact A/B reference: the same statistics (finalised in the same
 // kernel), an apply pass, the convolution on the stored rows — bit-identical results.  0 (default) = the round-3 path: the
@@ -80,6 +81,7 @@ struct Plan {
   std::vector<char> join_view;   // per op: this JoinTable is in place
   std::vector<int> bn_fold;      // per op: a BatchNorm folded into the gather of convolution bn_fold[j] (-1: applies itself)
   std::vector<int> pre_bn;       // per op: the BatchNorm folded into this convolution's gather (-1: none)
+  std::vector<int> lin_bn;       // per op: a LINEAR head whose data gradient is formed inside the backward pass of BatchNorm lin_bn[i] (BnLin; -1: written)
 };
 
 // shapes of the grouped / remapped walk the up-sampling convolution uses (conv.hip CONV_EX_CASES) with a compiled weight gradient
@@ -92,6 +94,7 @@ void make_plan(const View &v, const int32_t *keep, Plan &P) {
   P.join_view.assign(v.nops, 0);
   P.bn_fold.assign(v.nops, -1);
   P.pre_bn.assign(v.nops, -1);
+  P.lin_bn.assign(v.nops, -1);
   P.root.resize(v.nbuf);
   P.col.assign(v.nbuf, 0);
   P.ld.resize(v.nbuf);
@@ -104,6 +107,16 @@ void make_plan(const View &v, const int32_t *keep, Plan &P) {
   if (keep)
     for (int b = 0; b < v.nbuf; ++b)
       if (keep[b]) ++readers[b];
+  // a per-site head that is the ONLY reader of a BatchNormReLU's output: its data gradient is never stored (BnLin)
+  if (g_lin_bn)
+    for (int i = 0; i < v.nops; ++i) {
+      const int32_t *o = v.ops + OPW * i;
+      if (o[0] != OP_LINEAR || o[7] > 2 || readers[o[1]] != 1) continue;
+      for (int j = 0; j < i; ++j) {
+        const int32_t *b = v.ops + OPW * j;
+        if (b[0] == OP_BN && b[3] == o[1] && b[5] == o[5]) P.lin_bn[i] = j;
+      }
+    }
   // fused AddTable
   for (int i = 0; i + 1 < v.nops; ++i) {
     const int32_t *o = v.ops + OPW * i, *a = v.ops + OPW * (i + 1);
@@ -452,6 +465,11 @@ SGNN_EXPORT int64_t sgnn_prog_set_bn_fold_rows(int64_t rows) {
   return prev;
 }
 
+SGNN_EXPORT int sgnn_prog_set_lin_bn(int on) {
+  const int prev = g_lin_bn ? 1 : 0;
+  g_lin_bn = on != 0;
+  return prev;
+}
 SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
   const int prev = g_fuse ? 1 : 0;
   g_fuse = on != 0;
@@ -686,6 +704,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   // gradients into the arena)
   std::vector<char> init(nbuf, 0);
   std::vector<int> alias(nbuf, -1);
+  std::vector<int> lazy_lin(nbuf, -1);   // buffer -> LINEAR op whose data gradient the buffer's BatchNorm forms itself (BnLin)
   std::vector<char> viewed(nbuf, 0);      // storage shared through an in-place JoinTable: keeps the copying path
   for (int b = 0; b < nbuf; ++b)
     if (PL.root[b] != b) viewed[b] = viewed[PL.root[b]] = 1;
@@ -761,7 +780,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
     const int32_t *o = ops + OPW * i;
     const int type = o[0], in0 = o[1], in1 = o[2], out = o[3], par = o[4], lev = o[5], cin = o[6], cout = o[7];
     const int64_t n = lev_n[lev];
-    if (!init[out]) {  // no gradient reached this output: its producers contribute nothing
+    if (!init[out] && !(type == OP_BN && lazy_lin[out] >= 0)) {  // no gradient reached this output: its producers contribute nothing
       if (type == OP_CONV_SUBM || type == OP_CONV_DOWN || type == OP_EXPAND)
         PROG_TRY(sgnn_fill32(PG(par), 0u, (int64_t)(type == OP_CONV_DOWN ? 8 : 27) * cin * cout, hs));
       if (type == OP_BN) {
@@ -871,9 +890,18 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           ld_add = GRLD(in0);
         }
         float *t = wants(in0) ? G(in0) : scratch[0];
-        PROG_TRY(sgnn_bn_bwd_impl(X(in0), LD(in0), dy, ld_dy, n, cin, P(par), P(par + 1), save, save + cin, training,
+        BnLin bl{};
+        const bool lazy = lazy_lin[out] >= 0;
+        if (lazy) {                       // dy = (gradient of the head's output) x (the head's weights), never stored
+          const int32_t *lo = ops + OPW * lazy_lin[out];
+          bl.g = GR(lo[3]);
+          bl.ldg = GRLD(lo[3]);
+          bl.nout = lo[7];
+          for (int q = 0; q < lo[7]; ++q) bl.w[q] = P(lo[4] + 2 * q);
+        }
+        PROG_TRY(sgnn_bn_bwd_impl(X(in0), LD(in0), lazy ? nullptr : dy, ld_dy, n, cin, P(par), P(par + 1), save, save + cin, training,
                                   opf[4 * i + 2], addend, ld_add, t, wants(in0) ? LD(in0) : cin, PG(par), PG(par + 1), pre[i],
-                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev)));
+                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev), lazy ? &bl : nullptr));
         if (wants(in0)) {
           init[in0] = 1;
           alias[in0] = -1;
@@ -983,6 +1011,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           db[q] = PG(par + 2 * q + 1);
         }
         SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
+        if (PL.lin_bn[i] >= 0 && wants(in0) && !init[in0] && n > 0 && !pre[PL.lin_bn[i]]) {
+          // weight / bias gradients only; the BatchNorm before the head forms dx = dy w itself in both of its passes
+          PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, nullptr, dw, db, ws, ws_bytes, stream, CNT(lev)));
+          lazy_lin[in0] = i;
+          break;
+        }
         float *t = wants(in0) ? target(in0, 0) : nullptr;
         PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, t, dw, db, ws, ws_bytes, stream, CNT(lev)));
         if (t) PROG_TRY(commit(in0, t));

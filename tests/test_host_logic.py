@@ -1,11 +1,15 @@
 """Host-side logic that needs no GPU: module layout / state-dict contract, loss restatement, curriculum,
 synthetic data layout."""
+import os
+
 import numpy as np
 import torch
 
 import model_oracle as mo
 from sgnn_amd import synth, loss as L
 from sgnn_amd.train import get_loss_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_genmodel_layout_matches_oracle_and_reference_param_count():
@@ -379,3 +383,20 @@ def test_flat_adam_collect_leaves_no_stale_gradient_behind():
     assert torch.equal(opt.views_g[1], torch.zeros(5)) and torch.equal(opt.views_g[0], torch.ones(4, 3))
     g = opt.named_gradients(torch.nn.ParameterList(pa + pb))
     assert len(g) == 4 and all(v is not None for v in g.values())
+
+
+def test_sgnn_tune_calls_the_named_switches_and_rejects_anything_else():
+    """SGNN_TUNE is the measurement hook behind scripts/ab_env2.sh: `name=value` pairs call integer switches of the library
+    once at load; a name that is not a switch must raise instead of being ignored (a typo would silently A/B nothing)."""
+    import subprocess
+    import sys
+    code = ("from sgnn_amd import _lib; lib = _lib.load(); "
+            "print(lib.sgnn_conv_set_one_round(1), lib.sgnn_conv_set_dw_blocks(256), lib.sgnn_prog_set_lin_bn(1))")
+    env = dict(os.environ, SGNN_TUNE='sgnn_conv_set_one_round=0,sgnn_conv_set_dw_blocks=341,sgnn_prog_set_lin_bn=0')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['0', '341', '0']          # the setters return what SGNN_TUNE had installed
+    for bad in ('sgnn_conv_fwd=1', 'no_such_switch=1'):
+        env = dict(os.environ, SGNN_TUNE=bad)
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert out.returncode != 0 and 'SGNN_TUNE' in out.stderr

@@ -474,7 +474,9 @@ int sgnn_prog_set_lin_bn(int on);
  * and the convolution on the stored rows — bit-identical results.  0 (DEFAULT) = every BatchNorm applies itself (on small
  * levels its apply kernel also finalises the statistics).  The fold is built and tested but measured neutral (it moves an
  * HBM streaming pass into the VALU work of two gather-bound kernels), hence not the default.
- * Returns the previous setting. */
+ * A training forward call remembers the setting (and the rows threshold below) it ran with under its arena's address and
+ * the backward call of that arena uses the remembered one: flipping the switch between a forward pass and its backward
+ * pass cannot desynchronise the pair.  Returns the previous setting. */
 int sgnn_prog_set_bn_fold(int on);
 /* rows class size from which the fold applies (default 0 = every level); returns the previous value */
 int64_t sgnn_prog_set_bn_fold_rows(int64_t rows);

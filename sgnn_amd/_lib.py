@@ -161,9 +161,17 @@ def load():
         # switches once (scripts/ab_env2.sh SGNN_TUNE a=1 a=2 compares two settings on one box)
         for item in filter(None, os.environ.get('SGNN_TUNE', '').split(',')):
             name, _, val = item.partition('=')
-            if name not in PROTOTYPES or '_set_' not in name:
-                raise SgnnError('SGNN_TUNE: %r is not a switch of the library' % name)
-            getattr(lib, name)(int(val))
+            proto = PROTOTYPES.get(name)
+            # a switch = an entry point named *_set_* that takes exactly one integer (sgnn_prog_set_side_stream takes pointers)
+            if proto is None or '_set_' not in name or list(proto[1]) not in ([c_i32], [c_i64]):
+                raise SgnnError('SGNN_TUNE: %r is not an integer switch of the library' % name)
+            if not hasattr(lib, name):
+                raise SgnnError('SGNN_TUNE: the library at %s does not export %s' % (LIB_PATH, name))
+            try:
+                ival = int(val)
+            except ValueError:
+                raise SgnnError('SGNN_TUNE: %s=%r is not an integer' % (name, val))
+            getattr(lib, name)(ival)
         _lib = lib
     return _lib
 

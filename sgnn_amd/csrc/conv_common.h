@@ -1,5 +1,7 @@
-// Pieces shared by the convolution kernels (conv.hip: register-gather kernels; conv_lds.hip: LDS-DMA gather kernel).
+// Pieces shared by the convolution kernels (conv.hip: looped register-gather kernels, small-level kernel, weight gradients;
+// conv_unrolled.hip: the straight-line variants).  (The LDS-DMA gather kernel that also used this header was deleted in round 4.)
 #pragma once
+#include <atomic>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,17 +38,25 @@ struct ConvEx {
 
 // resident workgroups of a 256-thread kernel on the whole device (occupancy x CUs), cached per instantiation: the large-level
 // kernels size their row tiles so that ONE round of workgroups covers the level (k_conv_fwd; sgnn_conv_set_one_round)
+// Per DEVICE (a process may drive several) and thread-safe: relaxed atomics, every thread that races computes the same value.
+// A failed query is NOT cached (0 = "one-round mode off" would otherwise stick for the life of the process).  The J-tile
+// decomposition of a level — and with it the fp64 grouping of the BatchNorm statistics partials — follows this value, so
+// statistics are bit-reproducible per (device model, driver, compiler), not across them (include/sgnn_hip.h says so).
+// hipOccupancyMaxActiveBlocksPerMultiprocessor is a host-side query: legal during a stream capture.
 template <auto KERNEL>
 static int conv_wg_capacity() {
-  static int cap = -1;
-  if (cap < 0) {
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      per_cu = cus = 0;
-    cap = per_cu * cus;
-  }
-  return cap;
+  static std::atomic<int> cache[16];   // zero-initialised; value + 1 is stored so that 0 means "not computed yet"
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  const int slot = dev & 15;
+  const int have = cache[slot].load(std::memory_order_relaxed);
+  if (have > 0 && (dev < 16)) return have - 1;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  if (dev < 16) cache[slot].store(per_cu * cus + 1, std::memory_order_relaxed);
+  return per_cu * cus;
 }
 extern int g_conv_one_round;
 

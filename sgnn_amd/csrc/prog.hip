@@ -10,6 +10,7 @@
 // per stage and direction replaces ~12 Python autograd nodes and their tensor allocations.
 // Host-side code only: no kernels here.
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "common.h"
 
@@ -68,6 +69,25 @@ bool g_lin_bn = true; // sgnn_prog_set_lin_bn: the head's data gradient formed i
 // built, bit-identical, tested (tests/test_gpu_bn_fold.py), off by default.
 int g_bn_fold = 0;    // 0 (default): every BatchNorm applies itself; 1: folded into the consumer's gather; 2: exact reference of 1
 int64_t g_bn_fold_min_rows = 0;           // fold only rows classes of at least this size (sgnn_prog_set_bn_fold_rows)
+// The fold decides which buffers a forward pass WRITES (a folded BatchNorm's output rows never exist) and which rows its
+// backward pass re-reads, so a forward / backward pair must agree on it whatever the switches say in between: a
+// training forward call remembers the setting it ran with under its arena's address, the backward call of that arena uses it.
+struct FoldMode {
+  int fold;
+  int64_t min_rows;
+};
+std::mutex g_fold_mu;
+std::unordered_map<const void *, FoldMode> g_fold_of_arena;
+void remember_fold(const void *arena, FoldMode m) {
+  std::lock_guard<std::mutex> hold(g_fold_mu);
+  if (g_fold_of_arena.size() > 4096) g_fold_of_arena.clear();   // arenas come and go with the allocator: bounded
+  g_fold_of_arena[arena] = m;
+}
+FoldMode fold_of(const void *arena) {
+  std::lock_guard<std::mutex> hold(g_fold_mu);
+  auto it = g_fold_of_arena.find(arena);
+  return it != g_fold_of_arena.end() ? it->second : FoldMode{g_bn_fold, g_bn_fold_min_rows};
+}
 
 // What the executor decides once per call, identically in forward and backward:
 //  * add_dst[i] >= 0: convolution i writes straight into the output of the AddTable right behind it (fused add);
@@ -88,7 +108,7 @@ struct Plan {
 inline bool expand_shape_ok(int cin, int cout) { return (cin == 48 && cout == 16) || (cin == 24 && cout == 8); }
 
 
-void make_plan(const View &v, const int32_t *keep, Plan &P) {
+void make_plan(const View &v, const int32_t *keep, Plan &P, int64_t fold_min_rows = g_bn_fold_min_rows) {
   P.add_dst.assign(v.nops, -1);
   P.skip.assign(v.nops, 0);
   P.join_view.assign(v.nops, 0);
@@ -189,7 +209,7 @@ void make_plan(const View &v, const int32_t *keep, Plan &P) {
       // the statistics itself — folding would swap one launch for another (the finalise kernel) and charge the convolution and
       // its weight gradient five VALU operations per gathered value for it: measured neutral to slightly negative
       // (profiles/r04d_ab3b.txt), so small levels keep their apply pass.
-      if (v.lev_n && v.lev_n[bo[5]] < g_bn_fold_min_rows) continue;
+      if (v.lev_n && v.lev_n[bo[5]] < fold_min_rows) continue;
       const int i = last_reader[o];
       const int32_t *co = v.ops + OPW * i;
       if (P.skip[i] || co[1] != o || co[6] != bo[6]) continue;
@@ -521,10 +541,13 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || ext));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Plan PL;
-  make_plan(v, keep, PL);
+  const FoldMode fm{g_bn_fold, g_bn_fold_min_rows};
+  const int fold = fm.fold;
+  make_plan(v, keep, PL, fm.min_rows);
   Layout L;
   const bool infer = (training & 2) != 0;     // inference layout: no backward call may follow
   training &= 1;
+  if (!infer) remember_fold(arena, fm);
   SGNN_CHECK_ARG(make_layout(v, PL, L, infer, keep) == 0);
   if (arena_floats < L.fwd_total) {
     sgnn_set_error("sgnn_prog_forward: arena too small (%lld < %lld floats)", (long long)arena_floats,
@@ -594,7 +617,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         epi.ldy = LD(dst_buf);
         epi.n_dev = CNT(down ? lev + 1 : lev);
         const float *xin = B(in0);
-        if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {     // the BatchNormReLU in front of this convolution lives in its gather: read the raw rows
+        if (fold == 1 && PL.pre_bn[i] >= 0) {     // the BatchNormReLU in front of this convolution lives in its gather: read the raw rows
           const int jb = PL.pre_bn[i];
           const int32_t *bo = ops + OPW * jb;
           const float *save = arena + L.aux_off[jb];
@@ -613,7 +636,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
       case OP_BN: {
         float *save = arena + L.aux_off[i];
         // folded into its consumer's gather: statistics only; fold switched off: the exact A/B reference (own finalise kernel)
-        const int mode = (PL.bn_fold[i] >= 0 && g_bn_fold) ? (g_bn_fold == 1 ? 3 : 2) : 0;
+        const int mode = (PL.bn_fold[i] >= 0 && fold) ? (fold == 1 ? 3 : 2) : 0;
         PROG_TRY(sgnn_bn_fwd_impl(B(in0), LD(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
                                   opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), LD(out), pre[i],
                                   pre_nblk[i], ws, ws_bytes, stream, CNT(lev), mode));
@@ -635,7 +658,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       }
       case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
-        SGNN_CHECK_ARG(ROWS(out) == 8 * n && (LD(in0) == cin || (g_bn_fold == 1 && PL.pre_bn[i] >= 0)) && LD(out) == cout);
+        SGNN_CHECK_ARG(ROWS(out) == 8 * n && (LD(in0) == cin || (fold == 1 && PL.pre_bn[i] >= 0)) && LD(out) == cout);
         const int32_t *S, *ST, *PAR;
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         float *wc = arena + L.aux_off[i];
@@ -643,7 +666,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         ConvEpi xepi{};
         xepi.n_dev = CNT(lev);
         const float *xin = B(in0);
-        if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {
+        if (fold == 1 && PL.pre_bn[i] >= 0) {
           const int jb = PL.pre_bn[i];
           const int32_t *bo = ops + OPW * jb;
           const float *save = arena + L.aux_off[jb];
@@ -689,7 +712,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || (ext && gext)));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Plan PL;
-  make_plan(v, keep, PL);             // the same decisions the forward call took (same inputs)
+  const FoldMode fm = fold_of(arena);   // the fold setting of the forward call that filled this arena
+  const int fold = fm.fold;
+  make_plan(v, keep, PL, fm.min_rows);  // the same decisions the forward call took (same inputs)
   Layout L;
   SGNN_CHECK_ARG(make_layout(v, PL, L) == 0);
   if (arena_floats < L.total || ws_bytes < ws_need(v)) {
@@ -857,7 +882,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           const float *xw = X(in0);
           int64_t ldxw = LD(in0);
           BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
-          if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {       // the rows this convolution saw = BatchNormReLU of the stored rows: recomputed in the gather
+          if (fold == 1 && PL.pre_bn[i] >= 0) {       // the rows this convolution saw = BatchNormReLU of the stored rows: recomputed in the gather
             const int jb = PL.pre_bn[i];
             const int32_t *bo = ops + OPW * jb;
             const float *save = arena + L.aux_off[jb];
@@ -971,7 +996,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         float *dwc = side ? (float *)(dw_base + dw_off + dw_slice(v, i) - expand_dwc_bytes(cin, cout)) : garena + L.bextra;
         float *part = garena + L.bextra + round64(64 * (int64_t)cin * cout);
         const hipStream_t lane = dw_lane();
-        SGNN_CHECK_ARG(ld_dy == cout && (LD(in0) == cin || (g_bn_fold == 1 && PL.pre_bn[i] >= 0)));
+        SGNN_CHECK_ARG(ld_dy == cout && (LD(in0) == cin || (fold == 1 && PL.pre_bn[i] >= 0)));
         if (wants(in0) && n > 0) {
           // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
           const int Gs = EXPAND_DX_SPLIT;
@@ -987,7 +1012,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           const float *xw = X(in0);
           int64_t ldxw = cin;
           BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
-          if (g_bn_fold == 1 && PL.pre_bn[i] >= 0) {
+          if (fold == 1 && PL.pre_bn[i] >= 0) {
             const int jb = PL.pre_bn[i];
             const int32_t *bo = ops + OPW * jb;
             const float *save = arena + L.aux_off[jb];

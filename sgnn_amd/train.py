@@ -532,6 +532,12 @@ class FlatAdam(object):
             torch._foreach_zero_(stale)
         return reached
 
+    def zero_segments(self, which):
+        """Zero the gradient slices of the segments flagged in `which` (one fill per segment; capturable)."""
+        for (b, e), z in zip(self.bounds, which):
+            if z and e > b:
+                self.flat_g[b:e].zero_()
+
     def named_gradients(self, model):
         """{parameter name: what flat_g holds for it} — the gradients Adam consumes (after collect(): autograd-delivered
         ones copied in, program gradients written there by the backward kernels) — in the REFERENCE's layout (dense
@@ -676,7 +682,9 @@ class GraphStep(object):
         self.static = None
         self.loss = None
         self.losses = None
-        self.pending = []               # [(event, pinned status, batch, loss_weights)] of issued capacity steps
+        self.pending = []               # [(event, pinned status, batch, loss_weights, ...)] of issued steps, oldest first
+        self.slot_batch = None          # the batch whose gradients the current slot's grad_sync call carries ...
+        self.slot_kind = None           # ... and the kind of step that produced them: 'probe' | 'eager' | 'replay'
         self.stats = {'probe_steps': 0, 'eager_steps': 0, 'captures': 0, 'replays': 0, 'overflows': 0, 'replans': 0,
                       'replay_host_ms': 0.0}
         self._pins, self._npin = None, 0
@@ -716,6 +724,7 @@ class GraphStep(object):
         """Classic step (read-backs) that also sizes the capacities."""
         from .scn import metadata as MD
         nl, trunc, use_log, wgeo, masking = self.args
+        self.slot_batch, self.slot_kind = batch, 'probe'       # (what this slot's all-reduce carries: tests log it)
         self.opt.unbind()
         self._bound = False
         MD.runtime(batch['sdf'].device).state[1:2].zero_()     # a discarded capacity step may have left its overflow flag
@@ -838,6 +847,10 @@ class GraphStep(object):
             MD.join_pyramid_lane(st['sdf'].device)      # (also after an exception: nothing may outlive the keep-alive list)
             del P_._deferred[:]
         self.opt.collect()           # gradients autograd delivered (dense bottleneck); program gradients are in flat_g already
+        if self.grad_sync is not None:
+            # a stage these loss weights switch off runs no kernel at all, so nothing writes its slice of flat_g: make sure
+            # the all-reduce sums zeros there, not whatever an earlier curriculum stage left
+            self.opt.zero_segments([not a for a in self._active_segments(loss_weights)])
         return loss.detach(), losses, rt
 
     def _seg_cnts(self, loss_weights):
@@ -891,13 +904,16 @@ class GraphStep(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(rt.device))
         self._n_issued = getattr(self, '_n_issued', 0) + 1
-        self.pending.append((ev, pin, batch, loss_weights, None if probe else self.capacity, self._n_issued - 1))
+        # (the entry also keeps what the step's kernels touch alive until the host has seen the step end: under data
+        # parallelism a rank-local re-plan drops self.graphs / self.static while their last replay may still be in flight)
+        alive = None if probe else (self.graphs, self.static, getattr(self, '_keep', None))
+        self.pending.append((ev, pin, batch, loss_weights, None if probe else self.capacity, self._n_issued - 1, alive))
 
     def _check(self, keep):
         """Retire all but the `keep` newest issued steps; returns the batches whose step overflowed."""
         redo = []
         while len(self.pending) > keep:
-            ev, pin, batch, lw, cap, index = self.pending.pop(0)
+            ev, pin, batch, lw, cap, index, _alive = self.pending.pop(0)
             ev.synchronize()
             word = int(pin[0]) & 0xFFFFFFFF
             if cap is not None and cap is self.capacity:
@@ -966,46 +982,58 @@ class GraphStep(object):
 
     # -- the step -------------------------------------------------------------------------------------------
     def __call__(self, batch, loss_weights):
+        """One training step = one SLOT.  Under data parallelism (grad_sync) every slot is exactly one all-reduce on every
+        rank, whatever kind of step the rank runs in it (probe / eager capacity step / replay), and every rank retires its
+        status words at the same depth: slot k's word is read right after slot k+1 has been issued, never earlier — so the
+        common decisions (skip the update, re-run the batch) happen at the same point of every rank's collective sequence.
+        Rank-local decisions (this rank's input outgrew its capacity, this rank re-plans) only choose the KIND of step the
+        rank runs in a slot; they neither retire anything nor issue a collective.  What must be common to all ranks of a
+        slot: the loss weights and the batch SHAPE (they decide `key`), and calls to replan()."""
         loss_weights = np.asarray(loss_weights, dtype=np.float32)
         self.outputs = None
+        dp = self.grad_sync is not None
         key = (tuple(bool(w > 0) for w in loss_weights), tuple(batch['sdf'].shape))
         wkey = tuple(float(w) for w in loss_weights)
         if key != self.key:                          # new curriculum stage / batch shape: re-size and re-capture
-            self._drain()
+            self._drain()                            # (common to all ranks: see above)
             self.key, self.stage, self.graphs, self.capacity = key, 0, None, None
         if wkey != self.weights:                     # the loss weights are baked into the captured launches
             self._drain()
             self.weights, self.graphs = wkey, None
-        if self.stage == 0:
-            self._probe(batch, loss_weights)
-            self.stage = 1
-            return self.loss
         n_in = int(batch['input'][0].shape[0])
-        if n_in > self.capacity.input_rows:          # known on the host before anything is launched
-            self._drain()
+        if self.stage == 0 or n_in > self.capacity.input_rows:
+            # no plan yet, or (known on the host before anything is launched) the input level outgrew it: a classic step
+            # that also measures every level.  Rank-local under data parallelism: nothing in flight is retired here (the
+            # step before may carry a merged overflow that the peers will only see after THEIR next slot) — the pending
+            # entries keep the graph / buffers of their step alive instead.
+            if self.stage != 0 and not dp:
+                self._drain()
             self.graphs = None
             self._probe(batch, loss_weights)
             self.stage = 1
-            return self.loss
-        if self.stage == 1:
-            self._make_static(batch)
-        self._load(batch)
-        from .scn.metadata import runtime
-        rt = runtime(batch['sdf'].device)
-        if not self._bound:                          # programs were compiled by the probe step
-            self.opt.bind_programs(self.model)
-            self._bound = True
-        if self.stage in (1, 2):                     # eager capacity steps: warm-up, and while the row counts settle
-            loss, losses, _ = self._capacity_step_eager(loss_weights)     # (use_graph=False: forever)
-            self.stats['eager_steps'] += 1
-            if self.stage == 1:
-                self.stage = 3 if (self.use_graph and self.settle is False) else 2
+            if not dp:
+                return self.loss
         else:
-            if self.graphs is None:
-                self._capture(loss_weights)
-            loss, losses = self._replay()
-        self._issue_status(rt, batch, loss_weights)
-        self.loss, self.losses = loss, losses
+            if self.stage == 1:
+                self._make_static(batch)
+            self._load(batch)
+            from .scn.metadata import runtime
+            rt = runtime(batch['sdf'].device)
+            if not self._bound:                          # programs were compiled by the probe step
+                self.opt.bind_programs(self.model)
+                self._bound = True
+            self.slot_batch, self.slot_kind = batch, ('eager' if self.stage in (1, 2) else 'replay')
+            if self.stage in (1, 2):                     # eager capacity steps: warm-up, and while the row counts settle
+                loss, losses, _ = self._capacity_step_eager(loss_weights)     # (use_graph=False: forever)
+                self.stats['eager_steps'] += 1
+                if self.stage == 1:
+                    self.stage = 3 if (self.use_graph and self.settle is False) else 2
+            else:
+                if self.graphs is None:
+                    self._capture(loss_weights)
+                loss, losses = self._replay()
+            self._issue_status(rt, batch, loss_weights)
+            self.loss, self.losses = loss, losses
         redo = self._check(1)
         if redo:
             self._overflow(redo)
@@ -1058,9 +1086,14 @@ class GraphStep(object):
                 return
         # re-size from the live counts (moving up: leave more room than the steady-state headroom)
         self._loose = 0
-        self._drain()
-        if self.stage < 2:                     # the drain found an overflow and re-planned already
-            return
+        if self.grad_sync is None:
+            self._drain()
+            if self.stage < 2:                 # the drain found an overflow and re-planned already
+                return
+        # (data parallel: a re-plan is THIS rank's decision, so it must not retire the newest step's status word — that
+        # word may carry a merged overflow, and acting on it one slot before the peers do would put this rank's re-run
+        # all-reduce opposite the peers' next batch ("What's weak" 1).  The step in flight finishes on the
+        # old plan — its pending entry keeps graph and buffers alive — and a late overflow grows the NEW plan.)
         self._resize(live, 1.25 if tight else 1.0)
 
     def _resize(self, live, grow=1.0):

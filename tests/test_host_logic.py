@@ -396,7 +396,8 @@ def test_sgnn_tune_calls_the_named_switches_and_rejects_anything_else():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == ['0', '341', '0']          # the setters return what SGNN_TUNE had installed
-    for bad in ('sgnn_conv_fwd=1', 'no_such_switch=1'):
+    # not a switch; unknown; a *_set_* entry point that takes pointers; a value that is not an integer
+    for bad in ('sgnn_conv_fwd=1', 'no_such_switch=1', 'sgnn_prog_set_side_stream=1', 'sgnn_conv_set_one_round=on'):
         env = dict(os.environ, SGNN_TUNE=bad)
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
-        assert out.returncode != 0 and 'SGNN_TUNE' in out.stderr
+        assert out.returncode != 0 and 'SgnnError' in out.stderr and 'SGNN_TUNE' in out.stderr, (bad, out.stderr[-500:])

@@ -231,6 +231,14 @@ int sgnn_conv_set_dw_c1(int on);
  * Outputs are bit-identical either way; BatchNorm statistics partials are summed per workgroup, so their grouping
  * (fp64) differs.  Returns the previous setting. */
 int sgnn_conv_set_one_round(int on);
+/* epilogue of the 256-row rulebook walk for output rows of 8 / 12 / 16 channels (every FullyConvolutionalNet layer,
+ * torch/model.py:38-42, 180, 255, forward and data gradient): 1 (default) = the tile leaves the MFMA layout through a
+ * quad transpose, so the residual addend, the BatchNorm input of the backward statistics and the output rows move as
+ * row-contiguous 16-byte accesses, the operand loads issued under the last offset of the tile; 0 = one 4-byte access
+ * per accumulator element.  Used when every row stride involved is a multiple of 4 floats and the bases are 16-byte
+ * aligned (otherwise the element-wise form runs).  Stored rows are bit-identical; the fp64 statistics partials are
+ * summed in another fixed order.  Returns the previous setting. */
+int sgnn_conv_set_wide_epi(int on);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,

@@ -45,6 +45,7 @@ PROTOTYPES = {
     'sgnn_conv_set_dw_blocks': (c_i32, [c_i32]),
     'sgnn_conv_set_dw_c1': (c_i32, [c_i32]),
     'sgnn_conv_set_one_round': (c_i32, [c_i32]),
+    'sgnn_conv_set_wide_epi': (c_i32, [c_i32]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),

@@ -26,16 +26,20 @@
 static int g_small_grid = 160;             // ~40 k rows (sgnn_conv_set_small_rows: measurements)
 
 // EX = false: plain rulebook walk (ex is ignored; keeps the register budget of the hot instantiations)
-template <int CIN, int COUT, int M, bool EX, bool PRE = false>
-__global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
-                                                 const float *__restrict__ w, const int32_t *__restrict__ table,
-                                                 int64_t ld, int K, int64_t n_out, float *y, int flags,
-                                                 int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
+// WEPI: the wide (row-contiguous, 16-byte) epilogue of conv_common.h instead of the element-wise one
+// (the body of k_conv_fwd and k_conv_fwd_w below)
+template <int CIN, int COUT, int M, bool EX, bool PRE, bool WEPI>
+__device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64_t n_in,
+                                              const float *__restrict__ w, const int32_t *__restrict__ table,
+                                              int64_t ld, int K, int64_t n_out, float *y, int flags,
+                                              int in_shift, const ConvEx &ex, const ConvEpi &epi, int wg_cap) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, KC = C::KC;
   constexpr int RPW = 16 * M;   // rows per wave: M = 4 normally, 1 when the level is too small to fill the chip
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
   __shared__ double sred[4 * 2 * NT * 16];     // statistics scratch (the weight tile stays live across row tiles)
+  static_assert(!WEPI || (NT == 1 && M == 4 && !EX && COUT % 4 == 0), "wide epilogue: one column tile of whole 16-byte chunks");
+  __shared__ float ecst[WEPI ? 64 : 1];        // WEPI: per-column BatchNorm constants of the backward statistics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
   double s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+  if constexpr (WEPI) conv_epi_wide_constants<COUT>(ecst, epi, epi.stats);   // (visible after the barriers of the first stage())
 
   // one coalesced load fetches the wave's rule entries of an offset; lanes pick theirs with ds_bpermute
   // (the texture addresser, not HBM, is the scarce unit here: profiles/r01c_conv_pmc.txt)
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     lane_off = (uint32_t)(row0 + (lane & (RPW - 1))) * 4u;
   }
   const bool restage = j == 0 || K > KC;       // a weight tile that holds all K offsets is staged once
+  EpiRows<WEPI ? M : 1> erows;                 // WEPI: addend / BatchNorm-input rows of this tile, loaded under the last offset
 #pragma unroll
   for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -227,7 +233,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
     // (round 4: the B fragments run one offset ahead too — their ds_read is issued before the MFMAs of the current offset
     //  instead of right in front of its own, where every offset paid the LDS latency behind an lgkmcnt(0))
     float a0[M][V], a1[M][V], o0[PM], o1[PM], b0[NT][V], b1[NT][V];
-    for (int k0 = 0; k0 < K; k0 += KC) {
+    // (WEPI launches have K <= KC — the dispatcher checks: ONE chunk, so that the epilogue operands loaded under its last
+    //  offset are not values carried around a loop, which would keep their 32 registers allocated across the whole walk)
+    for (int k0 = 0; k0 < (WEPI ? 1 : K); k0 += KC) {
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       if (restage) stage(k0);
       int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
@@ -249,13 +257,41 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, i
         mma_b(a1, o1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (WEPI) {
+        // the epilogue's operand rows, issued while the rows of the last offset are still in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SGNN_WEPI_EARLY != 0) conv_epi_wide_prefetch<COUT, M>(erows, row0, n_out, epi, epi.stats, x, SGNN_WEPI_EARLY);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (kk < kc) mma_b(a0, o0, b0);
     }
   }
 
-  conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, EX ? 0 : epi.stats, x, s1, s2);
+  if constexpr (WEPI)
+    conv_epi_wide_finish<COUT, M>(acc, erows, row0, n_out, y, epi, epi.stats, ecst, s1, s2, x);
+  else
+    conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, EX ? 0 : epi.stats, x, s1, s2);
   }
   conv_epilogue_stats<COUT, NT>(s1, s2, epi, EX ? 0 : epi.stats, sred, blockIdx.x);
+}
+
+template <int CIN, int COUT, int M, bool EX, bool PRE = false>
+__global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
+                                                 const float *__restrict__ w, const int32_t *__restrict__ table,
+                                                 int64_t ld, int K, int64_t n_out, float *y, int flags,
+                                                 int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
+  conv_fwd_body<CIN, COUT, M, EX, PRE, false>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
+}
+
+// The 256-row kernel with the wide epilogue (plain walk, <= 16 channels either side, K <= 27).  Four waves per SIMD like the
+// element-wise kernel (92 + 16 registers): left to itself the register allocator takes 120 + 24 for the same loop — the
+// epilogue's operand rows raise the kernel's peak past 128, and once a wave per SIMD is gone anyway it relaxes the schedule of
+// the offset walk as well — so the occupancy is pinned and the allocator has to fit the walk into the 128 it needs there.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_fwd_w(
+    const float *__restrict__ x, int64_t n_in, const float *__restrict__ w, const int32_t *__restrict__ table, int64_t ld,
+    int K, int64_t n_out, float *y, int flags, int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
+  conv_fwd_body<CIN, COUT, CONV_MREP, false, false, true>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -587,6 +623,37 @@ SGNN_EXPORT int sgnn_conv_set_one_round(int on) {
   g_conv_one_round = on ? 1 : 0;
   return prev;
 }
+int g_conv_wide_epi = 1;     // sgnn_conv_set_wide_epi: 0 = the element-wise epilogue on every launch (A/B measurements)
+SGNN_EXPORT int sgnn_conv_set_wide_epi(int on) {
+  const int prev = g_conv_wide_epi;
+  g_conv_wide_epi = on ? 1 : 0;
+  return prev;
+}
+// the wide epilogue moves whole 16-byte chunks of a row: every row stride it touches must be a multiple of 4 floats and
+// the bases 16-byte aligned (views into a JoinTable buffer start at multiples of 16 columns; odd test strides fall back)
+bool conv_wide_epi_ok(const ConvEpi &epi, const float *y, int K) {
+  if (!g_conv_wide_epi || K > 27 || (epi.ldy & 3) || ((uintptr_t)y & 15)) return false;   // (27 = ConvCfg::KC for <= 16 channels)
+  if (epi.addend && ((epi.ld_add & 3) || ((uintptr_t)epi.addend & 15))) return false;
+  if (epi.stats == 2 && ((epi.ld_bnx & 3) || ((uintptr_t)epi.bn_x & 15))) return false;
+  return true;
+}
+// the 256-row kernel of a level: wide epilogue where the shape and the strides allow it
+template <int CI, int CO, bool EXV, bool PREV>
+static void conv_launch_big(unsigned grid4, hipStream_t s, const float *x, int64_t n_in, const float *w, const int32_t *table,
+                            int64_t ld, int K, int64_t n_out, float *y, int flags, int in_shift, const ConvEx &ex,
+                            const ConvEpi &epi) {
+  if constexpr (!EXV && !PREV && CO % 4 == 0 && CO <= 16 && CI <= 16) {
+    static_assert(ConvCfg<CI, CO>::KC >= 27, "one weight chunk holds a 3x3x3 filter");
+    if (conv_wide_epi_ok(epi, y, K)) {
+      SGNN_LAUNCH((k_conv_fwd_w<CI, CO>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, K, n_out, y, flags, in_shift,
+                  ex, epi, !g_conv_one_round ? 0 : conv_wg_capacity<k_conv_fwd_w<CI, CO>>());
+      return;
+    }
+  }
+  SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, K, n_out, y,
+              flags, in_shift, ex, epi,
+              (EXV || !g_conv_one_round) ? 0 : conv_wg_capacity<k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>>());
+}
 static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
 SGNN_EXPORT int sgnn_conv_set_small(int on) {
   const int prev = g_small_kernel;
@@ -651,9 +718,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
       SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV, PREV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table,  \
                          ld, K, n_out, y, flags, in_shift, ex, epi, 0);                                 \
     else                                                                                                \
-      SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>), dim3(grid4), dim3(256), 0, s, x, n_in,    \
-                         w, table, ld, K, n_out, y, flags, in_shift, ex, epi,                           \
-                         (EXV || !g_conv_one_round) ? 0 : conv_wg_capacity<k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>>()); \
+      conv_launch_big<CI, CO, EXV, PREV>(grid4, s, x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi); \
     done = true;                                                                                        \
   } while (0)
 // (the BatchNorm-folding instantiations exist for the shapes the planner folds: BN_FOLD_* lists below)

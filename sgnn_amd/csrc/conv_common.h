@@ -236,3 +236,152 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[M][NT], int64_t row0,
   conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, groups, grp, y, epi, stats, any_ptr, s1, s2);
   conv_epilogue_stats<COUT, NT>(s1, s2, epi, stats, sred, pblock);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide epilogue (round 5).  In the MFMA C layout a lane holds FOUR ROWS of one column, so the
+// element-wise epilogue above issues one 4-byte memory instruction per accumulator element and operand: 16 stores per wave
+// and 64-row tile in the forward pass, 16 + 16 loads (addend, BatchNorm input) on top in the data-gradient pass — 48
+// instructions against the 108 gathers of the 27-offset walk, at the tail of the tile with nothing to overlap them.  In the
+// step the dX launches of k_conv_fwd ran 25-45 % slower than forward launches of the same size for it
+// (profiles/r04p_step_launches.csv).  Here the four lanes of a quad (columns 4c .. 4c+3, same rows) transpose their 4 x 4
+// block with DPP quad permutes (16 VALU operations, no LDS): lane j of the quad then holds row q*4 + j, columns 4c .. 4c+3 —
+// one 16-byte row-contiguous access per operand and 16-row tile, 4x fewer memory instructions — and the operand loads are
+// issued BEFORE the last MFMA block of the tile (conv_epi_wide_prefetch), under the wait for the last gather.  The
+// arithmetic stays in the MFMA layout (operands are transposed INTO it, results out of it): rows and statistics partials
+// are bit-identical to the element-wise epilogue.
+// Needs COUT % 4 == 0, one column tile (COUT <= 16), row strides that are multiples of 4 floats (the dispatcher checks).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float sgnn_quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// in: lane j of a quad holds a[i] = B[i][j] (i = 0..3);  out: a[t] = B[j][t]
+__device__ __forceinline__ void sgnn_quad_transpose4(float (&a)[4], int lane) {
+  const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
+  float s, r;
+  s = odd ? a[0] : a[1]; r = sgnn_quad_perm<0xB1>(s); a[0] = odd ? r : a[0]; a[1] = odd ? a[1] : r;   // lanes j <-> j ^ 1
+  s = odd ? a[2] : a[3]; r = sgnn_quad_perm<0xB1>(s); a[2] = odd ? r : a[2]; a[3] = odd ? a[3] : r;
+  s = hi ? a[0] : a[2];  r = sgnn_quad_perm<0x4E>(s); a[0] = hi ? r : a[0];  a[2] = hi ? a[2] : r;    // lanes j <-> j ^ 2
+  s = hi ? a[1] : a[3];  r = sgnn_quad_perm<0x4E>(s); a[1] = hi ? r : a[1];  a[3] = hi ? a[3] : r;
+}
+
+template <int M>
+struct EpiRows {          // the tile's epilogue operands in the transposed layout: [16-row tile][4 columns]
+  float add[M][4], bnx[M][4];
+};
+#define SGNN_EPI_OOB 0xFFFFF800u   // slabs are limited to 0xFFFFF000 bytes: out of range, and +16 does not wrap
+
+// the per-column BatchNorm constants of the backward statistics (stats == 2) into LDS: cst[which][col], which = mean,
+// invstd, gamma, beta; call from all threads BEFORE a barrier that precedes the first epilogue
+template <int COUT>
+__device__ __forceinline__ void conv_epi_wide_constants(float *cst, const ConvEpi &epi, int stats) {
+  const int tid = threadIdx.x;
+  if (stats == 2 && tid < 64) {
+    const int which = tid >> 4, col = tid & 15;
+    const float *src = which == 0 ? epi.mean : (which == 1 ? epi.invstd : (which == 2 ? epi.gamma : epi.beta));
+    float v = which == 2 ? 1.f : 0.f;
+    if (src && col < COUT) v = src[col];
+    cst[tid] = v;
+  }
+}
+
+// which: bit 0 = the addend rows, bit 1 = the BatchNorm-input rows (SGNN_WEPI_EARLY of them are fetched under the last
+// offset, the rest at the head of conv_epi_wide_finish)
+#ifndef SGNN_WEPI_EARLY
+#define SGNN_WEPI_EARLY 3
+#endif
+template <int COUT, int M>
+__device__ __forceinline__ void conv_epi_wide_prefetch(EpiRows<M> &p, int64_t row0, int64_t n_out, const ConvEpi &epi,
+                                                       int stats, const float *any_ptr, int which = 3) {
+  const bool has_add = epi.addend != nullptr && (which & 1);
+  if (!(which & 2)) stats = 0;
+  if (!has_add && stats != 2) return;          // uniform over the launch
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const uint32_t c4 = (uint32_t)(r >> 2) * 4u;
+  const int jr = r & 3;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      make_rsrc(has_add ? epi.addend : any_ptr, has_add ? (uint32_t)(((n_out - 1) * epi.ld_add + COUT) * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rs_b =
+      make_rsrc(stats == 2 ? epi.bn_x : any_ptr, stats == 2 ? (uint32_t)(((n_out - 1) * epi.ld_bnx + COUT) * 4) : 0u);
+  const uint32_t lda4 = (uint32_t)epi.ld_add * 4u, ldb4 = (uint32_t)epi.ld_bnx * 4u;
+  // (the empty asm pins the address arithmetic below HERE: it is invariant in the offset loop, and hoisted in front of that
+  //  loop it cost the whole walk ~25 VGPRs — one wave per SIMD of occupancy)
+  uint32_t rbase = (uint32_t)row0 + (uint32_t)(q * 4 + jr);
+  asm volatile("" : "+v"(rbase));
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int64_t row = (int64_t)(rbase + (uint32_t)(m * 16));
+    const bool ok = c4 < (uint32_t)COUT && row < n_out;
+    if (has_add) buf_load_floats<4>(rs_a, ok ? (uint32_t)row * lda4 + c4 * 4u : SGNN_EPI_OOB, p.add[m]);
+    if (stats == 2) buf_load_floats<4>(rs_b, ok ? (uint32_t)row * ldb4 + c4 * 4u : SGNN_EPI_OOB, p.bnx[m]);
+  }
+}
+
+// The tile's epilogue.  Arithmetic and statistics happen in the ORIGINAL MFMA layout (lane = one column, four rows), exactly
+// as in conv_epilogue_rows — same fp32 operations per element, same fp64 summation order, so rows AND statistics partials are
+// bit-identical to the element-wise epilogue; only the memory side is transposed: the operand rows arrive as 16-byte chunks
+// and are quad-transposed into the MFMA layout, the result rows are quad-transposed back and leave as 16-byte chunks.
+template <int COUT, int M>
+__device__ __forceinline__ void conv_epi_wide_finish(f32x4 (&acc)[M][1], EpiRows<M> &p, int64_t row0, int64_t n_out,
+                                                     float *y, const ConvEpi &epi, int stats, const float *cst,
+                                                     double (&s1)[1], double (&s2)[1], const float *any_ptr) {
+  if constexpr (SGNN_WEPI_EARLY != 3) conv_epi_wide_prefetch<COUT, M>(p, row0, n_out, epi, stats, any_ptr, 3 & ~SGNN_WEPI_EARLY);
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const uint32_t c4 = (uint32_t)(r >> 2) * 4u;
+  const int jr = r & 3;
+  const bool has_add = epi.addend != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (uint32_t)(((n_out - 1) * epi.ldy + COUT) * 4));
+  const uint32_t ldy4 = (uint32_t)epi.ldy * 4u;
+  float cm = 0.f, ci = 0.f, cg = 1.f, cb = 0.f;
+  if (stats == 2) {
+    cm = cst[0 * 16 + r];
+    ci = cst[1 * 16 + r];
+    cg = cst[2 * 16 + r];
+    cb = cst[3 * 16 + r];
+  }
+  double f1 = 0.0, f2 = 0.0;
+  uint32_t rq = (uint32_t)row0 + (uint32_t)(q * 4);     // (pinned below the offset loop like the prefetch's addresses)
+  asm volatile("" : "+v"(rq));
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float v[4] = {acc[m][0][0], acc[m][0][1], acc[m][0][2], acc[m][0][3]};   // rows m*16 + q*4 + i, column r
+    if (has_add) {
+      float a[4] = {p.add[m][0], p.add[m][1], p.add[m][2], p.add[m][3]};
+      sgnn_quad_transpose4(a, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += a[i];
+    }
+    if (stats == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = r < COUT && (int64_t)(rq + (uint32_t)(m * 16 + i)) < n_out;
+        const double vm = ok ? (double)v[i] : 0.0;
+        f1 += vm;
+        f2 = fma(vm, vm, f2);
+      }
+    } else if (stats == 2) {
+      float xb[4] = {p.bnx[m][0], p.bnx[m][1], p.bnx[m][2], p.bnx[m][3]};
+      sgnn_quad_transpose4(xb, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = r < COUT && (int64_t)(rq + (uint32_t)(m * 16 + i)) < n_out;
+        const float xh = (xb[i] - cm) * ci;
+        const float t = fmaf(xh, cg, cb);
+        const float dz = ok ? (t > 0.f ? v[i] : v[i] * epi.leak) : 0.f;
+        f1 += (double)dz;
+        f2 = fma((double)dz, (double)xh, f2);
+      }
+    }
+    sgnn_quad_transpose4(v, lane);                                           // row m*16 + q*4 + jr, columns c4 .. c4+3
+    const int64_t row = (int64_t)(rq + (uint32_t)(m * 16 + jr));
+    const bool okt = c4 < (uint32_t)COUT && row < n_out;
+    u32x4 o;
+    o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, okt ? (uint32_t)row * ldy4 + c4 * 4u : SGNN_EPI_OOB, 0, 0);
+    // one 16-row tile at a time: interleaving the four tiles' transposes and fp64 chains (what the scheduler does with the
+    // unrolled loop) needs 4x the temporaries and costs the whole kernel a wave per SIMD of occupancy
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  s1[0] += f1;
+  s2[0] += f2;
+}

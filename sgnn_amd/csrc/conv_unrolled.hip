@@ -17,15 +17,19 @@
 // two barriers at compile-time positions of the unrolled sequence; ordinary loads in flight survive a barrier.
 #include "conv_common.h"
 
-template <int CIN, int COUT, int K, bool PRE>
-__global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
-                                                   const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
-                                                   int flags, int in_shift, ConvEpi epi, int wg_cap) {
+// WEPI: the wide (row-contiguous, 16-byte) epilogue of conv_common.h (output rows of 8 / 12 / 16 channels)
+// (the body of k_conv_fwd_u and k_conv_fwd_uw below)
+template <int CIN, int COUT, int K, bool PRE, bool WEPI>
+__device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
+                                                const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
+                                                int flags, int in_shift, const ConvEpi &epi, int wg_cap) {
   using C = ConvCfg<CIN, COUT>;
   constexpr int V = C::V, CINP = C::CINP, NT = C::NT, M = 4;
   constexpr int KC = C::KC < K ? C::KC : K;            // offsets per staged weight chunk
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
   __shared__ double sred[4 * 2 * NT * 16];             // statistics scratch (the weight tile stays live across row tiles)
+  static_assert(!WEPI || (NT == 1 && COUT % 4 == 0 && !PRE), "wide epilogue: one column tile of whole 16-byte chunks");
+  __shared__ float ecst[WEPI ? 64 : 1];                // WEPI: per-column BatchNorm constants of the backward statistics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
   int32_t idx[K];
   f32x4 acc[M][NT];
+  if constexpr (WEPI) conv_epi_wide_constants<COUT>(ecst, epi, epi.stats);   // (visible after the barriers of the first stage())
 
   // BatchNormReLU of the producing layer folded into the gather (ConvEpi.pre, see BnPre): the lane's V channels' constants
   // (a template parameter: the plain instantiations do not pay the 4 V + 2 M registers)
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   gather(0);
+  EpiRows<WEPI ? M : 1> erows;                 // WEPI: addend / BatchNorm-input rows of this tile, loaded under the last offset
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (k % KC == 0) {                        // compile-time positions (the loop is fully unrolled)
@@ -136,14 +142,37 @@ __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x,
     }
     if (k + 1 < K) gather(k + 1);
     if (k + 1 < K && (k + 1) % KC != 0) load_b(k + 1);
+    if constexpr (WEPI) {
+      if (k == K - 1) conv_epi_wide_prefetch<COUT, M>(erows, row0, n_out, epi, epi.stats, x);
+    }
     __builtin_amdgcn_sched_barrier(0);
     mma(k);
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, x, s1, s2);
+  if constexpr (WEPI)
+    conv_epi_wide_finish<COUT, M>(acc, erows, row0, n_out, y, epi, epi.stats, ecst, s1, s2, x);
+  else
+    conv_epilogue_rows<COUT, M, NT>(acc, row0, n_out, 1u, 0u, y, epi, epi.stats, x, s1, s2);
   }
   conv_epilogue_stats<COUT, NT>(s1, s2, epi, epi.stats, sred, blockIdx.x);
+}
+
+template <int CIN, int COUT, int K, bool PRE>
+__global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
+                                                   const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
+                                                   int flags, int in_shift, ConvEpi epi, int wg_cap) {
+  conv_fwd_u_body<CIN, COUT, K, PRE, false>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
+}
+
+// the stride-2 (8-offset) walks with the wide epilogue: with 32 gathers per 64-row tile the element-wise epilogue's 16-48
+// memory instructions weigh more than anywhere else.  Occupancy pinned like k_conv_fwd_w (conv.hip explains).  The 27-offset
+// wide-row shapes keep the element-wise form: their walk already needs 190-240 registers.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_fwd_uw(
+    const float *__restrict__ x, int64_t n_in, const float *__restrict__ w, const int32_t *__restrict__ table, int64_t ld,
+    int64_t n_out, float *y, int flags, int in_shift, ConvEpi epi, int wg_cap) {
+  conv_fwd_u_body<CIN, COUT, 8, false, true>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
 }
 
 // Shapes: where the straight-line form wins on the 366 k-row level (profiles/r04c_conv_ab.txt, same box, bit-identical
@@ -166,6 +195,22 @@ bool sgnn_conv_u_supported(int cin, int cout, int K) {
 }
 
 // launch over n_out rows (256-row workgroups; capacity mode through epi.n_dev); false: shape not compiled
+bool conv_wide_epi_ok(const ConvEpi &epi, const float *y, int K);   // conv.hip
+
+template <int CI, int CO, int KK>
+static void conv_u_launch_plain(unsigned grid, hipStream_t s, const float *x, int64_t n_in, const float *w, const int32_t *table,
+                                int64_t ld, int64_t n_out, float *y, int flags, int in_shift, const ConvEpi &epi) {
+  if constexpr (KK == 8 && CO % 4 == 0 && CO <= 16) {
+    if (conv_wide_epi_ok(epi, y, KK)) {
+      SGNN_LAUNCH((k_conv_fwd_uw<CI, CO>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi,
+                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_uw<CI, CO>>() : 0);
+      return;
+    }
+  }
+  SGNN_LAUNCH((k_conv_fwd_u<CI, CO, KK, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift,
+              epi, g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, KK, false>>() : 0);
+}
+
 bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                         int64_t n_out, int cout, float *y, int flags, int in_shift, const ConvEpi &epi, hipStream_t s) {
   const unsigned grid = (unsigned)((n_out + 255) / 256);
@@ -175,8 +220,7 @@ bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, i
       SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
                   g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 27, true>>() : 0); \
     else                                                                                                                 \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
-                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 27, false>>() : 0); \
+      conv_u_launch_plain<CI, CO, 27>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);                   \
     return true;                                                                                                         \
   }
   CONV_U_CASES_27(X)
@@ -187,8 +231,7 @@ bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, i
       SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
                   g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 8, true>>() : 0); \
     else                                                                                                                 \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
-                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 8, false>>() : 0); \
+      conv_u_launch_plain<CI, CO, 8>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);                    \
     return true;                                                                                                         \
   }
   CONV_U_CASES_8(X)

@@ -688,6 +688,7 @@ class GraphStep(object):
         self.stats = {'probe_steps': 0, 'eager_steps': 0, 'captures': 0, 'replays': 0, 'overflows': 0, 'replans': 0,
                       'replay_host_ms': 0.0}
         self._pins, self._npin = None, 0
+        self.overflow_log = []          # diagnostics: which levels were full in the steps that overflowed (see _check)
         self._bound = False
         try:
             hwq = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
@@ -771,6 +772,7 @@ class GraphStep(object):
                            [(max(k, ko), [max(a, b) for a, b in zip(p, po)]) for (k, p), (ko, po) in zip(new.gen, old.gen)]
                            if len(old.gen) == len(new.gen) else new.gen)
         self.capacity = new
+        self._live, self._hist = None, []        # counts read back so far belong to the plan this one replaces
         self.stats['probe_steps'] += 1
         self.loss, self.losses = loss.detach(), losses
         return self.loss
@@ -916,10 +918,19 @@ class GraphStep(object):
             ev, pin, batch, lw, cap, index, _alive = self.pending.pop(0)
             ev.synchronize()
             word = int(pin[0]) & 0xFFFFFFFF
-            if cap is not None and cap is self.capacity:
+            if cap is not None and cap is self.capacity and not (word & 4):
+                # (never from a step that overflowed: its producers CLAMPED their counts to the capacities, and a re-plan
+                #  sized from clamped counts shrinks exactly the levels that were too small — tests/test_gpu_dp_protocol.py
+                #  scenario C found a plan re-sized to 2 x 1024 rows for a 10 k-row level this way)
                 self._live = pin[1:].tolist()
             if word & 4 and not (word & 3):
                 redo.append((batch, lw))
+                # which of THIS rank's levels hit their capacity (a producer clamps its count to the capacity when it
+                # overflows; none = the overflow came from a peer's merged bit): [(step index, [(level, rows, capacity)])]
+                full = [] if cap is None else [(i, int(n), int(c)) for i, (n, c) in
+                                                enumerate(self._levels(pin[1:].tolist(), cap)) if n >= c]
+                self.overflow_log.append((index, full))
+                del self.overflow_log[:-32]
             elif word:
                 from .scn.metadata import runtime
                 runtime(batch['sdf'].device).raise_status(
@@ -1041,10 +1052,10 @@ class GraphStep(object):
             self._maybe_replan()
         return self.loss
 
-    def _levels(self, live):
-        """[(live rows, capacity)] of every count the plan tracks."""
+    def _levels(self, live, cap=None):
+        """[(live rows, capacity)] of every count the plan (default: the current one) tracks."""
         from .scn.capacity import ENC0
-        cap = self.capacity
+        cap = self.capacity if cap is None else cap
         pairs = [(live[0], cap.input_rows)] + [(live[ENC0 + l], c) for l, c in enumerate(cap.enc)]
         for g, (k, pyr) in enumerate(cap.gen):
             b = cap.gen_base(g)

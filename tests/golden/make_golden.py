@@ -97,8 +97,31 @@ def run_case(name, dims, batch, cfg, occupancy, train, weight_missing_geo, scene
     m64 = m64.double()
     if scene_mode:
         m64.update_sizes(np.array(dims), np.array(dims) // 8)
-    with torch.no_grad():
+    if scene_mode:
+        with torch.no_grad():
+            sdf64, occs64 = m64([locs, feats.double()], loss_weights)
+    else:
+        # round 5: the fp64 run also goes through the reference's loss and backward pass, so that the
+        # parameter gradients have an EXACT value to be held to.  grad64::<name> = the fp64 gradient rounded to fp32
+        # (6e-8 relative: three orders below any bar), grad_eref[i] = max |fp32 gradient - fp64 gradient| / max |fp64
+        # gradient| of tensor i — how far the reference's OWN fp32 run is from the exact value (ReLU / mask flips).
         sdf64, occs64 = m64([locs, feats.double()], loss_weights)
+        t_sdf, t_occs, t_hier = ref_loss.compute_targets(data['sdf'].clone(), [h.clone() for h in data['hierarchy']], 4, 3,
+                                                         True, data['known'])
+        loss64, losses64 = ref_loss.compute_loss(sdf64, occs64, t_sdf.double(), [t.double() for t in t_occs],
+                                                 [t.double() for t in t_hier], loss_weights, 3, True, weight_missing_geo,
+                                                 locs, True, data['known'])
+        loss64.backward()
+        out['loss64'] = np.float64(loss64.item())
+        eref = []
+        p32 = dict(m.named_parameters())
+        for n, p in m64.named_parameters():
+            g64 = p.grad if p.grad is not None else torch.zeros_like(p)
+            g32 = p32[n].grad if p32[n].grad is not None else torch.zeros_like(p32[n])
+            out['grad64::' + n] = to_np(g64).astype(np.float32)
+            scale = float(g64.abs().max())
+            eref.append(float((g32.double() - g64).abs().max()) / scale if scale > 0 else 0.0)
+        out['grad_eref'] = np.array(eref)
     for h, (l, v) in enumerate(occs64):
         assert np.array_equal(to_np(l).astype(np.int64), out['occ%d_locs' % h]), 'fp32/fp64 masks differ at level %d' % h
         out['occ%d_vals64' % h] = to_np(v).astype(np.float64)

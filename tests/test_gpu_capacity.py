@@ -301,3 +301,34 @@ def test_empty_level_in_capacity_mode_behaves_like_the_reference_early_return():
     assert any(not torch.equal(sd[k], state0[k]) for k in sd if k.startswith('refinement.0.p1'))
     steps = gs.opt.steps.cpu().tolist()
     assert steps[0] == 4 and steps[1] == 4 and steps[2] == 0 and steps[3] == 0 and steps[4] == 0
+
+
+def test_counts_of_an_overflowed_step_never_size_a_plan():
+    """Regression (round 5, found by tests/test_gpu_dp_protocol.py scenario C): the hierarchy dies in the probe step, so the
+    first plan has minimum capacities below the dead level; the next capacity steps overflow by a factor of 10 there.  The
+    counts that ride back with an overflowed step are CLAMPED to the capacities — they must not become the "live" counts a
+    later re-plan is sized from (the plan was re-sized to 2 x 1024 rows for a 10 k-row level and overflowed again)."""
+    from sgnn_amd.train import GraphStep
+    from sgnn_amd.scn import functions as F_
+    from test_gpu_dp_protocol import _kill_level
+    lw = np.ones(5, dtype=np.float32)
+    batches = [_batch(30 + i) for i in range(6)]
+    real = F_.compact_sigmoid_plan
+    active = [True]
+    calls = _kill_level(active)
+    try:
+        gs = GraphStep(_model(), lr=1e-3, headroom=2.0, settle=False, teacher_forced=True)
+        for i, b in enumerate(batches):
+            calls[0] = 0
+            gs(b, lw)
+            active[0] = False
+        torch.cuda.synchronize()
+        gs._drain()
+    finally:
+        F_.compact_sigmoid_plan = real
+    assert gs.stats['overflows'] == 2 and gs.stats['replans'] == 0, (gs.stats, gs.overflow_log)
+    assert [i for i, _ in gs.overflow_log] == [0, 1], gs.overflow_log      # the two capacity steps on the minimum plan
+    assert all(full for _, full in gs.overflow_log)                        # ... each names the levels that were full
+    live = gs.capacity.read()
+    assert live['gen'][3][0] > 2048 and gs.capacity.gen[3][0] >= live['gen'][3][0]
+    assert gs.stats['captures'] == 2 and gs.stats['replays'] >= 2

@@ -91,41 +91,34 @@ def test_graph_step_matches_reference_golden(name):
             assert sites.shape[0] == 0
         assert abs(loss - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss']))), (phase, loss, float(g['loss']))
         grads = gs.opt.named_gradients(m)        # what Adam consumes, reference layout
-        gw, loose = 0.0, 0
-        for n, a in zip(g['grad_names'], g['grad_abssum']):
-            gr = grads[str(n)]
-            got = 0.0 if gr is None else gr.double().abs().sum().item()
-            e = abs(got - a) / max(1.0, a)
-            gw = max(gw, e)
-            loose += e > GRAD_TOL
-            assert e <= GRAD_HARD, (name, phase, str(n), got, a)
-        for k in g.files:
-            if k.startswith('grad::'):
-                gr = grads[k[6:]].cpu().numpy()
-                e = np.abs(gr - g[k]).max() / max(1.0, np.abs(g[k]).max())
-                gw = max(gw, e)
-                loose += e > GRAD_TOL
-                assert e <= GRAD_HARD, (name, phase, k, e)
-        assert loose <= GRAD_LOOSE_FRAC * len(g['grad_names']), (name, phase, loose)
+        # Round 5: every tensor against the reference's EXACT (fp64) gradient, with the reference's own fp32 distance from
+        # it (grad_eref) as the yardstick — the bars of the 64^3 oracle case below: 2 e_ref + 1e-3 of the tensor's scale
+        # for >= 97 % of the tensors, 3 e_ref + 5e-3 for every tensor.  (Rounds 3-4: flat 1e-2 / 2e-2 against the fp32 run.)
+        gw, loose, total = (0.0, ''), 0, 0
+        for n, eo in zip(g['grad_names'], g['grad_eref']):
+            n = str(n)
+            g64 = g['grad64::' + n].astype(np.float64)
+            gr = grads[n]
+            got = np.zeros_like(g64) if gr is None else gr.cpu().double().numpy()
+            scale = float(np.abs(g64).max())
+            if scale == 0.0:                     # a stage the hierarchy never reached: no gradient at all
+                assert float(np.abs(got).max()) == 0.0, (name, phase, n)
+                continue
+            eh = float(np.abs(got - g64).max()) / scale
+            gw = max(gw, (eh, n))
+            total += 1
+            loose += eh > 2 * float(eo) + 1e-3
+            assert eh <= 3 * float(eo) + 5e-3, '%s %s %s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (name, phase, n, eh, eo)
+        assert loose <= 0.03 * total, (name, phase, loose, total)
+        gw, gw_name = gw
         if it == 0:      # BatchNorm running statistics after ONE step are the fixture's (later steps keep averaging)
             for k, want in bufs.items():
                 assert np.abs(dict(m.named_buffers())[k].cpu().numpy() - want).max() < 1e-5, k
-        report('%-22s %-26s sites exact, max |logit err| vs fp64 fixture %.2e, loss %.6f (fixture %.6f), worst gradient '
-               'deviation %.2e of scale' % (name, phase, worst, loss, float(g['loss']), gw))
+        report('%-22s %-26s sites exact, max |logit err| vs fp64 fixture %.2e, loss %.6f (fixture %.6f, fp64 %.6f), worst '
+               'gradient deviation from the fp64 gradient %.2e of scale (%s; reference fp32: up to %.2e)'
+               % (name, phase, worst, loss, float(g['loss']), float(g['loss64']), gw, gw_name, float(np.max(g['grad_eref']))))
     assert gs.stats['probe_steps'] == 1 and gs.stats['eager_steps'] == 1 and gs.stats['captures'] == 1, gs.stats
     assert gs.stats['replays'] == 3 and gs.stats['overflows'] == 0, gs.stats
-
-
-# golden-fixture gradients to 1e-2.  The fixtures are the reference's fp32 run, and a ReLU network's
-# parameter gradients are discontinuous in the activations: two correct fp32 evaluations decide a handful of borderline
-# ReLU / loss masks differently, which moves the few tensors that sum over those sites by up to 1.5 % (measured:
-# genmodel_train_rect, 5 of 187 tensors between 1.0 and 1.6 %, profiles/r04_parity_report.txt; the 32^3 and the
-# empty-prediction fixtures agree to 4e-4 and 1e-6).  Bar: 1e-2 of the tensor's scale for at least 95 % of the tensors,
-# 2e-2 for every tensor (the classic-path test in test_gpu_model.py used 5e-2 for all).  A kernel that is off by 1 % moves
-# EVERY tensor it produces and fails the first bar.
-GRAD_TOL = 1e-2
-GRAD_HARD = 2e-2
-GRAD_LOOSE_FRAC = 0.05
 
 
 def test_graph_step_vs_oracle_64_bs4_forced_masks():

@@ -77,6 +77,38 @@ def test_oracle_model_matches_reference_golden(name):
                 assert np.abs(dict(m.named_buffers())[k[5:]].numpy() - g[k]).max() < 1e-6, k
 
 
+@pytest.mark.parametrize('name', ['genmodel_train_32', 'genmodel_train_rect', 'genmodel_train_empty'])
+def test_oracle_fp64_gradients_match_reference_fp64(name):
+    """Round 5: the fixtures carry the reference's fp64 loss and parameter gradients (grad64::, stored rounded to fp32) and,
+    per tensor, how far the reference's own fp32 run is from them (grad_eref).  The oracle's fp64 evaluation of the same
+    step must reproduce the exact values — only the storage rounding (6e-8) separates them."""
+    g = load(name)
+    dims = tuple(int(d) for d in g['dims'])
+    m = mo.GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1)
+    param_fill(m, seed=int(g['cfg']))
+    m = m.train().double()
+    data = synth.make_batch(int(g['batch']), dims, cfg=int(g['cfg']), occupancy=float(g['occupancy']))
+    locs, feats = data['input']
+    lw = np.ones(5, dtype=np.float32)
+    t_sdf, t_occ, t_hier = mo.compute_targets(data['sdf'].clone(), [h.clone() for h in data['hierarchy']], 4, 3, True,
+                                              data['known'])
+    osdf, oocc = m([locs, feats.double()], lw)
+    loss, _ = mo.compute_loss(osdf, oocc, t_sdf.double(), [t.double() for t in t_occ], [t.double() for t in t_hier], lw, 3,
+                              True, float(g['weight_missing_geo']), locs, True, data['known'])
+    loss.backward()
+    assert abs(loss.item() - float(g['loss64'])) <= 1e-10 * max(1.0, abs(float(g['loss64'])))
+    names = [str(n) for n in g['grad_names']]
+    assert len(g['grad_eref']) == len(names)
+    for n, p in m.named_parameters():
+        want = g['grad64::' + n].astype(np.float64)
+        got = np.zeros_like(want) if p.grad is None else p.grad.numpy()
+        scale = max(float(np.abs(want).max()), 1e-300)
+        assert np.abs(got - want).max() <= 2e-7 * scale + 1e-30, n
+    # the reference's own fp32 run is up to a few per cent from its exact value on some tensors (ReLU / mask flips): that
+    # spread, not a flat tolerance, is what the GPU paths are held to (tests/test_gpu_graphstep_parity.py)
+    assert float(np.max(g['grad_eref'])) < 0.1
+
+
 def test_state_dict_keys_follow_reference_layout():
     # SURVEY.md App. B: nn.Sequential numeric child naming via .add(); 643 735 parameters
     m = mo.GenModel(8, (64, 64, 64), 1, 16, 16, 4, True, True, 1, 1)

@@ -97,3 +97,96 @@ def test_config4_bs8_training_step():
         del m, opt, batch
         P_.release_arenas()
         torch.cuda.empty_cache()
+
+
+def _trimmed(outputs):
+    """(sdf, occ) of GraphStep.outputs with every capacity-sized tensor cut to its live prefix (host read-backs)."""
+    from sgnn_amd.scn.capacity import trim
+    osdf, oocc = outputs
+    occ = []
+    for sites, vals in oocc:
+        s = trim(sites)
+        occ.append([s, vals.detach()[:int(s.shape[0])]])
+    s = trim(osdf[0])
+    return [s, osdf[1].detach()[:int(s.shape[0])]], occ
+
+
+def test_config4_bs8_graph_step_capacity_mode():
+    """the BENCHMARKED execution mode (train.GraphStep: capacity mode with device-side row counts, the
+    `n_dev` kernel variants, the capacity planner, HIP-graph capture and replay) at configs[4] size — 8 x 128^3 at 20 %,
+    2.6 M input sites — not only the classic path.  lr = 0 keeps the random weights (and with them the predicted masks)
+    fixed, so the probe step (classic path), the eager capacity-mode step, the capturing call and the replays must all
+    produce the classic step's hierarchy: bit-identical live-prefix site lists on every level, the same logits up to the
+    summation order of grid-dependent reductions, the size-independent invariants of _check_hierarchy, finite gradients.
+    Then a forced overflow at this size (one level's capacity cut under its live count): detected one step late, the plan
+    grows, the batch is re-run, the next steps are clean.  Catches 32-bit offsets / 4 GiB slabs in the n_dev variants."""
+    from sgnn_amd.model import GenModel
+    from sgnn_amd.scn import program as P_
+    from sgnn_amd.scn.capacity import Capacity
+    from sgnn_amd.train import GraphStep, to_device
+    B, D = 8, 128
+    prev = P_.PERSISTENT_ARENAS
+    P_.PERSISTENT_ARENAS = True
+    m = gs = batch = None
+    try:
+        batch = to_device(synth.make_batch(B, (D,) * 3, cfg=5, occupancy=0.2, dist='iid'), 'cuda')
+        n_in = int(batch['input'][0].shape[0])
+        assert 2400000 < n_in < 2900000
+        torch.manual_seed(1234)
+        m = GenModel(8, (D,) * 3, 1, 16, 16, 4, True, True, 1, 1).cuda().train()
+        lw = np.ones(5, dtype=np.float32)
+        gs = GraphStep(m, lr=0.0, headroom=1.15, settle=False, keep_outputs=True)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        ref = None
+        phases = ['probe (classic path)', 'eager capacity-mode step', 'capture + first replay', 'replay']
+        for phase in phases:
+            loss = float(gs(batch, lw))
+            torch.cuda.synchronize()
+            sdf, occ = _trimmed(gs.outputs)
+            levels = _check_hierarchy(occ, sdf, (D, D, D), B)
+            assert np.isfinite(loss)
+            g = gs.opt.flat_g[:gs.opt.numel]
+            assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+            cur = ([o[0].cpu() for o in occ] + [sdf[0].cpu()], [o[1].cpu() for o in occ] + [sdf[1].cpu()], loss)
+            if ref is None:
+                ref = cur
+            else:
+                for h, (a, b) in enumerate(zip(ref[0], cur[0])):
+                    assert torch.equal(a, b), '%s: level %d site list differs from the classic path' % (phase, h)
+                for h, (a, b) in enumerate(zip(ref[1], cur[1])):
+                    scale = max(1.0, float(a.abs().max()))
+                    assert float((a - b).abs().max()) <= 1e-4 * scale, (phase, h, float((a - b).abs().max()), scale)
+                assert abs(cur[2] - ref[2]) <= 1e-5 * abs(ref[2]), (phase, cur[2], ref[2])
+        peak = torch.cuda.max_memory_allocated() / GB
+        assert gs.stats['probe_steps'] == 1 and gs.stats['eager_steps'] == 1 and gs.stats['captures'] == 1, gs.stats
+        assert gs.stats['replays'] == 2 and gs.stats['overflows'] == 0, gs.stats
+        print('configs[4] GraphStep 8 x 128^3 @20 %%: %d input sites, sites per level %s, loss %.4f, peak allocated %.2f GB, '
+              'capacities %r' % (n_in, levels, ref[2], peak, gs.capacity.describe()))
+        assert peak <= 32.0, 'peak allocated %.2f GB' % peak
+        # forced overflow at full size: the last level's capacity cut to 60 % of its live rows
+        live = gs.capacity.read()
+        k3 = live['gen'][3][0]
+        assert k3 > 100000
+        gs._drain()
+        cap = gs.capacity
+        gs.capacity = Capacity(cap.device, cap.input_rows, cap.enc,
+                               [(k if g != 3 else int(0.6 * k3), p) for g, (k, p) in enumerate(cap.gen)])
+        gs.stage, gs.graphs, gs._live, gs._hist = 1, None, None, []
+        for _ in range(4):              # overflowing eager step, overflowing capture + replay, detection + re-run, clean steps
+            loss = float(gs(batch, lw))
+        torch.cuda.synchronize()
+        gs._drain()
+        assert gs.stats['overflows'] >= 1 and gs.capacity.gen[3][0] >= k3, (gs.stats, gs.capacity.describe())
+        assert any(lv == 13 for _, full in gs.overflow_log for lv, _, _ in full), gs.overflow_log   # level 13 = gen[3] kept rows
+        loss = float(gs(batch, lw))
+        torch.cuda.synchronize()
+        sdf, occ = _trimmed(gs.outputs)
+        for h, a in enumerate(ref[0][:4]):
+            assert torch.equal(a, occ[h][0].cpu()), 'after the overflow: level %d site list differs' % h
+        assert torch.equal(ref[0][4], sdf[0].cpu()) and abs(loss - ref[2]) <= 1e-5 * abs(ref[2])
+    finally:
+        P_.PERSISTENT_ARENAS = prev
+        del m, gs, batch
+        P_.release_arenas()
+        torch.cuda.empty_cache()

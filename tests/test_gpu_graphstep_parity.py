@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import param_fill
+from util import check_grads_vs_fp64_fixture, param_fill
 from sgnn_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -91,26 +91,9 @@ def test_graph_step_matches_reference_golden(name):
             assert sites.shape[0] == 0
         assert abs(loss - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss']))), (phase, loss, float(g['loss']))
         grads = gs.opt.named_gradients(m)        # what Adam consumes, reference layout
-        # Round 5: every tensor against the reference's EXACT (fp64) gradient, with the reference's own fp32 distance from
-        # it (grad_eref) as the yardstick — the bars of the 64^3 oracle case below: 2 e_ref + 1e-3 of the tensor's scale
-        # for >= 97 % of the tensors, 3 e_ref + 5e-3 for every tensor.  (Rounds 3-4: flat 1e-2 / 2e-2 against the fp32 run.)
-        gw, loose, total = (0.0, ''), 0, 0
-        for n, eo in zip(g['grad_names'], g['grad_eref']):
-            n = str(n)
-            g64 = g['grad64::' + n].astype(np.float64)
-            gr = grads[n]
-            got = np.zeros_like(g64) if gr is None else gr.cpu().double().numpy()
-            scale = float(np.abs(g64).max())
-            if scale == 0.0:                     # a stage the hierarchy never reached: no gradient at all
-                assert float(np.abs(got).max()) == 0.0, (name, phase, n)
-                continue
-            eh = float(np.abs(got - g64).max()) / scale
-            gw = max(gw, (eh, n))
-            total += 1
-            loose += eh > 2 * float(eo) + 1e-3
-            assert eh <= 3 * float(eo) + 5e-3, '%s %s %s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (name, phase, n, eh, eo)
-        assert loose <= 0.03 * total, (name, phase, loose, total)
-        gw, gw_name = gw
+        # Round 5: every tensor against the reference's EXACT (fp64) gradient, the reference's own fp32 distance from it as
+        # the yardstick (util.check_grads_vs_fp64_fixture; rounds 3-4: flat 1e-2 / 2e-2 against the fp32 run)
+        gw, gw_name = check_grads_vs_fp64_fixture(g, grads, '%s, %s' % (name, phase))
         if it == 0:      # BatchNorm running statistics after ONE step are the fixture's (later steps keep averaging)
             for k, want in bufs.items():
                 assert np.abs(dict(m.named_buffers())[k].cpu().numpy() - want).max() < 1e-5, k

@@ -69,3 +69,28 @@ def param_fill(model, seed=0):
         new[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
     model.load_state_dict(new, strict=True)
     return model
+
+
+def check_grads_vs_fp64_fixture(g, grads, what):
+    """Parameter gradients of a HIP path (name -> tensor in the reference's layout, or None) against the reference's EXACT
+    gradients in a golden fixture (tests/golden/make_golden.py: grad64:: = the reference run in fp64, grad_eref = how far
+    the reference's own fp32 run is from it, per tensor, as a fraction of the tensor's scale).  Bars (the ones of the 64^3
+    oracle case): 2 e_ref + 1e-3 for at least 97 % of the tensors, 3 e_ref + 5e-3 for every tensor; a stage the hierarchy
+    never reached must have no gradient at all.  Returns (worst deviation, its tensor)."""
+    worst, loose, total = (0.0, ''), 0, 0
+    for n, eo in zip(g['grad_names'], g['grad_eref']):
+        n = str(n)
+        g64 = g['grad64::' + n].astype(np.float64)
+        gr = grads[n]
+        got = np.zeros_like(g64) if gr is None else gr.detach().cpu().double().numpy()
+        scale = float(np.abs(g64).max())
+        if scale == 0.0:
+            assert float(np.abs(got).max()) == 0.0, (what, n)
+            continue
+        eh = float(np.abs(got - g64).max()) / scale
+        worst = max(worst, (eh, n))
+        total += 1
+        loose += eh > 2 * float(eo) + 1e-3
+        assert eh <= 3 * float(eo) + 5e-3, '%s %s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (what, n, eh, eo)
+    assert loose <= 0.03 * total, (what, loose, total)
+    return worst

@@ -182,9 +182,16 @@ def test_config4_bs8_graph_step_capacity_mode():
         loss = float(gs(batch, lw))
         torch.cuda.synchronize()
         sdf, occ = _trimmed(gs.outputs)
-        for h, a in enumerate(ref[0][:4]):
-            assert torch.equal(a, occ[h][0].cpu()), 'after the overflow: level %d site list differs' % h
-        assert torch.equal(ref[0][4], sdf[0].cpu()) and abs(loss - ref[2]) <= 1e-5 * abs(ref[2])
+        # The grown plan moves some levels across a kernel-selection threshold (the 32 768-row 16^3 level: 37.7 k rows of
+        # capacity = the 16-row small-level kernel, 56 k = the 256-row kernel, which sums the offsets in another order), so
+        # logits differ in their last bits and a handful of the 10^6 occupancy decisions that sit on the threshold may
+        # flip: the invariants must hold again, sizes and loss must agree closely — not bit for bit.
+        levels2 = _check_hierarchy(occ, sdf, (D, D, D), B)
+        for a, b in zip(levels, levels2):
+            assert abs(a - b) <= 1e-3 * a + 8, (levels, levels2)
+        assert abs(loss - ref[2]) <= 1e-4 * abs(ref[2]), (loss, ref[2])
+        print('configs[4] GraphStep after a forced overflow: sites per level %s (before: %s), loss %.6f (before %.6f), '
+              'overflow log %r' % (levels2, levels, loss, ref[2], gs.overflow_log))
     finally:
         P_.PERSISTENT_ARENAS = prev
         del m, gs, batch

@@ -113,7 +113,7 @@ def run_case(name, dims, batch, cfg, occupancy, train, weight_missing_geo, scene
                                                  locs, True, data['known'])
         loss64.backward()
         out['loss64'] = np.float64(loss64.item())
-        eref = []
+        eref, d2, n2 = [], 0.0, 0.0
         p32 = dict(m.named_parameters())
         for n, p in m64.named_parameters():
             g64 = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -121,7 +121,12 @@ def run_case(name, dims, batch, cfg, occupancy, train, weight_missing_geo, scene
             out['grad64::' + n] = to_np(g64).astype(np.float32)
             scale = float(g64.abs().max())
             eref.append(float((g32.double() - g64).abs().max()) / scale if scale > 0 else 0.0)
+            d2 += float(((g32.double() - g64) ** 2).sum())
+            n2 += float((g64 ** 2).sum())
         out['grad_eref'] = np.array(eref)
+        # the same distance over the WHOLE gradient vector in the 2-norm: |g32 - g64| / |g64| — insensitive to the single
+        # ReLU / mask flips that dominate the per-tensor maxima on levels with a few dozen rows
+        out['grad_eref_l2'] = np.float64((d2 / n2) ** 0.5)
     for h, (l, v) in enumerate(occs64):
         assert np.array_equal(to_np(l).astype(np.int64), out['occ%d_locs' % h]), 'fp32/fp64 masks differ at level %d' % h
         out['occ%d_vals64' % h] = to_np(v).astype(np.float64)

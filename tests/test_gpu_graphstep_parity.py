@@ -93,13 +93,14 @@ def test_graph_step_matches_reference_golden(name):
         grads = gs.opt.named_gradients(m)        # what Adam consumes, reference layout
         # Round 5: every tensor against the reference's EXACT (fp64) gradient, the reference's own fp32 distance from it as
         # the yardstick (util.check_grads_vs_fp64_fixture; rounds 3-4: flat 1e-2 / 2e-2 against the fp32 run)
-        gw, gw_name = check_grads_vs_fp64_fixture(g, grads, '%s, %s' % (name, phase))
+        gw, gw_name, gl2 = check_grads_vs_fp64_fixture(g, grads, '%s, %s' % (name, phase), report if it == 0 else None)
         if it == 0:      # BatchNorm running statistics after ONE step are the fixture's (later steps keep averaging)
             for k, want in bufs.items():
                 assert np.abs(dict(m.named_buffers())[k].cpu().numpy() - want).max() < 1e-5, k
         report('%-22s %-26s sites exact, max |logit err| vs fp64 fixture %.2e, loss %.6f (fixture %.6f, fp64 %.6f), worst '
-               'gradient deviation from the fp64 gradient %.2e of scale (%s; reference fp32: up to %.2e)'
-               % (name, phase, worst, loss, float(g['loss']), float(g['loss64']), gw, gw_name, float(np.max(g['grad_eref']))))
+               'gradient tensor %.2e of scale from the fp64 gradient (%s; reference fp32: up to %.2e), whole vector %.2e in the '
+               '2-norm (reference fp32 %.2e)' % (name, phase, worst, loss, float(g['loss']), float(g['loss64']), gw, gw_name,
+                                                 float(np.max(g['grad_eref'])), gl2, float(g['grad_eref_l2'])))
     assert gs.stats['probe_steps'] == 1 and gs.stats['eager_steps'] == 1 and gs.stats['captures'] == 1, gs.stats
     assert gs.stats['replays'] == 3 and gs.stats['overflows'] == 0, gs.stats
 

@@ -71,13 +71,24 @@ def param_fill(model, seed=0):
     return model
 
 
-def check_grads_vs_fp64_fixture(g, grads, what):
+def check_grads_vs_fp64_fixture(g, grads, what, report=None):
     """Parameter gradients of a HIP path (name -> tensor in the reference's layout, or None) against the reference's EXACT
-    gradients in a golden fixture (tests/golden/make_golden.py: grad64:: = the reference run in fp64, grad_eref = how far
-    the reference's own fp32 run is from it, per tensor, as a fraction of the tensor's scale).  Bars (the ones of the 64^3
-    oracle case): 2 e_ref + 1e-3 for at least 97 % of the tensors, 3 e_ref + 5e-3 for every tensor; a stage the hierarchy
-    never reached must have no gradient at all.  Returns (worst deviation, its tensor)."""
-    worst, loose, total = (0.0, ''), 0, 0
+    gradients in a golden fixture (tests/golden/make_golden.py: grad64:: = the reference code run in fp64; grad_eref[i] =
+    how far the reference's OWN fp32 run is from it on tensor i, max-norm over the tensor's scale; grad_eref_l2 = the same
+    over the whole gradient vector in the 2-norm).
+
+    Two correct fp32 evaluations of a ReLU network do not agree to round-off: each decides a few of the ~10^6 ReLU / loss
+    masks whose argument is below fp32 resolution the other way, and ONE flipped mask on a level of a few dozen rows moves
+    every gradient upstream of it by per cent (genmodel_train_rect: the reference's own fp32 run is 1.5 % from its exact
+    value in the 2-norm and up to 4.8 % on a tensor; genmodel_train_32 / _empty: 1e-5).  So the yardstick is the
+    reference's own distance, per tensor and per fixture:
+      every tensor    <= max(3 e_ref + 5e-3, 1.25 x the reference's worst tensor of this fixture)
+      97 % of them    <= 2 e_ref + 1e-3        (fixtures where the reference's fp32 run has no flip: worst e_ref < 2e-3)
+      90 % of them    <= 3 e_ref + 5e-3        (fixtures where it has)
+      whole vector    2-norm distance <= 2 x the reference's + 1e-3
+    A stage the hierarchy never reached must have no gradient at all.  Returns (worst deviation, its tensor, 2-norm
+    distance).  report: callable that gets one line per tensor over 2 e_ref + 1e-3 (the distribution behind the verdict)."""
+    rows, d2, n2 = [], 0.0, 0.0
     for n, eo in zip(g['grad_names'], g['grad_eref']):
         n = str(n)
         g64 = g['grad64::' + n].astype(np.float64)
@@ -87,10 +98,28 @@ def check_grads_vs_fp64_fixture(g, grads, what):
         if scale == 0.0:
             assert float(np.abs(got).max()) == 0.0, (what, n)
             continue
-        eh = float(np.abs(got - g64).max()) / scale
-        worst = max(worst, (eh, n))
-        total += 1
-        loose += eh > 2 * float(eo) + 1e-3
-        assert eh <= 3 * float(eo) + 5e-3, '%s %s: HIP %.3e of scale vs fp64, reference fp32 %.3e' % (what, n, eh, eo)
-    assert loose <= 0.03 * total, (what, loose, total)
-    return worst
+        d2 += float(((got - g64) ** 2).sum())
+        n2 += float((g64 ** 2).sum())
+        rows.append((float(np.abs(got - g64).max()) / scale, float(eo), n, int(g64.size)))
+    rows.sort(reverse=True)
+    total = len(rows)
+    e_worst = float(np.max(g['grad_eref']))
+    l2, l2_ref = (d2 / n2) ** 0.5, float(g['grad_eref_l2'])
+    tight = [r for r in rows if r[0] > 2 * r[1] + 1e-3]
+    wide = [r for r in rows if r[0] > 3 * r[1] + 5e-3]
+    hard = [r for r in rows if r[0] > max(3 * r[1] + 5e-3, 1.25 * e_worst)]
+    if report is not None:
+        report('    %s: gradient vector 2-norm distance from fp64 %.3e (reference fp32: %.3e); %d of %d tensors over 2 e_ref + '
+               '1e-3, %d over 3 e_ref + 5e-3; reference fp32 worst tensor %.3e' % (what, l2, l2_ref, len(tight), total,
+                                                                                    len(wide), e_worst))
+        for eh, eo, n, size in tight[:24]:
+            report('      %-52s %7d entries  HIP %.3e of scale from fp64, reference fp32 %.3e%s'
+                   % (n, size, eh, eo, '   > 3 e_ref + 5e-3' if eh > 3 * eo + 5e-3 else ''))
+    assert not hard, '%s: %d tensors beyond max(3 e_ref + 5e-3, 1.25 x %.2e), worst %s: HIP %.3e of scale vs fp64, reference ' \
+                     'fp32 %.3e' % (what, len(hard), e_worst, hard[0][2], hard[0][0], hard[0][1])
+    if e_worst < 2e-3:
+        assert len(tight) <= 0.03 * total, (what, len(tight), total)
+    else:
+        assert len(wide) <= 0.10 * total, (what, len(wide), total)
+    assert l2 <= 2 * l2_ref + 1e-3, (what, l2, l2_ref)
+    return rows[0][0], rows[0][2], l2

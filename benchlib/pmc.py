@@ -96,7 +96,7 @@ N_SIMD = 1024      # 256 CUs x 4 SIMDs
 N_XCD = 8
 
 
-def instep_counters(args, kernels=('k_conv_fwd<16, 16, 4', 'k_conv_small<16, 16', 'k_conv_dw<16, 16, false, 0', 'k_bn_apply',
+def instep_counters(args, kernels=('k_conv_fwd_w<16, 16', 'k_conv_fwd<16, 16, 4', 'k_conv_small<16, 16', 'k_conv_dw<16, 16, false, 0', 'k_bn_apply',
                                    'k_bn_bwd_apply'), settle=60, replays=8):
     """Three passes over scripts/pmc_step.py.  Per kernel (name prefix): launches seen, mean per dispatch of each counter,
     and the derived figures

@@ -47,9 +47,15 @@ def collect_prof(lib, valid_ratio=None, row_map=None):
         a['flops_exec'] += fl_exec
         # the same kernel serves levels of very different size: keep the launches apart by output rows (powers of 4)
         bucket = 0 if live <= 0 else int(np.floor(np.log(max(live, 1)) / np.log(4.0)))
-        b = a['by_size'].setdefault(bucket, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'rows': 0, 'rules': 0.0})
+        b = a['by_size'].setdefault(bucket, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'rows': 0, 'rules': 0.0,
+                                             'n_fwd': 0, 'ms_fwd': 0.0, 'n_dx': 0, 'ms_dx': 0.0})
         b['launches'] += 1
         b['ms'] += ms.value
+        # forward launches and data-gradient launches (SGNN_CONV_TRANSPOSE_W) of the same kernel, kept apart: the fused
+        # backward epilogue once made the latter 25-45 % slower — this keeps the ratio visible
+        d = 'dx' if (kind.value == 0 and (flags.value & 1)) else 'fwd'
+        b['n_' + d] += 1
+        b['ms_' + d] += ms.value
         b['flops'] += fl
         b['rows'] += live
         b['rules'] += ratio * K.value * live
@@ -169,7 +175,9 @@ def roofline_record(agg, n_prof_steps, timing_note):
                  'rules_per_row': round(b['rules'] / max(b['rows'], 1), 2),
                  'avg_us': round(1e3 * b['ms'] / b['launches'], 1), 'share_of_kernel_time': round(b['ms'] / dom['ms'], 3),
                  'TFLOPs': round(b['flops'] / (b['ms'] * 1e-3) / 1e12, 2),
-                 'frac_of_fp32_mfma_peak': round(b['flops'] / (b['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+                 'frac_of_fp32_mfma_peak': round(b['flops'] / (b['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4),
+                 'dx_vs_fwd_us': [round(1e3 * b['ms_dx'] / b['n_dx'], 1) if b['n_dx'] else None,
+                                  round(1e3 * b['ms_fwd'] / b['n_fwd'], 1) if b['n_fwd'] else None]}
                 for _, b in sorted(dom['by_size'].items(), reverse=True) if b['ms'] > 0],
             # the five classes with the largest total time, each against the roof that binds it
             'top_kernels': [class_record(k, a) for k, a in ranked[:5] if a['ms'] > 0]}

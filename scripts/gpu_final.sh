@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 closing run: smoke, the default bench (CPU leg, isolated + in-step PMC passes), kernel trace + stats of the bench
-# command.   Usage: scripts/gpu_r4_final.sh TAG      (the full `pytest -m gpu` suite is run separately)
+# Closing run of a round (round 4 on): smoke, the default bench (CPU leg, isolated + in-step PMC passes), kernel trace + stats of the bench
+# command.   Usage: scripts/gpu_final.sh TAG      (the full `pytest -m gpu` suite is run separately)
 TAG=$1
 mkdir -p gpurun_out
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc $?"; tail -2 gpurun_out/${TAG}_smoke.log

@@ -34,10 +34,22 @@ names = {0: '64 B rows, conv (MFMA-operand) mapping, b128', 1: '64 B rows, row-c
          16: 'conv loop: 4 offsets in flight + 16 MFMA/offset',
          17: 'conv loop: 1 in flight + 16 MFMA + weights staged in LDS', 18: 'conv loop: 1 in flight + 16 MFMA + 64 B/row store',
          19: 'conv loop: 1 in flight + 16 MFMA + LDS weights + store',
-         8: '64 B rows, conv mapping, offsets walked dx-major (no shared lines in flight)'}
+         8: '64 B rows, conv mapping, offsets walked dx-major (no shared lines in flight)',
+         20: 'per (dz,dy): three full gathers (baseline of modes 21/22)', 21: 'per (dz,dy): 1 full + 2 fallback gathers + DPP shifts',
+         22: 'mode 21, fallback skipped when no lane needs it'}
 ref = {}
 xs = {16: torch.randn(g.n, 16, device=dev), 8: torch.randn(g.n, 8, device=dev)}
-for mode in (10, 13, 17, 18, 19):
+ap_modes = [int(v) for v in os.environ.get('GATHER_MODES', '10,13,17,18,19').split(',')]
+t = tab.view(27, g.ld)[:, :g.n]
+hit = 0
+for k in range(0, 27, 3):
+    j = torch.arange(g.n - 1, device=dev)
+    okp = (t[k + 2][:-1] >= 0) & (t[k + 2][:-1] == t[k + 1][1:]) & ((j % 16) != 15)
+    okm = (t[k][1:] >= 0) & (t[k][1:] == t[k + 1][:-1]) & (((j + 1) % 16) != 0)
+    hit += int(okp.sum()) + int(okm.sum())
+side = int((t[0::3] >= 0).sum()) + int((t[2::3] >= 0).sum())
+print('dx = -1 / +1 rules served by a lane shift of the dx = 0 gather: %.1f %% of %d' % (100.0 * hit / side, side))
+for mode in ap_modes:
     c = 8 if mode in (4, 5) else 16
     x = xs[c]
     stream = torch.cuda.current_stream().cuda_stream
@@ -54,7 +66,8 @@ for mode in (10, 13, 17, 18, 19):
     us = e0.elapsed_time(e1) / args.iters * 1e3
     s = float(out.double().sum())
     key = c
-    if key in ref and mode < 10:
+    key = (c, mode >= 20)
+    if key in ref and (mode < 10 or mode >= 20):
         assert abs(s - ref[key]) <= 1e-4 * max(1.0, abs(ref[key])), (mode, s, ref[key])   # every mapping loads the same rows
     ref.setdefault(key, s)
     print('mode %d  %-62s %7.1f us   %6.2f TB/s gathered (rules only: %6.2f)   %5.1f cycles/gather-instr/CU @2.4GHz'

@@ -215,6 +215,71 @@ __global__ __launch_bounds__(256) void k_loop(const float *__restrict__ x, int64
   }
 }
 
+
+// Modes 20-22 (round 5; VERDICT r4 item 5, DESIGN.md section 8 "open 2"): fewer gathers per rule.  On a raster-ordered level the
+// dx = -1, 0, +1 neighbours of consecutive output rows are consecutive input rows: nbr[(dz,dy,+1)][j] == nbr[(dz,dy,0)][j+1]
+// wherever both exist.  In the MFMA-operand mapping lane (r, q) holds chunk q of the row of output row r of a 16-row tile, so the
+// dx = +1 rows of a tile are the dx = 0 rows one lane further (DPP row_shl:1), the dx = -1 rows one lane back (row_shr:1) — except
+// at the tile's edge lane and wherever the table disagrees (run boundaries, generated levels in child order), where a per-lane
+// FALLBACK gather fetches the row (all other lanes out of range: the instruction still issues, but touches few rows).
+//   mode 20: three full gathers per (dz, dy) pair (the baseline in this loop structure)
+//   mode 21: one full gather + two fallback gathers + DPP shifts
+//   mode 22: mode 21, fallback instruction skipped (wave-uniform branch) when no lane of the wave needs it
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gather3(const float *__restrict__ x, int64_t n_in, const int32_t *__restrict__ table,
+                                                int64_t ld, int64_t n_out, float *__restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, (uint32_t)(n_in * 64));
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(table, (uint32_t)(27 * ld * 4));
+  const uint32_t lane_off = (uint32_t)(row0 + lane) * 4u, ld4 = (uint32_t)ld * 4u;
+  const int r = lane & 15, q = lane >> 4;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  auto add = [&](const u32x4 &v) {
+    acc0 += __uint_as_float(v.x); acc1 += __uint_as_float(v.y); acc2 += __uint_as_float(v.z); acc3 += __uint_as_float(v.w);
+  };
+  for (int t = 0; t < 9; ++t) {
+    const int32_t ivm = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, (3 * t) * ld4, 0);
+    const int32_t iv0 = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, (3 * t + 1) * ld4, 0);
+    const int32_t ivp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, (3 * t + 2) * ld4, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int32_t idm = __builtin_amdgcn_ds_bpermute((m * 16 + r) * 4, ivm);
+      const int32_t id0 = __builtin_amdgcn_ds_bpermute((m * 16 + r) * 4, iv0);
+      const int32_t idp = __builtin_amdgcn_ds_bpermute((m * 16 + r) * 4, ivp);
+      const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (uint32_t)id0 * 64u + q * 16, 0, 0);
+      add(v0);
+      if constexpr (MODE == 20) {
+        add(__builtin_amdgcn_raw_buffer_load_b128(rs_x, (uint32_t)idm * 64u + q * 16, 0, 0));
+        add(__builtin_amdgcn_raw_buffer_load_b128(rs_x, (uint32_t)idp * 64u + q * 16, 0, 0));
+      } else {
+        const int32_t id0n = (int32_t)dpp_row<0x101>((uint32_t)id0), id0p = (int32_t)dpp_row<0x111>((uint32_t)id0);
+        const bool hitp = r != 15 && idp >= 0 && idp == id0n, hitm = r != 0 && idm >= 0 && idm == id0p;   // (edge lanes of the 16-row tile: no neighbour lane)
+        const uint32_t offp = hitp ? 0xFFFFF800u : (uint32_t)idp * 64u + q * 16, offm = hitm ? 0xFFFFF800u : (uint32_t)idm * 64u + q * 16;
+        u32x4 fp = {0, 0, 0, 0}, fm = {0, 0, 0, 0};
+        if constexpr (MODE == 21) {
+          fp = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offp, 0, 0);
+          fm = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offm, 0, 0);
+        } else {
+          if (__ballot(!hitp && idp >= 0)) fp = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offp, 0, 0);
+          if (__ballot(!hitm && idm >= 0)) fm = __builtin_amdgcn_raw_buffer_load_b128(rs_x, offm, 0, 0);
+        }
+        u32x4 sp, sm;
+        sp.x = dpp_row<0x101>(v0.x); sp.y = dpp_row<0x101>(v0.y); sp.z = dpp_row<0x101>(v0.z); sp.w = dpp_row<0x101>(v0.w);
+        sm.x = dpp_row<0x111>(v0.x); sm.y = dpp_row<0x111>(v0.y); sm.z = dpp_row<0x111>(v0.z); sm.w = dpp_row<0x111>(v0.w);
+        add(hitp ? sp : fp);
+        add(hitm ? sm : fm);
+      }
+    }
+  }
+  (void)n_out;
+  out[row0 + lane] = (acc0 + acc1) + (acc2 + acc3);
+}
+
 extern "C" __attribute__((visibility("default"))) int gather_bench(const float *x, int64_t n_in, int c,
                                                                     const int32_t *table, int64_t ld, int K,
                                                                     int64_t n_out, float *out, int mode, void *stream) {
@@ -238,6 +303,9 @@ extern "C" __attribute__((visibility("default"))) int gather_bench(const float *
     case 19: hipLaunchKernelGGL((k_loop<1, 16, 3>), grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
     case 16: hipLaunchKernelGGL((k_loop<4, 16>), grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
     case 8: hipLaunchKernelGGL(k_gather<8>, grid, block, 0, s, x, n_in, c, table, ld, K, n_out, out); break;
+    case 20: hipLaunchKernelGGL(k_gather3<20>, grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
+    case 21: hipLaunchKernelGGL(k_gather3<21>, grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
+    case 22: hipLaunchKernelGGL(k_gather3<22>, grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
     case 6: hipLaunchKernelGGL(k_gather_dma<4>, grid, block, 0, s, x, n_in, table, ld, n_out, out); break;
     case 7: hipLaunchKernelGGL(k_gather_dma<8>, dim3((unsigned)((n_out + 511) / 512)), dim3(512), 0, s, x, n_in, table, ld, n_out, out); break;
     default: return -1;

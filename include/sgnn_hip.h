@@ -229,7 +229,9 @@ int sgnn_conv_set_dw_c1(int on);
 /* large levels: every workgroup of the rulebook walk takes as many consecutive 256-row tiles as it needs for ALL live
  * workgroups to be resident at once (no partial second round of workgroups; default on).  0 = one tile per workgroup.
  * Outputs are bit-identical either way; BatchNorm statistics partials are summed per workgroup, so their grouping
- * (fp64) differs.  Returns the previous setting. */
+ * (fp64) differs.  The tile count per workgroup follows the number of workgroups of the kernel the DEVICE holds at once
+ * (occupancy x compute units, queried per device on first use): statistics are bit-reproducible for a given device model,
+ * driver and compiler, not across them.  Returns the previous setting. */
 int sgnn_conv_set_one_round(int on);
 /* epilogue of the 256-row rulebook walk for output rows of 8 / 12 / 16 channels (every FullyConvolutionalNet layer,
  * torch/model.py:38-42, 180, 255, forward and data gradient): 1 (default) = the tile leaves the MFMA layout through a

@@ -185,3 +185,54 @@ def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
     assert ((s1 - s0).abs() <= 1e-12 * s0.abs().clamp_min(1.0)).all()
     want = torch.stack([y0.double().sum(0), (y0.double() ** 2).sum(0)])
     assert ((s1 - want).abs() <= 1e-9 * want.abs().clamp_min(1.0)).all()
+
+
+@pytest.mark.parametrize('c', [16, 8, 12])
+def test_wide_epilogue_is_bit_identical_and_falls_back_on_odd_strides(c):
+    """Round 5: the wide (quad-transposed, 16-byte) epilogue of the 256-row kernels (sgnn_conv_set_wide_epi) against the
+    element-wise one — forward with residual + statistics and data gradient with in-place accumulation + BatchNorm-backward
+    statistics: rows AND fp64 statistics partials bit-identical (the arithmetic stays in the MFMA layout); with a row stride
+    that is not a multiple of four floats the dispatcher must fall back to the element-wise form by itself."""
+    from sgnn_amd import _lib
+    from sgnn_amd.scn import functions as F_
+    lib = _lib.load()
+    g, tab = _grid(5, 64, 13)
+    n = g.n
+    assert -(-n // 256) >= 160                       # the 256-row kernels
+    gen = torch.Generator(device='cuda').manual_seed(100 + c)
+    x = torch.randn(n, c, device='cuda', generator=gen)
+    w = torch.randn(27, c, c, device='cuda', generator=gen) * 0.2
+    add = torch.randn(n, c, device='cuda', generator=gen)
+    bn_x = torch.randn(n, c, device='cuda', generator=gen)
+    mean, inv = torch.randn(c, device='cuda', generator=gen) * 0.1, torch.rand(c, device='cuda', generator=gen) + 0.5
+    gamma, beta = torch.rand(c, device='cuda', generator=gen) + 0.5, torch.randn(c, device='cuda', generator=gen) * 0.3
+    nblk = _lib.query('sgnn_conv_stats_blocks', n)
+    flags = F_.CONV_TRANSPOSE_W | F_.CONV_FLIP_K
+
+    def run(ldy, col0, stats, fl):
+        y = torch.full((n, ldy), 3.0, device='cuda')
+        y[:, col0:col0 + c] = add
+        part = torch.zeros(nblk, 2, c, dtype=torch.float64, device='cuda')
+        yp = y.data_ptr() + 4 * col0
+        _lib.call('sgnn_conv_fwd_epi', x.data_ptr(), n, c, 0, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, c, yp, ldy, fl,
+                  yp, ldy, stats, part.data_ptr(), bn_x.data_ptr() if stats == 2 else None, 0,
+                  mean.data_ptr() if stats == 2 else None, inv.data_ptr() if stats == 2 else None,
+                  gamma.data_ptr() if stats == 2 else None, beta.data_ptr() if stats == 2 else None, 0.0)
+        return y, part
+
+    prev = lib.sgnn_conv_set_wide_epi(1)
+    try:
+        for ldy, col0 in ((c, 0), (c + 8, 4), (c + 1, 0), (c + 3, 2)):       # aligned, aligned view, odd strides (fallback)
+            for stats, fl in ((1, 0), (2, flags)):
+                lib.sgnn_conv_set_wide_epi(0)
+                y0, p0 = run(ldy, col0, stats, fl)
+                lib.sgnn_conv_set_wide_epi(1)
+                y1, p1 = run(ldy, col0, stats, fl)
+                assert torch.equal(y0, y1), (ldy, col0, stats)
+                assert torch.equal(p0, p1), (ldy, col0, stats)
+                assert (y1[:, :col0] == 3).all() and (y1[:, col0 + c:] == 3).all()
+                if stats == 1:      # and it is the convolution + residual it claims to be
+                    want = F_.conv_fwd_raw(x, c, w, 27, tab, g.ld, n, c) + add
+                    assert torch.equal(y1[:, col0:col0 + c], want)
+    finally:
+        lib.sgnn_conv_set_wide_epi(prev)

@@ -754,7 +754,7 @@ class GraphStep(object):
                 self.grad_sync(self.opt.flat_g)
                 self.opt.merge_overflow(rt.status32)
                 self.opt.step(flags_in_grads=True, grad_scale=1.0 / self.world_size, status=rt.status32)
-                self._issue_status(rt, batch, loss_weights, probe=True)
+                self._issue_status(batch, loss_weights, probe=True)
             else:
                 self.opt.step(reached=reached)
             log = MD.COUNT_LOG
@@ -893,9 +893,14 @@ class GraphStep(object):
         self._opt_step(loss_weights, rt)
         return loss, losses, rt
 
-    def _issue_status(self, rt, batch, loss_weights, probe=False):
+    def _issue_status(self, batch, loss_weights, probe=False):
         """Queue this step's status word (+ the live row counts) for a read one step late.  probe: a classic step under
-        data parallelism — it has no row counts of its own, only the merged overflow bit of its all-reduce slot."""
+        data parallelism — it has no row counts of its own, only the merged overflow bit of its all-reduce slot.
+        (Everything device-specific of a slot lives in this method and in the step kinds it follows — _probe,
+        _capacity_step_eager, _capture / _replay: tests/test_dp_protocol_sim.py replaces exactly those and drives the
+        protocol logic of __call__ / _check / _overflow / _maybe_replan with two simulated ranks on the CPU.)"""
+        from .scn.metadata import runtime
+        rt = runtime(batch['sdf'].device)
         if self._pins is None:      # [status word | the capacity's 64 live row counts], per in-flight step
             self._pins = [torch.zeros(65, dtype=torch.int64).pin_memory() for _ in range(8)]
         pin = self._pins[self._npin % len(self._pins)]
@@ -1028,8 +1033,6 @@ class GraphStep(object):
             if self.stage == 1:
                 self._make_static(batch)
             self._load(batch)
-            from .scn.metadata import runtime
-            rt = runtime(batch['sdf'].device)
             if not self._bound:                          # programs were compiled by the probe step
                 self.opt.bind_programs(self.model)
                 self._bound = True
@@ -1043,7 +1046,7 @@ class GraphStep(object):
                 if self.graphs is None:
                     self._capture(loss_weights)
                 loss, losses = self._replay()
-            self._issue_status(rt, batch, loss_weights)
+            self._issue_status(batch, loss_weights)
             self.loss, self.losses = loss, losses
         redo = self._check(1)
         if redo:

@@ -556,6 +556,62 @@ __global__ __launch_bounds__(256) void k_concat3_bwd(const float *__restrict__ d
   }
 }
 
+// Row-group form of the two kernels above (round 5): T threads own one destination row, four columns each — no 64-bit
+// division per element, the three row indices loaded once per thread instead of once per element, 16 bytes per thread in
+// and out.  (The element-per-thread form took 67 us for the 517 k x 26 input rows of the surface stage, 1.4 TB/s over
+// bytes read + written, at the head of the stage's dependent chain.)  Same values: pure data movement.
+template <int T>
+__global__ __launch_bounds__(256) void k_concat3_rg(Cat3 s, int64_t m, float *__restrict__ dst, const int64_t *n_dev) {
+  m = sgnn_dyn_n(m, n_dev);
+  const int c01 = s.c[0] + s.c[1], c = c01 + s.c[2];
+  const int t = threadIdx.x % T, col0 = 4 * t;
+  const int64_t stride = (int64_t)gridDim.x * (256 / T);
+  for (int64_t r = (int64_t)blockIdx.x * (256 / T) + threadIdx.x / T; r < m; r += stride) {
+    if (col0 >= c) continue;
+    int64_t i[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) i[w] = (s.c[w] > 0 && s.idx[w]) ? (int64_t)s.idx[w][r] : r;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + j;
+      const int which = col < s.c[0] ? 0 : (col < c01 ? 1 : 2);
+      const int lc = col - (which == 0 ? 0 : (which == 1 ? s.c[0] : c01));
+      const int64_t ii = which == 0 ? i[0] : (which == 1 ? i[1] : i[2]);
+      v[j] = (col < c && ii >= 0) ? s.src[which][ii * s.c[which] + lc] : 0.f;
+    }
+    float *d = dst + r * c + col0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col0 + j < c) d[j] = v[j];
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_concat3_bwd_rg(const float *__restrict__ ddst, int64_t m, Cat3Out o,
+                                                       const int64_t *n_dev) {
+  m = sgnn_dyn_n(m, n_dev);
+  const int c01 = o.c[0] + o.c[1], c = c01 + o.c[2];
+  const int t = threadIdx.x % T, col0 = 4 * t;
+  const int64_t stride = (int64_t)gridDim.x * (256 / T);
+  for (int64_t r = (int64_t)blockIdx.x * (256 / T) + threadIdx.x / T; r < m; r += stride) {
+    if (col0 >= c) continue;
+    int64_t i[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) i[w] = (o.c[w] > 0 && o.idx[w]) ? (int64_t)o.idx[w][r] : r;
+    const float *g = ddst + r * c + col0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + j;
+      if (col >= c) break;
+      const int which = col < o.c[0] ? 0 : (col < c01 ? 1 : 2);
+      const int lc = col - (which == 0 ? 0 : (which == 1 ? o.c[0] : c01));
+      const int64_t ii = which == 0 ? i[0] : (which == 1 ? i[1] : i[2]);
+      if (o.dst[which] && ii >= 0) o.dst[which][ii * o.c[which] + lc] = g[j];
+    }
+  }
+}
+
 SGNN_EXPORT int sgnn_concat3_rows(const float *a, int ca, const int32_t *ia, const float *b, int cb, const int32_t *ib,
                                   const float *c, int cc, const int32_t *ic, int64_t m, float *dst,
                                   sgnn_stream_t stream) {
@@ -569,8 +625,13 @@ int sgnn_concat3_rows_dn(const float *a, int ca, const int32_t *ia, const float 
   if (m == 0) return SGNN_OK;
   SGNN_CHECK_ARG(dst && (ca == 0 || a) && (cb == 0 || b) && (cc == 0 || c));
   const Cat3 s{{a, b, c}, {ia, ib, ic}, {ca, cb, cc}};
-  SGNN_LAUNCH(k_concat3, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     s, m, dst, n_dev);
+  const int ctot = ca + cb + cc;
+  if (ctot <= 32)
+    SGNN_LAUNCH(k_concat3_rg<8>, dim3(sgnn_grid_for(m * 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, s, m, dst, n_dev);
+  else if (ctot <= 64)
+    SGNN_LAUNCH(k_concat3_rg<16>, dim3(sgnn_grid_for(m * 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, s, m, dst, n_dev);
+  else
+    SGNN_LAUNCH(k_concat3, dim3(sgnn_grid_for(m * ctot, 256, 4096)), dim3(256), 0, (hipStream_t)stream, s, m, dst, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }
@@ -597,7 +658,13 @@ int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int c
   SGNN_CHECK_ARG(ddst);
   SGNN_CHECK_ARG((ia || !da || na >= m) && (ib || !db || nb >= m) && (ic || !dc || nc >= m));
   const Cat3Out o{{da, db, dc}, {ia, ib, ic}, {ca, cb, cc}};
-  SGNN_LAUNCH(k_concat3_bwd, dim3(sgnn_grid_for(m * (ca + cb + cc), 256, 4096)), dim3(256), 0, s, ddst, m, o, n_dev);
+  const int ctot = ca + cb + cc;
+  if (ctot <= 32)
+    SGNN_LAUNCH(k_concat3_bwd_rg<8>, dim3(sgnn_grid_for(m * 8, 256, 8192)), dim3(256), 0, s, ddst, m, o, n_dev);
+  else if (ctot <= 64)
+    SGNN_LAUNCH(k_concat3_bwd_rg<16>, dim3(sgnn_grid_for(m * 16, 256, 8192)), dim3(256), 0, s, ddst, m, o, n_dev);
+  else
+    SGNN_LAUNCH(k_concat3_bwd, dim3(sgnn_grid_for(m * ctot, 256, 4096)), dim3(256), 0, s, ddst, m, o, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -25,8 +25,12 @@ SGNN_EXPORT int sgnn_version(void) { return 100; }
 SGNN_EXPORT const char *sgnn_arch(void) { return "gfx950"; }
 
 SGNN_EXPORT int64_t sgnn_hash_capacity(int64_t n) {
+  // load factor <= 0.5; <= 0.25 below 64 k sites: there a launch is latency-bound and what a probing kernel costs is the
+  // LENGTH of the longest probe sequence in a wave — every step of it one more dependent memory round trip (1.5-2 us) — not
+  // the table's cache footprint.  k_rulebook_subm3 on 2.5 k / 9 k / 33 k rows: 19.0 / 18.6 / 21.8 -> 13.5 / 11.1 / 12.5 us
+  // (round 5; rocprofv3, isolated launches).  What remains is the chain coords -> keys -> values -> walk -> stores itself.
   int64_t cap = 1024;
-  while (cap < 2 * n) cap <<= 1;
+  while (cap < (n < 65536 ? 4 : 2) * n) cap <<= 1;
   return cap;
 }
 

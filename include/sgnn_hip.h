@@ -95,6 +95,10 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
  * table only for neighbours not found there); default 0 = the global-probe kernel, which measured faster on MI355X
  * (96.7 vs 123.9 us at N = 366 k).  Both produce identical tables.  Returns the previous setting. */
 int sgnn_rulebook_set_lds(int on);
+/* Tables of at most `rows` rows (ld) are built by the 26-probe kernel: every entry written by the site's own thread, no
+ * pre-fill launch of the mirrored rows (default 32768: the launch-bound coarse levels; 0 = the 13-probe mirrored kernel
+ * everywhere).  Identical tables.  Returns the previous setting. */
+int64_t sgnn_rulebook_set_full_rows(int64_t rows);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         const int64_t *n_dev, sgnn_stream_t stream);
@@ -342,6 +346,10 @@ int sgnn_add(const float *a, const float *b, int64_t count, float *y, sgnn_strea
 /* children coords: out[(8i+j)] = {2z+dz, 2y+dy, 2x+dx, b}, j = 4dz+2dy+dx
  * (Refinement.to_next_level_locs, torch/model.py:192-207) */
 int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *out, const int64_t *n_dev, sgnn_stream_t stream);
+/* the same, also writing the children as the int64 (z, y, x, b) rows the model returns per level (torch/model.py:207,243;
+ * = sgnn_coords_to_i64 of `out`) in the same pass */
+int sgnn_expand8_coords_i64(const int32_t *coords, int64_t n, int32_t *out, int64_t *locs, const int64_t *n_dev,
+                            sgnn_stream_t stream);
 /* all voxel coordinates of a dense (B, d0, d1, d2) volume, batch-major raster order
  * (GenModel.dense_coarse_to_sparse, torch/model.py:319-321) */
 int sgnn_dense_coords(int batch, int d0, int d1, int d2, int32_t *out, sgnn_stream_t stream);
@@ -365,6 +373,20 @@ int sgnn_compact_sigmoid_cap(const float *logits, int64_t stride, int64_t n, con
 int sgnn_compact_dense_cap(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol, int batch, int d0,
                            int d1, int d2, int32_t *sel, int64_t *count2, int64_t keep_cap, int32_t *status, void *ws,
                            int64_t ws_bytes, sgnn_stream_t stream);
+/* the same two, also writing locs[r] = coords[sel[r]] (16-byte {z,y,x,b} rows) for the kept rows r < keep_cap: the next
+ * level's site list (torch/model.py:236-243) without a gather launch of its own */
+int sgnn_compact_sigmoid_cap_locs(const float *logits, int64_t stride, int64_t n, const int64_t *n_dev,
+                                  const int32_t *coords, int32_t *sel, int32_t *locs, int64_t *count2, int64_t keep_cap,
+                                  int32_t *status, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+int sgnn_compact_dense_cap_locs(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol, int batch, int d0,
+                                int d1, int d2, int32_t *sel, int32_t *locs, int64_t *count2, int64_t keep_cap,
+                                int32_t *status, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
+/* A/B switches of the compaction / stride-2 pipelines (defaults 1; identical results; return the previous setting):
+ * sgnn_scan_set_inline — the write kernels sum the (<= 4096) raw block counts themselves instead of a scan launch between
+ * the count and the write kernel; sgnn_chain_set_merged — sgnn_down2_chain_tables runs the tables pass of level l and the
+ * hash insertion of level l + 1 in one launch */
+int sgnn_scan_set_inline(int on);
+int sgnn_chain_set_merged(int on);
 
 /* scn.SparseToDense (torch/model.py:47): dense (B, C, d0, d1, d2) zero-filled here */
 int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, int c, float *dense,

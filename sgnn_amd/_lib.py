@@ -25,6 +25,9 @@ PROTOTYPES = {
     'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_rulebook_set_lds': (c_i32, [c_i32]),
+    'sgnn_rulebook_set_full_rows': (c_i64, [c_i64]),
+    'sgnn_scan_set_inline': (c_i32, [c_i32]),
+    'sgnn_chain_set_merged': (c_i32, [c_i32]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
@@ -66,6 +69,7 @@ PROTOTYPES = {
     'sgnn_concat_rows_bwd': (c_i32, [c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'sgnn_add': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_expand8_coords': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'sgnn_expand8_coords_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_dense_coords': (c_i32, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'sgnn_compact_ws_bytes': (c_i64, [c_i64]),
     'sgnn_compact_sigmoid': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -73,6 +77,8 @@ PROTOTYPES = {
     'sgnn_compact_mask': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_compact_sigmoid_cap': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_compact_dense_cap': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_compact_sigmoid_cap_locs': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'sgnn_compact_dense_cap_locs': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_adam_flat': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
     'sgnn_seg_flags': (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     'sgnn_status_merge': (c_i32, [c_vp, c_vp, c_vp]),

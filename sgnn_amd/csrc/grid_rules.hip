@@ -234,6 +234,58 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
 }
 
 // ---------------------------------------------------------------------------
+// Small levels (round 5): all 26 neighbours probed by the site's own thread — twice the probes of the mirrored kernel above,
+// but they are independent loads of ONE round trip either way on a level that cannot fill the chip, every table entry has
+// exactly one writer (the site's thread, coalesced) and the pre-fill launch of rows 14..26 disappears (10 of the 13
+// hash-built rulebooks of a configs[1] step are on such levels).  Same table as k_rulebook_subm3, entry for entry.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rulebook_subm3_full(const uint64_t *__restrict__ keys,
+                                                            const int32_t *__restrict__ vals, uint64_t mask,
+                                                            const int4 *__restrict__ coords, int64_t n,
+                                                            int32_t *__restrict__ nbr, int64_t ld,
+                                                            const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= pad_end(n, ld)) return;
+  if (j >= n) {  // padding entries: the conv kernels rely on them being -1
+#pragma unroll
+    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
+    return;
+  }
+  const int4 c = coords[j];
+  uint64_t key[27], slot[27], got[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+    const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
+    const bool ok = k != 13 && ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
+    key[k] = ok ? sgnn_pack_key(z, y, x, c.w) : SGNN_EMPTY_KEY;     // the empty key never matches a stored one
+    slot[k] = sgnn_hash64(key[k]) & mask;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) got[k] = key[k] == SGNN_EMPTY_KEY ? SGNN_EMPTY_KEY : keys[slot[k]];
+  int32_t r[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) r[k] = (got[k] == key[k] && key[k] != SGNN_EMPTY_KEY) ? vals[slot[k]] : -1;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    if (got[k] != key[k] && got[k] != SGNN_EMPTY_KEY) {              // first slot held another key: keep probing
+      uint64_t sl = (slot[k] + 1) & mask;
+      while (true) {
+        const uint64_t kk = keys[sl];
+        if (kk == key[k]) {
+          r[k] = vals[sl];
+          break;
+        }
+        if (kk == SGNN_EMPTY_KEY) break;
+        sl = (sl + 1) & mask;
+      }
+    }
+    nbr[(int64_t)k * ld + j] = (k == 13) ? (int32_t)j : r[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The same rulebook with the voxel index of a row WINDOW held in LDS (north_star: "hash-table voxel indexing in LDS").
 // A workgroup owns 256 consecutive rows; in every site order this pipeline produces — batch-major raster order of the
 // input blocks (scene_dataloader.py:13-36), 8-children-per-parent order of the generated levels (model.py:195-207) —
@@ -446,6 +498,13 @@ SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *v
   return SGNN_OK;
 }
 
+static int64_t g_rulebook_full_rows = 32768;   // tables of at most this many rows (ld) use the 26-probe kernel; 0 = never
+SGNN_EXPORT int64_t sgnn_rulebook_set_full_rows(int64_t rows) {
+  const int64_t prev = g_rulebook_full_rows;
+  g_rulebook_full_rows = rows < 0 ? 0 : rows;
+  return prev;
+}
+
 static int g_rulebook_lds = 0;   // sgnn_rulebook_set_lds(1) selects the LDS-window kernel (parity test, A/B)
 SGNN_EXPORT int sgnn_rulebook_set_lds(int on) {
   const int prev = g_rulebook_lds;
@@ -461,6 +520,12 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   SGNN_CHECK_ARG(coords && nbr);
   if (g_rulebook_lds) {
     SGNN_LAUNCH(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
+                       vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+  }
+  if (ld <= g_rulebook_full_rows) {   // small level: one launch, no pre-fill
+    SGNN_LAUNCH(k_rulebook_subm3_full, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
                        vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
@@ -542,6 +607,65 @@ struct ScanLimit {
 };
 static const ScanLimit kNoLimit{-1, nullptr, 0, nullptr};
 
+// Round 5: the write kernels derive their offsets from the RAW block sums themselves where the table is short
+// (nblk <= SCAN_INLINE_MAX: at most one 16 KB, L2-resident read per workgroup), so the single-workgroup scan launch between
+// the count and the write kernel disappears (15 launches of a configs[1] training step: 11 stride-2 levels + 4 mask
+// compactions).  Integer sums: the offsets and counts are the scan kernel's, bit for bit.  ScanInline.nblk == 0 keeps the
+// three-launch form (block_sums already hold exclusive offsets).
+#define SCAN_INLINE_MAX 4096
+static int g_scan_inline = 1;   // sgnn_scan_set_inline: 0 = the separate scan launch everywhere (A/B measurements, parity test)
+SGNN_EXPORT int sgnn_scan_set_inline(int on) {
+  const int prev = g_scan_inline;
+  g_scan_inline = on ? 1 : 0;
+  return prev;
+}
+static inline bool scan_inline_ok(int64_t nblk) { return g_scan_inline && nblk >= 1 && nblk <= SCAN_INLINE_MAX; }
+
+struct ScanInline {
+  int64_t nblk;      // > 0: block_sums are raw counts, this many of them
+  int64_t *count;    // where workgroup 0 publishes the (clamped) total
+  ScanLimit lim;
+};
+static const ScanInline kNoInline{0, nullptr, {-1, nullptr, 0, nullptr}};
+
+// before = sum of sums[0 .. b), total = sum of all; lds8: 8 ints of LDS (free again on return).  Call from all threads.
+__device__ __forceinline__ void scan_offsets_inline(const int32_t *sums, int64_t nblk, int64_t b, int *lds8, int &before,
+                                                    int64_t &total) {
+  int sb = 0, sa = 0;
+  for (int64_t i = threadIdx.x; i < nblk; i += 256) {
+    const int v = sums[i];
+    sa += v;
+    sb += (i < b) ? v : 0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    sa += __shfl_xor(sa, d);
+    sb += __shfl_xor(sb, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    lds8[threadIdx.x >> 6] = sb;
+    lds8[4 + (threadIdx.x >> 6)] = sa;
+  }
+  __syncthreads();
+  before = lds8[0] + lds8[1] + lds8[2] + lds8[3];
+  total = (int64_t)lds8[4] + lds8[5] + lds8[6] + lds8[7];
+  __syncthreads();
+}
+
+// what k_scan_block_sums' last thread does with the total: clamp, flag, publish.  Returns the clamped count; only the
+// publishing thread (workgroup 0, thread 0) writes.
+__device__ __forceinline__ int64_t scan_publish(int64_t total, int64_t *count, const ScanLimit &lim, bool writer) {
+  int64_t c = total;
+  const bool over = lim.cap >= 0 && c > lim.cap;
+  if (over) c = lim.cap;
+  if (writer) {
+    if (over && lim.status) atomicOr(lim.status, SGNN_STATUS_OVERFLOW);
+    *count = c;
+    if (lim.count_mul) *lim.count_mul = c * lim.mul;
+  }
+  return c;
+}
+
 __global__ __launch_bounds__(1024) void k_scan_block_sums(int32_t *__restrict__ block_sums, int64_t nblk,
                                                          int64_t *__restrict__ count, ScanLimit lim) {
   __shared__ int wsum[16];
@@ -584,11 +708,18 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(int32_t *__restrict__ 
 
 template <class F, class Emit>
 __global__ __launch_bounds__(256) void k_scan_emit(F flag, Emit emit, int64_t n,
-                                                  const int32_t *__restrict__ block_offsets, const int64_t *n_dev) {
+                                                  const int32_t *block_offsets, const int64_t *n_dev, ScanInline si) {
   n = sgnn_dyn_n(n, n_dev);
-  __shared__ int lds[4];
+  __shared__ int lds[8];
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
-  int running = block_offsets[blockIdx.x];
+  int running;
+  if (si.nblk > 0) {     // raw block sums: this workgroup's offset and the total, no scan launch (uniform over the launch)
+    int64_t total;
+    scan_offsets_inline(block_offsets, si.nblk, blockIdx.x, lds, running, total);
+    scan_publish(total, si.count, si.lim, blockIdx.x == 0 && threadIdx.x == 0);
+  } else {
+    running = block_offsets[blockIdx.x];
+  }
 #pragma unroll 1
   for (int it = 0; it < SCAN_ITEMS; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
@@ -605,13 +736,24 @@ struct EmitSel {
   __device__ __forceinline__ void operator()(int64_t i, int rank) const { sel[rank] = (int32_t)i; }
 };
 
+struct EmitSelLocs {   // + the kept sites' coordinates, as sgnn_gather_rows_dn(coords, sel) would copy them (rows past the
+  int32_t *sel;        //   capacity of `locs` are dropped: such a step is flagged SGNN_STATUS_OVERFLOW and discarded)
+  const int4 *coords;
+  int4 *locs;
+  int64_t cap;
+  __device__ __forceinline__ void operator()(int64_t i, int rank) const {
+    sel[rank] = (int32_t)i;
+    if (rank < cap) locs[rank] = coords[i];
+  }
+};
+
 SGNN_EXPORT int64_t sgnn_compact_ws_bytes(int64_t n) {
   const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   return (nblk + 1) * (int64_t)sizeof(int32_t) + 64;
 }
 
-template <class F>
-static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes,
+template <class F, class Emit>
+static int compact_impl(F flag, Emit emit, int64_t n, int64_t *count, void *ws, int64_t ws_bytes,
                         hipStream_t s, const int64_t *n_dev = nullptr, const ScanLimit &lim = kNoLimit) {
   if (n == 0) {
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), s);
@@ -629,9 +771,10 @@ static int compact_impl(F flag, int64_t n, int32_t *sel, int64_t *count, void *w
   const int64_t nblk = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   int32_t *block_sums = (int32_t *)ws;
   SGNN_LAUNCH((k_scan_count<F>), dim3((unsigned)nblk), dim3(256), 0, s, flag, n, block_sums, n_dev);
-  SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count, lim);
-  SGNN_LAUNCH((k_scan_emit<F, EmitSel>), dim3((unsigned)nblk), dim3(256), 0, s, flag, EmitSel{sel}, n,
-                     (const int32_t *)block_sums, n_dev);
+  const bool inl = scan_inline_ok(nblk);
+  if (!inl) SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, count, lim);
+  SGNN_LAUNCH((k_scan_emit<F, Emit>), dim3((unsigned)nblk), dim3(256), 0, s, flag, emit, n,
+                     (const int32_t *)block_sums, n_dev, inl ? ScanInline{nblk, count, lim} : kNoInline);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     sgnn_set_error("compact: HIP error: %s", hipGetErrorString(e));
@@ -644,7 +787,7 @@ SGNN_EXPORT int sgnn_compact_sigmoid(const float *logits, int64_t stride, int64_
                                      int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && count && stride >= 1 && n < (1ll << 31));
   SGNN_CHECK_ARG(n == 0 || (logits && sel));
-  return compact_impl(FlagSigmoid{logits, stride}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+  return compact_impl(FlagSigmoid{logits, stride}, EmitSel{sel}, n, count, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // Capacity mode of the two generative mask compactions: the candidate count comes from device memory (*n_dev, NULL =
@@ -656,7 +799,7 @@ SGNN_EXPORT int sgnn_compact_sigmoid_cap(const float *logits, int64_t stride, in
   SGNN_CHECK_ARG(n >= 0 && count2 && stride >= 1 && n < (1ll << 31) && keep_cap >= 0 && status);
   SGNN_CHECK_ARG(n == 0 || (logits && sel));
   if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
-  return compact_impl(FlagSigmoid{logits, stride}, n, sel, count2, ws, ws_bytes, (hipStream_t)stream, n_dev,
+  return compact_impl(FlagSigmoid{logits, stride}, EmitSel{sel}, n, count2, ws, ws_bytes, (hipStream_t)stream, n_dev,
                       ScanLimit{keep_cap, count2 + 1, 8, status});
 }
 
@@ -667,7 +810,33 @@ SGNN_EXPORT int sgnn_compact_dense_cap(const int32_t *coords, int64_t n, const i
                  status);
   SGNN_CHECK_ARG(n == 0 || (coords && vol && sel));
   if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
-  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, n, sel, count2, ws, ws_bytes,
+  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, EmitSel{sel}, n, count2, ws, ws_bytes,
+                      (hipStream_t)stream, n_dev, ScanLimit{keep_cap, count2 + 1, 8, status});
+}
+
+// The same two compactions, also writing locs[r] = coords[sel[r]] for the kept rows r < keep_cap — what the caller otherwise
+// gathers with a launch of its own (sgnn_gather_rows_dn) on the critical path between two generative stages.
+SGNN_EXPORT int sgnn_compact_sigmoid_cap_locs(const float *logits, int64_t stride, int64_t n, const int64_t *n_dev,
+                                              const int32_t *coords, int32_t *sel, int32_t *locs, int64_t *count2,
+                                              int64_t keep_cap, int32_t *status, void *ws, int64_t ws_bytes,
+                                              sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count2 && stride >= 1 && n < (1ll << 31) && keep_cap >= 0 && status);
+  SGNN_CHECK_ARG(n == 0 || (logits && sel && coords && (locs || keep_cap == 0)));
+  if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
+  return compact_impl(FlagSigmoid{logits, stride}, EmitSelLocs{sel, (const int4 *)coords, (int4 *)locs, keep_cap}, n, count2,
+                      ws, ws_bytes, (hipStream_t)stream, n_dev, ScanLimit{keep_cap, count2 + 1, 8, status});
+}
+
+SGNN_EXPORT int sgnn_compact_dense_cap_locs(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol,
+                                            int batch, int d0, int d1, int d2, int32_t *sel, int32_t *locs, int64_t *count2,
+                                            int64_t keep_cap, int32_t *status, void *ws, int64_t ws_bytes,
+                                            sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && count2 && n < (1ll << 31) && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0 && keep_cap >= 0 &&
+                 status);
+  SGNN_CHECK_ARG(n == 0 || (coords && vol && sel && (locs || keep_cap == 0)));
+  if (n == 0) SGNN_HIP_TRY(hipMemsetAsync(count2, 0, 2 * sizeof(int64_t), (hipStream_t)stream));
+  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2},
+                      EmitSelLocs{sel, (const int4 *)coords, (int4 *)locs, keep_cap}, n, count2, ws, ws_bytes,
                       (hipStream_t)stream, n_dev, ScanLimit{keep_cap, count2 + 1, 8, status});
 }
 
@@ -678,7 +847,7 @@ SGNN_EXPORT int sgnn_compact_dense(const int32_t *coords, int64_t n, const float
                                    int32_t *sel, int64_t *count, void *ws, int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && count && n < (1ll << 31) && batch >= 0 && d0 >= 0 && d1 >= 0 && d2 >= 0);
   SGNN_CHECK_ARG(n == 0 || (coords && vol && sel));
-  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, n, sel, count, ws, ws_bytes,
+  return compact_impl(FlagDense{(const int4 *)coords, vol, batch, d0, d1, d2}, EmitSel{sel}, n, count, ws, ws_bytes,
                       (hipStream_t)stream);
 }
 
@@ -686,7 +855,7 @@ SGNN_EXPORT int sgnn_compact_mask(const uint8_t *mask, int64_t n, int32_t *sel, 
                                   int64_t ws_bytes, sgnn_stream_t stream) {
   SGNN_CHECK_ARG(n >= 0 && count && n < (1ll << 31));
   SGNN_CHECK_ARG(n == 0 || (mask && sel));
-  return compact_impl(FlagMask{mask}, n, sel, count, ws, ws_bytes, (hipStream_t)stream);
+  return compact_impl(FlagMask{mask}, EmitSel{sel}, n, count, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -795,10 +964,12 @@ SGNN_EXPORT int sgnn_rulebook_down2(const int32_t *fine_coords, int64_t nf, uint
   FlagOwner flag{slot_of, cvals};
   SGNN_LAUNCH((k_scan_count<FlagOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag, nf, block_sums,
                      (const int64_t *)nullptr);
-  SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse, kNoLimit);
+  const bool inl = scan_inline_ok(nblk);
+  if (!inl) SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, n_coarse, kNoLimit);
   SGNN_LAUNCH((k_scan_emit<FlagOwner, EmitOwner>), dim3((unsigned)nblk), dim3(256), 0, s, flag,
                      EmitOwner{(const int4 *)fine_coords, (int4 *)coarse_coords, rank_at}, nf,
-                     (const int32_t *)block_sums, (const int64_t *)nullptr);
+                     (const int32_t *)block_sums, (const int64_t *)nullptr,
+                     inl ? ScanInline{nblk, n_coarse, kNoLimit} : kNoInline);
   SGNN_LAUNCH(k_down2_parent, dim3(g), dim3(256), 0, s, nf, (const int32_t *)cvals,
                      (const int32_t *)rank_at, (const int32_t *)slot_of, parent);
   SGNN_LAUNCH(k_down2_fix_vals, dim3(g), dim3(256), 0, s, nf, (const int32_t *)slot_of,
@@ -827,10 +998,10 @@ __global__ __launch_bounds__(256) void k_chain_init(unsigned long long *__restri
   }
 }
 
-__global__ __launch_bounds__(256) void k_chain_insert(const int4 *__restrict__ fine, const int64_t *n_dev, int64_t n_host,
-                                                     unsigned long long *__restrict__ ckeys,
-                                                     int32_t *__restrict__ owner, uint64_t mask,
-                                                     int32_t *__restrict__ slot_of) {
+__device__ __forceinline__ void chain_insert_rows(const int4 *__restrict__ fine, const int64_t *n_dev, int64_t n_host,
+                                                  unsigned long long *__restrict__ ckeys,
+                                                  int32_t *__restrict__ owner, uint64_t mask,
+                                                  int32_t *__restrict__ slot_of) {
   const int64_t nf = dev_n(n_dev, n_host);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -846,6 +1017,13 @@ __global__ __launch_bounds__(256) void k_chain_insert(const int4 *__restrict__ f
     atomicMin(&owner[slot], (int32_t)i);  // first-touch owner = smallest fine row
     slot_of[i] = (int32_t)slot;
   }
+}
+
+__global__ __launch_bounds__(256) void k_chain_insert(const int4 *__restrict__ fine, const int64_t *n_dev, int64_t n_host,
+                                                     unsigned long long *__restrict__ ckeys,
+                                                     int32_t *__restrict__ owner, uint64_t mask,
+                                                     int32_t *__restrict__ slot_of) {
+  chain_insert_rows(fine, n_dev, n_host, ckeys, owner, mask, slot_of);
 }
 
 __global__ __launch_bounds__(256) void k_chain_count(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ owner,
@@ -869,12 +1047,19 @@ __global__ __launch_bounds__(256) void k_chain_count(const int32_t *__restrict__
 // owners, in fine-row order, become the coarse rows: coordinates and rank
 __global__ __launch_bounds__(256) void k_chain_emit(const int4 *__restrict__ fine, const int32_t *__restrict__ slot_of,
                                                    const int32_t *__restrict__ owner, const int64_t *n_dev,
-                                                   int64_t n_host, const int32_t *__restrict__ block_offsets,
-                                                   int4 *__restrict__ coarse, int32_t *__restrict__ rank_at) {
-  __shared__ int lds[4];
+                                                   int64_t n_host, const int32_t *block_offsets,
+                                                   int4 *__restrict__ coarse, int32_t *__restrict__ rank_at, ScanInline si) {
+  __shared__ int lds[8];
   const int64_t n = dev_n(n_dev, n_host);
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
-  int running = block_offsets[blockIdx.x];
+  int running;
+  if (si.nblk > 0) {
+    int64_t total;
+    scan_offsets_inline(block_offsets, si.nblk, blockIdx.x, lds, running, total);
+    scan_publish(total, si.count, si.lim, blockIdx.x == 0 && threadIdx.x == 0);
+  } else {
+    running = block_offsets[blockIdx.x];
+  }
 #pragma unroll 1
   for (int it = 0; it < SCAN_ITEMS; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
@@ -950,11 +1135,12 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
                        owner, (uint64_t)(ccap - 1), slot_of);
     SGNN_LAUNCH(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, block_sums);
-    SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
-                       level_caps ? ScanLimit{level_caps[l] < cap ? level_caps[l] : cap, nullptr, 0, status} : kNoLimit);
+    const ScanLimit lim = level_caps ? ScanLimit{level_caps[l] < cap ? level_caps[l] : cap, nullptr, 0, status} : kNoLimit;
+    const bool inl = scan_inline_ok(nblk);
+    if (!inl) SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l, lim);
     SGNN_LAUNCH(k_chain_emit, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of,
                        (const int32_t *)owner, n_dev, n_host, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
-                       rank_at);
+                       rank_at, inl ? ScanInline{nblk, counts_dev + l, lim} : kNoInline);
     SGNN_LAUNCH(k_chain_parent, dim3(g), dim3(256), 0, s, n_dev, n_host, (const int32_t *)owner,
                        (const int32_t *)rank_at, (const int32_t *)slot_of, (int32_t *)parent[l], (int32_t *)cvals[l]);
     fine = (const int4 *)coarse_coords[l];
@@ -1000,20 +1186,30 @@ __global__ __launch_bounds__(256) void k_chain_init_all(ChainInit a) {
 
 __global__ __launch_bounds__(256) void k_chain_emit2(const int4 *__restrict__ fine, const int32_t *__restrict__ slot_of,
                                                     const int32_t *__restrict__ owner, const int64_t *n_dev,
-                                                    int64_t n_host, const int32_t *__restrict__ block_offsets,
+                                                    int64_t n_host, const int32_t *block_offsets,
                                                     int4 *__restrict__ coarse, int32_t *__restrict__ rank_at,
-                                                    const int64_t *nc_dev, int32_t *__restrict__ children, int64_t ldc) {
-  __shared__ int lds[4];
+                                                    const int64_t *nc_dev, int32_t *__restrict__ children, int64_t ldc,
+                                                    ScanInline si) {
+  __shared__ int lds[8];
   const int64_t n = dev_n(n_dev, n_host);
-  // children[8][0 .. roundup256(live coarse rows)) := -1 (the count is final: the scan kernel ran before this one)
+  int running = 0;
+  int64_t nc_live;
+  if (si.nblk > 0) {     // raw block sums: offset, total and the clamped live count of the coarse level from this workgroup's own sum
+    int64_t total;
+    scan_offsets_inline(block_offsets, si.nblk, blockIdx.x, lds, running, total);
+    nc_live = scan_publish(total, si.count, si.lim, blockIdx.x == 0 && threadIdx.x == 0);
+  } else {
+    nc_live = sgnn_dyn_n(ldc, nc_dev);      // final: the scan kernel ran before this one
+  }
+  // children[8][0 .. roundup256(live coarse rows)) := -1
   {
-    const int64_t end = pad_end(sgnn_dyn_n(ldc, nc_dev), ldc);
+    const int64_t end = pad_end(nc_live, ldc);
     const int64_t total = end * 8, stride = (int64_t)gridDim.x * 256;
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) children[(g / end) * ldc + (g % end)] = -1;
   }
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK;
   if (base >= n) return;
-  int running = block_offsets[blockIdx.x];
+  if (si.nblk <= 0) running = block_offsets[blockIdx.x];
 #pragma unroll 1
   for (int it = 0; it < SCAN_ITEMS; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
@@ -1029,14 +1225,28 @@ __global__ __launch_bounds__(256) void k_chain_emit2(const int4 *__restrict__ fi
   }
 }
 
-__global__ __launch_bounds__(256) void k_chain_parent_tables(const int4 *__restrict__ fine, const int64_t *n_dev,
-                                                            int64_t n_host, const int32_t *__restrict__ owner,
-                                                            const int32_t *__restrict__ rank_at,
-                                                            const int32_t *__restrict__ slot_of,
-                                                            int32_t *__restrict__ parent, int32_t *__restrict__ cvals,
-                                                            const int64_t *nc_dev, int64_t nc_cap,
-                                                            int32_t *__restrict__ children, int64_t ldc,
-                                                            int32_t *__restrict__ ptable, int64_t ldf) {
+struct ChainTables {   // arguments of the parent / children / ptable pass of one level
+  const int4 *fine;
+  const int64_t *n_dev;
+  int64_t n_host;
+  const int32_t *owner, *rank_at, *slot_of;
+  int32_t *parent, *cvals;
+  const int64_t *nc_dev;
+  int64_t nc_cap;
+  int32_t *children;
+  int64_t ldc;
+  int32_t *ptable;
+  int64_t ldf;
+};
+
+__device__ __forceinline__ void chain_parent_tables_rows(const int4 *__restrict__ fine, const int64_t *n_dev,
+                                                         int64_t n_host, const int32_t *__restrict__ owner,
+                                                         const int32_t *__restrict__ rank_at,
+                                                         const int32_t *__restrict__ slot_of,
+                                                         int32_t *__restrict__ parent, int32_t *__restrict__ cvals,
+                                                         const int64_t *nc_dev, int64_t nc_cap,
+                                                         int32_t *__restrict__ children, int64_t ldc,
+                                                         int32_t *__restrict__ ptable, int64_t ldf) {
   const int64_t nf = dev_n(n_dev, n_host);
   const int64_t nc = sgnn_dyn_n(nc_cap, nc_dev);
   const int64_t iend = pad_end(nf, ldf);
@@ -1059,6 +1269,29 @@ __global__ __launch_bounds__(256) void k_chain_parent_tables(const int4 *__restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) ptable[(int64_t)k * ldf + i] = (k == off) ? p : -1;
   }
+}
+
+__global__ __launch_bounds__(256) void k_chain_parent_tables(ChainTables t) {
+  chain_parent_tables_rows(t.fine, t.n_dev, t.n_host, t.owner, t.rank_at, t.slot_of, t.parent, t.cvals, t.nc_dev, t.nc_cap,
+                           t.children, t.ldc, t.ptable, t.ldf);
+}
+
+// Round 5: the tables pass of level l and the hash insertion of level l + 1 both wait for level l's write kernel only
+// (coarse coordinates + count, ranks) and touch disjoint arrays — one launch runs both loops (a launch less per inner level).
+__global__ __launch_bounds__(256) void k_chain_tables_insert(ChainTables t, unsigned long long *__restrict__ ckeys_next,
+                                                            int32_t *__restrict__ owner_next, uint64_t mask,
+                                                            int32_t *__restrict__ slot_of_next, const int4 *coarse,
+                                                            int64_t n_host_next) {
+  chain_parent_tables_rows(t.fine, t.n_dev, t.n_host, t.owner, t.rank_at, t.slot_of, t.parent, t.cvals, t.nc_dev, t.nc_cap,
+                           t.children, t.ldc, t.ptable, t.ldf);
+  chain_insert_rows(coarse, t.nc_dev, n_host_next, ckeys_next, owner_next, mask, slot_of_next);
+}
+
+static int g_chain_merged = 1;   // sgnn_chain_set_merged: 0 = one launch per pass (A/B measurements, parity test)
+SGNN_EXPORT int sgnn_chain_set_merged(int on) {
+  const int prev = g_chain_merged;
+  g_chain_merged = on ? 1 : 0;
+  return prev;
 }
 
 SGNN_EXPORT int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth) {
@@ -1105,21 +1338,28 @@ SGNN_EXPORT int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_
   const int64_t *n_dev = n0_dev;
   int64_t fine_cap = cap;
   const int g = sgnn_grid_for(cap, 256, 8192);
+  const bool inl = scan_inline_ok(nblk), merged = g_chain_merged != 0;
   for (int l = 0; l < depth; ++l) {
     const int64_t ccap_l = level_caps[l] < cap ? level_caps[l] : cap;
     const int64_t ldc = ((ccap_l + 255) / 256) * 256, ldf = ((fine_cap + 255) / 256) * 256;
-    SGNN_LAUNCH(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (unsigned long long *)ckeys[l], owner[l],
-                       (uint64_t)(ccap - 1), slot_of[l]);
+    if (l == 0 || !merged)     // (merged: level l's insertion ran in the tables launch of level l - 1)
+      SGNN_LAUNCH(k_chain_insert, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (unsigned long long *)ckeys[l], owner[l],
+                         (uint64_t)(ccap - 1), slot_of[l]);
     SGNN_LAUNCH(k_chain_count, dim3((unsigned)nblk), dim3(256), 0, s, (const int32_t *)slot_of[l],
                        (const int32_t *)owner[l], n_dev, cap, block_sums);
-    SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l,
-                       ScanLimit{ccap_l, nullptr, 0, status});
+    const ScanLimit lim{ccap_l, nullptr, 0, status};
+    if (!inl) SGNN_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, block_sums, nblk, counts_dev + l, lim);
     SGNN_LAUNCH(k_chain_emit2, dim3((unsigned)nblk), dim3(256), 0, s, fine, (const int32_t *)slot_of[l],
                        (const int32_t *)owner[l], n_dev, cap, (const int32_t *)block_sums, (int4 *)coarse_coords[l],
-                       rank_at[l], (const int64_t *)(counts_dev + l), (int32_t *)children[l], ldc);
-    SGNN_LAUNCH(k_chain_parent_tables, dim3(g), dim3(256), 0, s, fine, n_dev, cap, (const int32_t *)owner[l],
-                       (const int32_t *)rank_at[l], (const int32_t *)slot_of[l], (int32_t *)parent[l], (int32_t *)cvals[l],
-                       (const int64_t *)(counts_dev + l), ccap_l, (int32_t *)children[l], ldc, (int32_t *)ptable[l], ldf);
+                       rank_at[l], (const int64_t *)(counts_dev + l), (int32_t *)children[l], ldc,
+                       inl ? ScanInline{nblk, counts_dev + l, lim} : kNoInline);
+    const ChainTables t{fine, n_dev, cap, owner[l], rank_at[l], slot_of[l], (int32_t *)parent[l], (int32_t *)cvals[l],
+                        counts_dev + l, ccap_l, (int32_t *)children[l], ldc, (int32_t *)ptable[l], ldf};
+    if (merged && l + 1 < depth)
+      SGNN_LAUNCH(k_chain_tables_insert, dim3(g), dim3(256), 0, s, t, (unsigned long long *)ckeys[l + 1], owner[l + 1],
+                         (uint64_t)(ccap - 1), slot_of[l + 1], (const int4 *)coarse_coords[l], cap);
+    else
+      SGNN_LAUNCH(k_chain_parent_tables, dim3(g), dim3(256), 0, s, t);
     fine = (const int4 *)coarse_coords[l];
     n_dev = counts_dev + l;
     fine_cap = ccap_l;
@@ -1196,6 +1436,34 @@ SGNN_EXPORT int sgnn_expand8_coords(const int32_t *coords, int64_t n, int32_t *o
   SGNN_CHECK_ARG(coords && out);
   SGNN_LAUNCH(k_expand8, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const int4 *)coords, n, (int4 *)out, n_dev);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// the children AND their int64 (z, y, x, b) rows — the per-level `locs` output of the model (torch/model.py:207,243) — in one
+// pass instead of an expansion launch followed by a conversion launch on the critical path between two stages
+__global__ __launch_bounds__(256) void k_expand8_i64(const int4 *__restrict__ coords, int64_t n, int4 *__restrict__ out,
+                                                    int64_t *__restrict__ locs, const int64_t *n_dev) {
+  n = sgnn_dyn_n(n, n_dev);
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per child
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; t < 8 * n; t += stride) {
+    const int4 c = coords[t >> 3];
+    const int j = (int)(t & 7);
+    const int4 o = make_int4(2 * c.x + (j >> 2), 2 * c.y + ((j >> 1) & 1), 2 * c.z + (j & 1), c.w);
+    out[t] = o;
+    reinterpret_cast<longlong2 *>(locs)[2 * t] = make_longlong2(o.x, o.y);
+    reinterpret_cast<longlong2 *>(locs)[2 * t + 1] = make_longlong2(o.z, o.w);
+  }
+}
+
+SGNN_EXPORT int sgnn_expand8_coords_i64(const int32_t *coords, int64_t n, int32_t *out, int64_t *locs, const int64_t *n_dev,
+                                        sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords && out && locs);
+  SGNN_LAUNCH(k_expand8_i64, dim3(sgnn_grid_for(8 * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const int4 *)coords, n, (int4 *)out, locs, n_dev);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -405,7 +405,7 @@ class Refinement(nn.Module):
                                     ext=ext, idx=idx, extra_rows=extra,
                                     extra_cnt=None if cnt8 is None else {'child': cnt8})
         children = getattr(locs, '_sgnn_children', None)     # already made by GenModel._teacher_plans
-        return outs[0], outs[1], (children if children is not None else F_.expand8_coords(locs))
+        return outs[0], outs[1], (children if children is not None else F_.expand8_coords(locs, with_i64=True))
 
 
 def _stage_program(owner, prev, skip, chain, nf_in, tail):

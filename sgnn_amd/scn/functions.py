@@ -10,8 +10,13 @@ from .. import _lib
 from .._lib import ptr
 from .metadata import runtime
 
+import os
+
 CONV_TRANSPOSE_W = 1
 CONV_FLIP_K = 2
+# Round 5: the glue between two generative stages with fewer launches (kept coordinates written by the compaction's write
+# kernel, children + their int64 rows in one pass).  SGNN_FUSED_GLUE=0 restores the separate launches (A/B, parity test).
+FUSED_GLUE = os.environ.get('SGNN_FUSED_GLUE', '1') != '0'
 
 
 _ws_cache = {}
@@ -534,16 +539,25 @@ def compact_capped(logits, stride, n_all, coords_all, depth, capacity, g, teache
     sel = torch.empty(max(n_all, 1), dtype=torch.int32, device=dev)
     wsb = _lib.query('sgnn_compact_ws_bytes', n_all)
     ws = rt.workspace(wsb)
-    if teacher is None:
-        _lib.call('sgnn_compact_sigmoid_cap', ptr(logits), stride, n_all, ptr(n_cnt), ptr(sel), ptr(cnt2), K,
-                  ptr(rt.status32), ptr(ws), wsb)
-    else:
-        B, _, d0, d1, d2 = (int(v) for v in teacher.shape)
-        _lib.call('sgnn_compact_dense_cap', ptr(coords_all), n_all, ptr(n_cnt), ptr(teacher), B, d0, d1, d2, ptr(sel),
-                  ptr(cnt2), K, ptr(rt.status32), ptr(ws), wsb)
     kept, kept8 = cnt2[0:1], cnt2[1:2]
     locs = torch.empty(K, 4, dtype=torch.int32, device=dev)
-    _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(kept), K, ptr(locs))
+    if FUSED_GLUE:       # the kept sites' coordinates are written by the compaction's own write kernel
+        if teacher is None:
+            _lib.call('sgnn_compact_sigmoid_cap_locs', ptr(logits), stride, n_all, ptr(n_cnt), ptr(coords_all), ptr(sel),
+                      ptr(locs), ptr(cnt2), K, ptr(rt.status32), ptr(ws), wsb)
+        else:
+            B, _, d0, d1, d2 = (int(v) for v in teacher.shape)
+            _lib.call('sgnn_compact_dense_cap_locs', ptr(coords_all), n_all, ptr(n_cnt), ptr(teacher), B, d0, d1, d2,
+                      ptr(sel), ptr(locs), ptr(cnt2), K, ptr(rt.status32), ptr(ws), wsb)
+    else:
+        if teacher is None:
+            _lib.call('sgnn_compact_sigmoid_cap', ptr(logits), stride, n_all, ptr(n_cnt), ptr(sel), ptr(cnt2), K,
+                      ptr(rt.status32), ptr(ws), wsb)
+        else:
+            B, _, d0, d1, d2 = (int(v) for v in teacher.shape)
+            _lib.call('sgnn_compact_dense_cap', ptr(coords_all), n_all, ptr(n_cnt), ptr(teacher), B, d0, d1, d2, ptr(sel),
+                      ptr(cnt2), K, ptr(rt.status32), ptr(ws), wsb)
+        _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(kept), K, ptr(locs))
     locs._sgnn_cnt, locs._sgnn_cnt8 = kept, kept8
     if depth >= 1:
         depth = min(depth, len(pyr_caps))
@@ -570,13 +584,22 @@ def gather_coords(coords32, sel, m):
     return out
 
 
-def expand8_coords(coords32):
+def expand8_coords(coords32, with_i64=False):
+    """with_i64: the children's int64 rows (what coords_to_i64 would return for them) are written in the same pass and
+    travel with the result (`_sgnn_i64`) — the model returns them as the level's `locs`."""
     n = coords32.shape[0]
     out = torch.empty(8 * n, 4, dtype=torch.int32, device=coords32.device)
     cnt = getattr(coords32, '_sgnn_cnt', None)
-    _lib.call('sgnn_expand8_coords', ptr(coords32), n, ptr(out), ptr(cnt))
+    if with_i64 and FUSED_GLUE:
+        o64 = torch.empty(8 * n, 4, dtype=torch.int64, device=coords32.device)
+        _lib.call('sgnn_expand8_coords_i64', ptr(coords32), n, ptr(out), ptr(o64), ptr(cnt))
+        out._sgnn_i64 = o64
+    else:
+        _lib.call('sgnn_expand8_coords', ptr(coords32), n, ptr(out), ptr(cnt))
     if cnt is not None:          # capacity mode: the children's live row count (8 x kept) sits next to the kept count
         out._sgnn_cnt = coords32._sgnn_cnt8
+        if getattr(out, '_sgnn_i64', None) is not None:
+            out._sgnn_i64._sgnn_cnt = out._sgnn_cnt
     return out
 
 
@@ -587,6 +610,9 @@ def dense_coords(batch, d0, d1, d2, device):
 
 
 def coords_to_i64(coords32):
+    made = getattr(coords32, '_sgnn_i64', None)       # expand8_coords(with_i64=True) already wrote them
+    if made is not None:
+        return made
     n = coords32.shape[0]
     out = torch.empty(n, 4, dtype=torch.int64, device=coords32.device)
     cnt = getattr(coords32, '_sgnn_cnt', None)

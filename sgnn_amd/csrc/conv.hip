@@ -1522,7 +1522,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     else                                            \
       LAUNCH_DW(CI, CO, true, false);               \
   }
-  X(48, 16) X(24, 8)
+  X(48, 16) X(24, 8) X(64, 32) X(56, 28)   // up-sampling convolution; dense ConvTranspose3d(k4,s2) by parity groups (model.DenseK4S2)
 #undef X
   if (!done) {
     if (ldx != cin || ld_dy != cout) {

@@ -34,9 +34,38 @@ STAGES = True   # each generative stage (skip join .. heads) as one native progr
 TEACHER_GEOMETRY_FIRST = os.environ.get('SGNN_TEACHER_GEOMETRY_FIRST', '1') != '0'
 
 
+def _k4s2_maps():
+    """The 64 taps of a k4/s2/p1 convolution (or transposed convolution) grouped by the PARITY of the fine voxel they touch.
+    A fine voxel 2c + j (j = its parity per axis) meets coarse voxel c + o through tap k = j + 1 - 2o on that axis, so per
+    axis two taps and two coarse neighbours serve each parity: with i = o + 1 - j in {0, 1}, slot q = g*8 + i_
+    (g = 4jz+2jy+jx, i_ = 4iz+2iy+ix) holds tap K4S2_TAPS[q] and reads the coarse level's 3x3x3 neighbour row K4S2_NBR[q]
+    — the index structure of the generative up-sampling convolution (functions.expand_maps).  The dense k4/s2 weights
+    are STORED in this slot order (DenseConv), so the fine side of every such layer — ConvTranspose3d forward and its weight
+    gradient, Conv3d data gradient — runs as 8 parity groups of 8 taps on the coarse rulebook instead of walking 64 taps per
+    fine voxel of which 56 are empty."""
+    P, S = [], []
+    for g in range(8):
+        j = (g >> 2, (g >> 1) & 1, g & 1)
+        for i_ in range(8):
+            i = (i_ >> 2, (i_ >> 1) & 1, i_ & 1)
+            k = [3 - 2 * i[a] - j[a] for a in range(3)]
+            o = [i[a] - 1 + j[a] for a in range(3)]
+            P.append((k[0] * 4 + k[1]) * 4 + k[2])
+            S.append((o[0] + 1) * 9 + (o[1] + 1) * 3 + (o[2] + 1))
+    assert sorted(P) == list(range(64))
+    return P, S
+
+
+K4S2_TAPS, K4S2_NBR = _k4s2_maps()
+K4S2_SLOT = [K4S2_TAPS.index(t) for t in range(64)]     # slot of tap (kz*4+ky)*4+kx
+# 8 parity groups on the coarse rulebook (default) / 0: the 64-tap walk over the fine rows (A/B measurements, parity test)
+DENSE_PARITY = os.environ.get('SGNN_DENSE_PARITY', '1') != '0'
+
+
 class DenseConv(nn.Module):
     """Parameter holder of an nn.Conv3d / nn.ConvTranspose3d (bias=False, torch/model.py:89-136) whose `weight` lives
-    in the layout the rulebook kernels read — (K = k^3 taps, Cin, Cout) — instead of torch's (Cout, Cin, k, k, k) /
+    in the layout the rulebook kernels read — (K = k^3 taps, Cin, Cout), the taps of a k4/s2 layer in parity-group order
+    (K4S2_TAPS) — instead of torch's (Cout, Cin, k, k, k) /
     (Cin, Cout, k, k, k): the training step no longer re-permutes six weight tensors (and their gradients) every
     iteration.  state_dict() / load_state_dict() speak the torch layout, so reference checkpoints load unchanged and
     saved ones load into the reference; initial values are drawn exactly as the torch module draws them."""
@@ -50,12 +79,21 @@ class DenseConv(nn.Module):
         self.weight._sgnn_dense = self     # optimizer checkpoints convert their per-parameter state with it too
         self._register_state_dict_hook(DenseConv._save_hook)
 
+    @property
+    def parity_order(self):      # k4/s2/p1: the taps are stored in parity-group order (K4S2_TAPS)
+        return self.k == 4 and self.stride == 2 and self.pad == 1
+
     def to_native(self, w):      # torch layout -> (K, Cin, Cout)
         perm = (2, 3, 4, 0, 1) if self.transposed else (2, 3, 4, 1, 0)
-        return w.permute(*perm).reshape(self.k ** 3, self.cin, self.cout).contiguous()
+        w = w.permute(*perm).reshape(self.k ** 3, self.cin, self.cout)
+        if self.parity_order:
+            w = w[torch.tensor(K4S2_TAPS, device=w.device)]
+        return w.contiguous()
 
     def to_torch(self, w):       # (K, Cin, Cout) -> torch layout
         k = self.k
+        if self.parity_order:
+            w = w[torch.tensor(K4S2_SLOT, device=w.device)]
         w = w.reshape(k, k, k, self.cin, self.cout)
         return (w.permute(3, 4, 0, 1, 2) if self.transposed else w.permute(4, 3, 0, 1, 2)).contiguous()
 
@@ -220,17 +258,22 @@ class _DenseGeometry(object):
         self._levels = {}
 
     def level(self, lv):
-        """Tables between pyramid level lv (dims / 2^lv) and lv+1: (down [64][ld_c], ld_c, n_c, up [64][ld_f],
-        ld_f, n_f).  down[k][o] = fine row feeding coarse voxel o through tap k = (kz*4+ky)*4+kx
-        (input index 2*o - 1 + k, zero padding 1); up[k][i] = coarse row that fine voxel i feeds through tap k."""
+        """Tables between pyramid level lv (fine, dims / 2^lv) and lv+1 (coarse), an object with
+          tdown (64 x ld_c): tdown[q][o] = fine row feeding coarse voxel o through the tap of slot q (K4S2_TAPS[q] =
+                (kz*4+ky)*4+kx: input index 2*o - 1 + k per axis, zero padding 1);
+          tup (64 x ld_f):   tup[q][i] = coarse row that fine voxel i meets through that tap (56 of the 64 are -1);
+          nbr27 (27 x ld_c): the coarse level's dense 3x3x3 neighbour table (row (oz+1)*9+(oy+1)*3+(ox+1));
+          slots (64):        K4S2_NBR — the nbr27 row of slot q;
+          child_of_raster (n_f) / raster_of_child (n_f): fine voxel <-> its position 8*coarse + parity in child order.
+        Rows of both levels are batch-major raster order."""
         if lv not in self._levels:
             fd = [d >> lv for d in self.dims]
             if any(d % 2 for d in fd):
                 raise ValueError('dense level dims %s are not even' % (fd,))
             cd = [d // 2 for d in fd]
             dev, B = self.device, self.batch
-            k = torch.arange(64, device=dev)
-            kz, ky, kx = (k // 16).view(64, 1), ((k // 4) % 4).view(64, 1), (k % 4).view(64, 1)
+            taps = torch.tensor(K4S2_TAPS, device=dev)
+            kz, ky, kx = (taps // 16).view(64, 1), ((taps // 4) % 4).view(64, 1), (taps % 4).view(64, 1)
 
             def unravel(n, d):
                 r = torch.arange(n, device=dev)
@@ -247,14 +290,35 @@ class _DenseGeometry(object):
             ok = (iz >= 0) & (iz < fd[0]) & (iy >= 0) & (iy < fd[1]) & (ix >= 0) & (ix < fd[2])
             down = torch.full((64, ld_c), -1, dtype=torch.int32, device=dev)
             down[:, :n_c] = torch.where(ok, ((b_ * fd[0] + iz) * fd[1] + iy) * fd[2] + ix, -1).to(torch.int32)
+            o = torch.arange(27, device=dev)
+            oz, oy, ox = (o // 9 - 1).view(27, 1), ((o // 3) % 3 - 1).view(27, 1), (o % 3 - 1).view(27, 1)
+            nz, ny, nx = z_ + oz, y_ + oy, x_ + ox
+            ok = (nz >= 0) & (nz < cd[0]) & (ny >= 0) & (ny < cd[1]) & (nx >= 0) & (nx < cd[2])
+            nbr27 = torch.full((27, ld_c), -1, dtype=torch.int32, device=dev)
+            nbr27[:, :n_c] = torch.where(ok, ((b_ * cd[0] + nz) * cd[1] + ny) * cd[2] + nx, -1).to(torch.int32)
             b_, z_, y_, x_ = unravel(n_f, fd)
             tz, ty, tx = z_ + 1 - kz, y_ + 1 - ky, x_ + 1 - kx
             ok = ((tz >= 0) & (tz % 2 == 0) & (tz // 2 < cd[0]) & (ty >= 0) & (ty % 2 == 0) & (ty // 2 < cd[1]) &
                   (tx >= 0) & (tx % 2 == 0) & (tx // 2 < cd[2]))
             up = torch.full((64, ld_f), -1, dtype=torch.int32, device=dev)
             up[:, :n_f] = torch.where(ok, ((b_ * cd[0] + tz // 2) * cd[1] + ty // 2) * cd[2] + tx // 2, -1).to(torch.int32)
-            self._levels[lv] = (down.contiguous().view(-1), ld_c, n_c, up.contiguous().view(-1), ld_f, n_f)
+            coarse = ((b_ * cd[0] + z_ // 2) * cd[1] + y_ // 2) * cd[2] + x_ // 2
+            child = (8 * coarse + 4 * (z_ % 2) + 2 * (y_ % 2) + (x_ % 2)).view(-1)
+            raster = torch.empty_like(child)
+            raster[child] = torch.arange(n_f, device=dev)
+            t = _K4S2Level()
+            t.tdown, t.ld_c, t.n_c = down.contiguous().view(-1), ld_c, n_c
+            t.tup, t.ld_f, t.n_f = up.contiguous().view(-1), ld_f, n_f
+            t.nbr27 = nbr27.contiguous().view(-1)
+            t.slots = torch.tensor(K4S2_NBR, dtype=torch.int32, device=dev)
+            t.child_of_raster, t.raster_of_child = child.to(torch.int32).contiguous(), raster.to(torch.int32).contiguous()
+            self._levels[lv] = t
         return self._levels[lv]
+
+
+class _K4S2Level(object):
+    """Static index tables of one dense k4/s2 level pair (see _DenseGeometry.level)."""
+    __slots__ = ('tdown', 'ld_c', 'n_c', 'tup', 'ld_f', 'n_f', 'nbr27', 'slots', 'child_of_raster', 'raster_of_child')
 
 
 _dense_cache = {}
@@ -272,17 +336,16 @@ def dense_geometry(batch, dims, device):
 
 def _dense_conv(rows, conv, tables, down):
     """nn.Conv3d(k4,s2,p1) (down=True) or nn.ConvTranspose3d(k4,s2,p1) (down=False) on channel-last rows."""
-    tdown, ld_c, n_c, tup, ld_f, n_f = tables
     w = conv.weight
-    if isinstance(conv, DenseConv):        # already (64, Cin, Cout)
+    if isinstance(conv, DenseConv):        # already (64, Cin, Cout) in parity-group slot order
         wk = w
-    elif down:   # nn.Conv3d weight (Cout, Cin, 4,4,4) -> (64, Cin, Cout)
-        wk = w.permute(2, 3, 4, 1, 0).reshape(64, w.shape[1], w.shape[0])
-    else:        # nn.ConvTranspose3d (Cin, Cout, 4,4,4) -> (64, Cin, Cout)
-        wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])
-    if down:
-        return F_.SparseConv.apply(rows, wk, tdown, ld_c, n_c, tup, ld_f, n_f, F_.CONV_TRANSPOSE_W, 0)
-    return F_.SparseConv.apply(rows, wk, tup, ld_f, n_f, tdown, ld_c, n_c, F_.CONV_TRANSPOSE_W, 0)
+    else:
+        if down:     # nn.Conv3d weight (Cout, Cin, 4,4,4) -> (64 taps, Cin, Cout)
+            wk = w.permute(2, 3, 4, 1, 0).reshape(64, w.shape[1], w.shape[0])
+        else:        # nn.ConvTranspose3d (Cin, Cout, 4,4,4) -> (64 taps, Cin, Cout)
+            wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])
+        wk = wk[torch.tensor(K4S2_TAPS, device=w.device)]
+    return F_.DenseK4S2.apply(rows, wk, tables, bool(down), DENSE_PARITY)
 
 
 _ident_tables = {}

@@ -117,6 +117,73 @@ class SparseConv(Function):
         return dx, dw, None, None, None, None, None, None, None, None
 
 
+class DenseK4S2(Function):
+    """nn.Conv3d(k4,s2,p1) (down) / nn.ConvTranspose3d(k4,s2,p1) (up) between two dense pyramid levels on channel-last rows in
+    batch-major raster order (torch/model.py:89-136).  weight: (64, Cin, Cout), the taps in parity-group
+    slot order (model.K4S2_TAPS); lvl: model._DenseGeometry.level().
+
+    The coarse side of either layer sees all 64 taps (Conv3d forward, ConvTranspose3d data gradient, Conv3d weight
+    gradient): a 64-offset rulebook walk over the coarse rows (tdown), cut into tap slices that run side by side
+    (conv_fwd_split).  The FINE side sees 8 taps per voxel — which 8 is decided by the voxel's parity — so walking a
+    64-row table per fine voxel (tup) issues 56 empty gathers and MFMA blocks for every 8 that carry data.  With
+    `parity` the fine side runs on the COARSE rulebook instead, as 8 parity groups of 8 taps (sgnn_conv_fwd_ex /
+    sgnn_conv_bwd_weight_ex with groups = 8 — the walk of the generative up-sampling convolution, ExpandConv): rows come
+    out / go in in child order (8*coarse + parity) and one 16-byte-row gather converts to / from raster order.
+    Measured (profiles/r05u_*): ConvTranspose3d(56 -> 28) forward at 2048 -> 16384 rows and its weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lvl, down, parity):
+        x, weight = _f32c(x), _f32c(weight)
+        K, cin, cout = weight.shape
+        assert K == 64 and x.shape[1] == cin, 'k4/s2 layer: weight %s, rows %s' % (tuple(weight.shape), tuple(x.shape))
+        if down:
+            assert x.shape[0] == lvl.n_f
+            y = conv_fwd_split(x, cin, weight, 64, lvl.tdown, lvl.ld_c, lvl.n_c, cout, 0)
+        elif parity:
+            assert x.shape[0] == lvl.n_c
+            y8 = torch.empty(8 * lvl.n_c, cout, dtype=torch.float32, device=x.device)
+            _lib.call('sgnn_conv_fwd_ex', ptr(x), lvl.n_c, cin, ptr(weight), 8, ptr(lvl.nbr27), lvl.ld_c, lvl.n_c, cout,
+                      ptr(y8), 0, 0, ptr(lvl.slots), None, 1, 8, 27)
+            y = gather_rows_raw(y8, cout, lvl.child_of_raster, lvl.n_f)
+        else:
+            y = conv_fwd_split(x, cin, weight, 64, lvl.tup, lvl.ld_f, lvl.n_f, cout, 0)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (lvl, down, parity)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        lvl, down, parity = ctx.cfg
+        _, cin, cout = weight.shape
+        dy = _f32c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if not down:         # coarse side: all 64 taps
+                dx = conv_fwd_split(dy, cout, weight, 64, lvl.tdown, lvl.ld_c, lvl.n_c, cin, CONV_TRANSPOSE_W)
+            elif parity:
+                dx8 = torch.empty(8 * lvl.n_c, cin, dtype=torch.float32, device=dy.device)
+                _lib.call('sgnn_conv_fwd_ex', ptr(dy), lvl.n_c, cout, ptr(weight), 8, ptr(lvl.nbr27), lvl.ld_c, lvl.n_c,
+                          cin, ptr(dx8), CONV_TRANSPOSE_W, 0, ptr(lvl.slots), None, 1, 8, 27)
+                dx = gather_rows_raw(dx8, cin, lvl.child_of_raster, lvl.n_f)
+            else:
+                dx = conv_fwd_split(dy, cout, weight, 64, lvl.tup, lvl.ld_f, lvl.n_f, cin, CONV_TRANSPOSE_W)
+        if ctx.needs_input_grad[1]:
+            if down:
+                dw = conv_dw_raw(x, cin, dy, cout, lvl.tdown, lvl.ld_c, 64, lvl.n_c)
+            elif parity:
+                dy8 = gather_rows_raw(dy, cout, lvl.raster_of_child, lvl.n_f)
+                rt = runtime(x.device)
+                dw = torch.empty_like(weight)
+                wsb = _lib.query('sgnn_conv_bwd_weight_ws_bytes', lvl.n_c, 64, cin, cout)
+                ws = rt.workspace(wsb)
+                _lib.call('sgnn_conv_bwd_weight_ex', ptr(x), lvl.n_c, cin, ptr(dy8), cout, ptr(lvl.nbr27), lvl.ld_c, 8,
+                          lvl.n_c, ptr(dw), 0, ptr(lvl.slots), None, 1, 8, 27, ptr(ws), wsb)
+            else:
+                dw = conv_dw_raw(x, cin, dy, cout, lvl.tup, lvl.ld_f, 64, lvl.n_f)
+        return dx, dw, None, None, None
+
+
 _expand_cache = {}
 
 

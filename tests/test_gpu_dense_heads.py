@@ -8,10 +8,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.mark.parametrize('cin,cout,dims', [(16, 24, (8, 8, 8)), (24, 32, (4, 4, 4)), (16, 24, (4, 8, 4))])
-def test_dense_k4s2_conv_and_transpose_match_torch(cin, cout, dims):
-    """torch/model.py:89-136: nn.Conv3d / nn.ConvTranspose3d (k4, s2, p1) as 64-offset rulebooks."""
+@pytest.mark.parametrize('parity', [True, False])
+@pytest.mark.parametrize('cin,cout,dims', [(16, 24, (8, 8, 8)), (24, 32, (4, 4, 4)), (16, 24, (4, 8, 4)), (28, 56, (8, 8, 8)),
+                                            (32, 64, (4, 4, 4))])
+def test_dense_k4s2_conv_and_transpose_match_torch(cin, cout, dims, parity, monkeypatch):
+    """torch/model.py:89-136: nn.Conv3d / nn.ConvTranspose3d (k4, s2, p1) as rulebook walks — the fine side of each layer as 8
+    parity groups of 8 taps on the coarse rulebook (parity, the default) or as a 64-offset walk over the fine rows.  (28, 56)
+    and (32, 64) are the shapes of the model's two ConvTranspose3d layers, read right to left."""
     from sgnn_amd import model as M
+    monkeypatch.setattr(M, 'DENSE_PARITY', parity)
     torch.manual_seed(cin + cout)
     B = 3
     x = torch.randn(B, cin, *dims)

@@ -312,7 +312,7 @@ def test_inference_layout_packs_buffers_by_liveness():
 def test_dense_conv_keeps_native_layout_and_speaks_the_reference_layout():
     """model.DenseConv stores (K, Cin, Cout) — what the rulebook kernels read — while state_dict / load_state_dict /
     named_gradients use nn.Conv3d's (Cout, Cin, k, k, k) and nn.ConvTranspose3d's (Cin, Cout, k, k, k)."""
-    from sgnn_amd.model import DenseConv, GenModel, named_gradients
+    from sgnn_amd.model import DenseConv, GenModel, named_gradients, K4S2_SLOT
     torch.manual_seed(3)
     for transposed, (cin, cout, k) in ((False, (16, 24, 4)), (True, (64, 32, 4)), (False, (32, 32, 1))):
         ref = (torch.nn.ConvTranspose3d if transposed else torch.nn.Conv3d)(cin, cout, k, stride=2 if k == 4 else 1,
@@ -322,10 +322,13 @@ def test_dense_conv_keeps_native_layout_and_speaks_the_reference_layout():
         assert tuple(d.state_dict()['weight'].shape) == tuple(ref.weight.shape)
         d.load_state_dict(ref.state_dict())
         assert torch.equal(d.state_dict()['weight'], ref.weight.detach())
-        # tap (a, b, c) of the torch weight is slice a*k*k + b*k + c of the native one, transposed to (Cin, Cout)
+        # tap (a, b, c) of the torch weight is one (Cin, Cout) slice of the native one: slice a*k*k + b*k + c, or — k4/s2
+        # layers keep their taps in parity-group order (model.K4S2_TAPS) — the slot that holds that tap
         a, b, c = (1, 2, 3) if k == 4 else (0, 0, 0)
         want = ref.weight[:, :, a, b, c] if transposed else ref.weight[:, :, a, b, c].t()
-        assert torch.equal(d.weight[(a * k + b) * k + c], want)
+        slot = K4S2_SLOT[(a * k + b) * k + c] if k == 4 else (a * k + b) * k + c
+        assert d.parity_order == (k == 4)
+        assert torch.equal(d.weight[slot], want)
         assert torch.equal(d.to_native(d.to_torch(d.weight)), d.weight)
     torch.manual_seed(5)
     hm = GenModel(8, (32,) * 3, 1, 16, 16, 4, True, True, 1, 1)

@@ -498,6 +498,11 @@ int sgnn_prog_set_fusion(int on);
  * dy w is formed inside the two BatchNorm backward passes instead of being written and read back (bit-identical values);
  * 0 = k_linear_bwd writes it.  Applies to programs planned after the call.  Returns the previous setting. */
 int sgnn_prog_set_lin_bn(int on);
+/* a per-site linear head whose input rows already carry a gradient when its backward pass runs (a Refinement's two heads: the
+ * rows the next level reads brought theirs, torch/model.py:230-243): 1 (default) = the head's kernel writes dy w + that
+ * gradient in one pass; 0 = it writes dy w and an add launch over the level follows.  Same sums (one fp32 addition per
+ * element either way).  Returns the previous setting. */
+int sgnn_prog_set_lin_add(int on);
 /* BatchNormReLU -> convolution (torch/model.py:37-42, 181, 187, 256: every scn.BatchNormReLU in front of a
  * SubmanifoldConvolution / Convolution).  sgnn_prog_set_bn_fold(1): when the convolution is the only reader of the
  * BatchNorm output, the executor launches no apply pass — the convolution (forward, and its weight gradient in backward)

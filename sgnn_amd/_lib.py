@@ -105,6 +105,7 @@ PROTOTYPES = {
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
     'sgnn_prog_set_fusion': (c_i32, [c_i32]),
     'sgnn_prog_set_lin_bn': (c_i32, [c_i32]),
+    'sgnn_prog_set_lin_add': (c_i32, [c_i32]),
     'sgnn_prog_set_bn_fold': (c_i32, [c_i32]),
     'sgnn_prog_set_bn_fold_rows': (c_i64, [c_i64]),
     'sgnn_prog_defer_join': (c_i32, [c_i32]),

@@ -128,7 +128,8 @@ int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const 
                          float *y, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
                          float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
-                         sgnn_stream_t stream, const int64_t *n_dev = nullptr);
+                         sgnn_stream_t stream, const int64_t *n_dev = nullptr, const float *addend = nullptr,
+                         int64_t ld_add = 0);
 
 // every kernel launch of the library goes through this macro: sgnn_launch_count() (bench.py: launches per step =
 // kernel nodes this library contributes to the captured graph of one training step)

@@ -58,10 +58,12 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 }
 
 // dx[r][c] = sum_o dy[r][o] w[o][c]; block partials of dW[o][c] = sum_r dy[r][o] x[r][c], db[o] = sum_r dy[r][o]
+// addend (may be dx itself): a gradient the input rows already carry — dx = dy w + addend in the same pass instead of an
+// add launch over the level behind this one (row stride ld_add floats, a multiple of 4 when CIN % 4 == 0)
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_linear_bwd(const float *__restrict__ x, const float *__restrict__ dy,
-                                                   int64_t n, LinW p, float *__restrict__ dx,
-                                                   double *__restrict__ partial, const int64_t *n_dev) {
+                                                   int64_t n, LinW p, float *dx, double *__restrict__ partial,
+                                                   const int64_t *n_dev, const float *addend, int64_t ld_add) {
   constexpr int NV = COUT * CIN + COUT;
   n = sgnn_dyn_n(n, n_dev);
   __shared__ float ws[COUT * CIN];
@@ -91,6 +93,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd(const float *__restrict__ x,
 #pragma unroll
         for (int o = 0; o < COUT; ++o) t = fmaf(g[o], ws[o * CIN + c], t);
         d[c] = t;
+      }
+      if (addend) {       // uniform over the launch
+        float a[CIN];
+        load_row<CIN, (CIN % 4 == 0) ? 4 : 1>(addend + r * ld_add, a);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) d[c] += a[c];
       }
       if constexpr (CIN % 4 == 0) {
 #pragma unroll
@@ -137,8 +145,10 @@ __global__ __launch_bounds__(256) void k_linear_finalize(const double *__restric
   }
 }
 
+// one row per thread up to LIN_MAX_BLOCKS workgroups (a thread's rows are a serial load -> FMA -> store chain: with four rows per
+// thread the heads of a 16 k-row level ran 13-14 us on 16 CUs), several rows per thread only above 131 k rows
 static int lin_blocks(int64_t n) {
-  int64_t b = (n + 1023) / 1024;
+  int64_t b = (n + 255) / 256;
   if (b < 1) b = 1;
   if (b > LIN_MAX_BLOCKS) b = LIN_MAX_BLOCKS;
   return (int)b;
@@ -193,9 +203,10 @@ SGNN_EXPORT int sgnn_linear_fwd(const float *x, int64_t n, int cin, const float 
 
 int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, const float *const *w, int cout,
                          float *dx, float *const *dw, float *const *db, void *ws, int64_t ws_bytes,
-                         sgnn_stream_t stream, const int64_t *n_dev) {
+                         sgnn_stream_t stream, const int64_t *n_dev, const float *addend, int64_t ld_add) {
   hipStream_t s = (hipStream_t)stream;
   SGNN_CHECK_ARG(n >= 0 && cin >= 1 && cout >= 1 && cout <= LIN_MAX_OUT && w);
+  SGNN_CHECK_ARG(!addend || (dx && ld_add >= cin && (cin % 4 != 0 || (ld_add % 4 == 0 && ((uintptr_t)addend & 15) == 0))));
   if (n == 0) {
     for (int o = 0; o < cout; ++o) {
       if (dw && dw[o]) SGNN_HIP_TRY(hipMemsetAsync(dw[o], 0, (size_t)cin * sizeof(float), s));
@@ -221,7 +232,7 @@ int sgnn_linear_bwd_rows(const float *x, const float *dy, int64_t n, int cin, co
   bool done = false;
 #define X(CI, CO)                                                                                          \
   if (!done && cin == CI && cout == CO) {                                                                  \
-    SGNN_LAUNCH((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws, n_dev); \
+    SGNN_LAUNCH((k_linear_bwd<CI, CO>), dim3(nblk), dim3(256), 0, s, x, dy, n, p, dx, (double *)ws, n_dev, addend, ld_add); \
     done = true;                                                                                           \
   }
   LIN_CASES(X)

@@ -58,6 +58,7 @@ std::vector<int> count_readers(const View &v) {
 }
 
 bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
+bool g_lin_add = true; // sgnn_prog_set_lin_add: a head's data gradient is added to the gradient its input already carries inside the head's kernel
 bool g_lin_bn = true; // sgnn_prog_set_lin_bn: the head's data gradient formed inside the BatchNorm backward passes (BnLin)
 // sgnn_prog_set_bn_fold(1): BatchNormReLU layers whose only reader is a convolution launch no apply pass — the convolution
 // normalises the rows in its gather (BnPre).  2 = its exact A/B reference: the same statistics (finalised in the same
@@ -488,6 +489,11 @@ SGNN_EXPORT int64_t sgnn_prog_set_bn_fold_rows(int64_t rows) {
 SGNN_EXPORT int sgnn_prog_set_lin_bn(int on) {
   const int prev = g_lin_bn ? 1 : 0;
   g_lin_bn = on != 0;
+  return prev;
+}
+SGNN_EXPORT int sgnn_prog_set_lin_add(int on) {
+  const int prev = g_lin_add ? 1 : 0;
+  g_lin_add = on != 0;
   return prev;
 }
 SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
@@ -1040,6 +1046,17 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           // weight / bias gradients only; the BatchNorm before the head forms dx = dy w itself in both of its passes
           PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, nullptr, dw, db, ws, ws_bytes, stream, CNT(lev)));
           lazy_lin[in0] = i;
+          break;
+        }
+        // the input rows already carry a gradient (the caller's, for the rows the next level reads; an alias; or G itself):
+        // the head adds it in its own pass — dx = dy w + that — instead of an add launch over the level (round 5)
+        const float *have = (g_fuse && g_lin_add && wants(in0) && init[in0] && n > 0) ? GR(in0) : nullptr;
+        const int64_t have_ld = have ? GRLD(in0) : 0;
+        if (have && have_ld % 4 == 0 && ((uintptr_t)have & 15) == 0 && !viewed[in0]) {
+          PROG_TRY(sgnn_linear_bwd_rows(X(in0), dy, n, cin, w, cout, G(in0), dw, db, ws, ws_bytes, stream, CNT(lev), have,
+                                        have_ld));
+          alias[in0] = -1;
+          init[in0] = 1;
           break;
         }
         float *t = wants(in0) ? target(in0, 0) : nullptr;

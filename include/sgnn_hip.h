@@ -95,10 +95,6 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
  * table only for neighbours not found there); default 0 = the global-probe kernel, which measured faster on MI355X
  * (96.7 vs 123.9 us at N = 366 k).  Both produce identical tables.  Returns the previous setting. */
 int sgnn_rulebook_set_lds(int on);
-/* Tables of at most `rows` rows (ld) are built by the 26-probe kernel: every entry written by the site's own thread, no
- * pre-fill launch of the mirrored rows (default 32768: the launch-bound coarse levels; 0 = the 13-probe mirrored kernel
- * everywhere).  Identical tables.  Returns the previous setting. */
-int64_t sgnn_rulebook_set_full_rows(int64_t rows);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         const int64_t *n_dev, sgnn_stream_t stream);

@@ -25,7 +25,6 @@ PROTOTYPES = {
     'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_rulebook_set_lds': (c_i32, [c_i32]),
-    'sgnn_rulebook_set_full_rows': (c_i64, [c_i64]),
     'sgnn_scan_set_inline': (c_i32, [c_i32]),
     'sgnn_chain_set_merged': (c_i32, [c_i32]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),

@@ -233,58 +233,10 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
   nbr[(int64_t)13 * ld + j] = (int32_t)j;
 }
 
-// ---------------------------------------------------------------------------
-// Small levels (round 5): all 26 neighbours probed by the site's own thread — twice the probes of the mirrored kernel above,
-// but they are independent loads of ONE round trip either way on a level that cannot fill the chip, every table entry has
-// exactly one writer (the site's thread, coalesced) and the pre-fill launch of rows 14..26 disappears (10 of the 13
-// hash-built rulebooks of a configs[1] step are on such levels).  Same table as k_rulebook_subm3, entry for entry.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rulebook_subm3_full(const uint64_t *__restrict__ keys,
-                                                            const int32_t *__restrict__ vals, uint64_t mask,
-                                                            const int4 *__restrict__ coords, int64_t n,
-                                                            int32_t *__restrict__ nbr, int64_t ld,
-                                                            const int64_t *n_dev) {
-  n = sgnn_dyn_n(n, n_dev);
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= pad_end(n, ld)) return;
-  if (j >= n) {  // padding entries: the conv kernels rely on them being -1
-#pragma unroll
-    for (int k = 0; k < 27; ++k) nbr[(int64_t)k * ld + j] = -1;
-    return;
-  }
-  const int4 c = coords[j];
-  uint64_t key[27], slot[27], got[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-    const int z = c.x + dz, y = c.y + dy, x = c.z + dx;
-    const bool ok = k != 13 && ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u);
-    key[k] = ok ? sgnn_pack_key(z, y, x, c.w) : SGNN_EMPTY_KEY;     // the empty key never matches a stored one
-    slot[k] = sgnn_hash64(key[k]) & mask;
-  }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) got[k] = key[k] == SGNN_EMPTY_KEY ? SGNN_EMPTY_KEY : keys[slot[k]];
-  int32_t r[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) r[k] = (got[k] == key[k] && key[k] != SGNN_EMPTY_KEY) ? vals[slot[k]] : -1;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    if (got[k] != key[k] && got[k] != SGNN_EMPTY_KEY) {              // first slot held another key: keep probing
-      uint64_t sl = (slot[k] + 1) & mask;
-      while (true) {
-        const uint64_t kk = keys[sl];
-        if (kk == key[k]) {
-          r[k] = vals[sl];
-          break;
-        }
-        if (kk == SGNN_EMPTY_KEY) break;
-        sl = (sl + 1) & mask;
-      }
-    }
-    nbr[(int64_t)k * ld + j] = (k == 13) ? (int32_t)j : r[k];
-  }
-}
-
+// (Round 5: a 26-probe variant — every entry written by the site's own thread, no mirror scatter, no pre-fill launch of
+//  rows 14..26 — was built for the levels below 32 k rows, produced identical tables, and ran 2-4x as long as this kernel plus
+//  its pre-fill (27 x {key, slot, probe} live per thread; 44 vs 16 us at 12.6 k rows, 27 vs 14 us at 2.7 k rows under
+//  rocprofv3, profiles/r05w_step_launches.csv) for a launch that costs < 2 us in a replayed graph: deleted.)
 // ---------------------------------------------------------------------------
 // The same rulebook with the voxel index of a row WINDOW held in LDS (north_star: "hash-table voxel indexing in LDS").
 // A workgroup owns 256 consecutive rows; in every site order this pipeline produces — batch-major raster order of the
@@ -498,13 +450,6 @@ SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *v
   return SGNN_OK;
 }
 
-static int64_t g_rulebook_full_rows = 32768;   // tables of at most this many rows (ld) use the 26-probe kernel; 0 = never
-SGNN_EXPORT int64_t sgnn_rulebook_set_full_rows(int64_t rows) {
-  const int64_t prev = g_rulebook_full_rows;
-  g_rulebook_full_rows = rows < 0 ? 0 : rows;
-  return prev;
-}
-
 static int g_rulebook_lds = 0;   // sgnn_rulebook_set_lds(1) selects the LDS-window kernel (parity test, A/B)
 SGNN_EXPORT int sgnn_rulebook_set_lds(int on) {
   const int prev = g_rulebook_lds;
@@ -520,12 +465,6 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   SGNN_CHECK_ARG(coords && nbr);
   if (g_rulebook_lds) {
     SGNN_LAUNCH(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
-                       vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
-    SGNN_CHECK_LAUNCH();
-    return SGNN_OK;
-  }
-  if (ld <= g_rulebook_full_rows) {   // small level: one launch, no pre-fill
-    SGNN_LAUNCH(k_rulebook_subm3_full, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
                        vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;

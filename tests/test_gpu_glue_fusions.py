@@ -4,7 +4,6 @@ switch must not change a single bit of any table, site list or count —
 * sgnn_scan_set_inline      the write kernels of the compactions / stride-2 levels sum the raw block counts themselves
                             (no scan launch between the count and the write kernel);
 * sgnn_chain_set_merged     tables pass of level l + hash insertion of level l + 1 in one launch;
-* sgnn_rulebook_set_full_rows   26-probe rulebook kernel on small levels (no pre-fill launch of the mirrored rows);
 * SGNN_FUSED_GLUE / functions.FUSED_GLUE   kept coordinates written by the compaction's write kernel, children and
                             their int64 rows in one pass.
 
@@ -20,35 +19,6 @@ pytestmark = pytest.mark.gpu
 def _lib():
     from sgnn_amd import _lib as L
     return L.load()
-
-
-@pytest.mark.parametrize('order', ['raster', 'shuffled', 'children'])
-def test_full_probe_rulebook_equals_mirrored_rulebook(order):
-    from sgnn_amd import synth
-    from sgnn_amd.scn import functions as F_
-    from sgnn_amd.scn.metadata import Grid, coords_from_locs
-    lib = _lib()
-    locs = synth.make_batch(3, (32, 32, 32), cfg=9, occupancy=0.1)['input'][0]
-    extra = torch.tensor([[0, 0, 0, 0], [31, 31, 31, 1], [0, 31, 0, 2], [32, 5, 5, 0], [31, 5, 5, 0]], dtype=locs.dtype)
-    locs = torch.unique(torch.cat([locs, extra]), dim=0)
-    if order == 'shuffled':
-        locs = locs[torch.randperm(locs.shape[0], generator=torch.Generator().manual_seed(0))]
-    coords = coords_from_locs(locs, torch.device('cuda'))
-    if order == 'children':
-        coords = F_.expand8_coords(coords)
-    tabs = []
-    for rows in (1 << 30, 0):          # every level "small" / no level small
-        prev = lib.sgnn_rulebook_set_full_rows(rows)
-        try:
-            g = Grid(coords)
-            tabs.append(g.subm_table().clone())
-        finally:
-            lib.sgnn_rulebook_set_full_rows(prev)
-    assert torch.equal(tabs[0], tabs[1])
-    n = coords.shape[0]
-    t = tabs[0].view(27, -1)
-    assert torch.equal(t[13, :n].cpu(), torch.arange(n, dtype=torch.int32))
-    assert int((t[:, n:] != -1).sum()) == 0
 
 
 @pytest.mark.parametrize('keep_cap', [1 << 20, 37])
@@ -118,7 +88,7 @@ def test_expand8_with_int64_rows_equals_the_two_launches():
 
 def test_capacity_forward_is_bit_identical_with_the_fusions_off():
     """The whole capacity-mode forward + backward (compactions, stride-2 chains with their tables, rulebooks, every level's
-    site list, logits, loss, gradients) with all four fusions on (the default) and with all of them off."""
+    site list, logits, loss, gradients) with the fusions on (the default) and with all of them off."""
     from test_gpu_capacity import _batch, _model, _classic, _capped
     from sgnn_amd.scn.capacity import Capacity
     from sgnn_amd.scn import functions as F_
@@ -128,8 +98,7 @@ def test_capacity_forward_is_bit_identical_with_the_fusions_off():
     _, _, _, log = _classic(_model(), batch, lw)
     runs = []
     for on in (True, False):
-        prev = (lib.sgnn_scan_set_inline(int(on)), lib.sgnn_chain_set_merged(int(on)),
-                lib.sgnn_rulebook_set_full_rows(32768 if on else 0), F_.FUSED_GLUE)
+        prev = (lib.sgnn_scan_set_inline(int(on)), lib.sgnn_chain_set_merged(int(on)), F_.FUSED_GLUE)
         F_.FUSED_GLUE = on
         try:
             m = _model()
@@ -142,8 +111,7 @@ def test_capacity_forward_is_bit_identical_with_the_fusions_off():
         finally:
             lib.sgnn_scan_set_inline(prev[0])
             lib.sgnn_chain_set_merged(prev[1])
-            lib.sgnn_rulebook_set_full_rows(prev[2])
-            F_.FUSED_GLUE = prev[3]
+            F_.FUSED_GLUE = prev[2]
     from sgnn_amd.scn.capacity import trim
     (sa, oa, la, lva, ga), (sb, ob, lb, lvb, gb) = runs
     assert lva == lvb

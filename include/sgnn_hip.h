@@ -109,6 +109,12 @@ int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
 int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *vals, int64_t cap, const int32_t *coords, int64_t n,
                               int dim_z, int dim_y, int dim_x, int32_t *volume, int64_t volume_entries, int32_t *nbr,
                               int64_t ld, const int64_t *n_dev, sgnn_stream_t stream);
+/* The same table for a level whose sites are known to lie inside the volume (the generated levels: children of a dense
+ * coarse volume bounded by the model's own sizes, torch/model.py:192-207): volume only, no hash grid of the level is read —
+ * or built.  A site the volume does not cover raises SGNN_STATUS_COORD_RANGE in *status. */
+int sgnn_rulebook_subm3_volume(const int32_t *coords, int64_t n, int dim_z, int dim_y, int dim_x, int32_t *volume,
+                               int64_t volume_entries, int32_t *nbr, int64_t ld, const int64_t *n_dev, int32_t *status,
+                               sgnn_stream_t stream);
 
 /* stride-2 / size-2 rulebook, phase 1 (scn.Convolution(...,2,2), torch/model.py:44):
  * finds the coarse active set unique(floor(p/2)) in FIRST-TOUCH order of the fine

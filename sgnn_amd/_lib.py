@@ -29,6 +29,7 @@ PROTOTYPES = {
     'sgnn_chain_set_merged': (c_i32, [c_i32]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_rulebook_subm3_volume': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
     'sgnn_rulebook_down2': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_down2_chain_ws_bytes': (c_i64, [c_i64]),

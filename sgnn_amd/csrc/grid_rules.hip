@@ -363,13 +363,16 @@ __device__ __forceinline__ bool vol_covers(const VolDims d, int z, int y, int x,
          (unsigned)b < (unsigned)d.bcap;
 }
 
+// status != NULL (volume-only rulebooks, sgnn_rulebook_subm3_volume): a site the volume does not cover has no other index
+// to be found in — SGNN_STATUS_COORD_RANGE is raised instead of building a table with holes
 __global__ __launch_bounds__(256) void k_vol_mark(const int4 *__restrict__ coords, int64_t n, int32_t *__restrict__ vol,
-                                                 VolDims d, int clear, const int64_t *n_dev) {
+                                                 VolDims d, int clear, const int64_t *n_dev, int32_t *status) {
   n = sgnn_dyn_n(n, n_dev);
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int4 c = coords[j];
   if (vol_covers(d, c.x, c.y, c.z, c.w)) vol[(((int64_t)c.w * d.Z + c.x) * d.Y + c.y) * d.X + c.z] = clear ? -1 : (int32_t)j;
+  else if (status) atomicOr(status, SGNN_STATUS_COORD_RANGE);
 }
 
 __global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__restrict__ keys,
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3_vol(const uint64_t *__re
         v = (int32_t)j;
       } else if (vol_covers(d, z, y, x, c.w)) {
         v = vol[(((int64_t)c.w * d.Z + z) * d.Y + y) * d.X + x];
-      } else if (((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u)) {
+      } else if (keys && ((unsigned)z <= 65535u) && ((unsigned)y <= 65535u) && ((unsigned)x <= 65535u)) {   // (keys == NULL: volume only)
         const uint64_t key = sgnn_pack_key(z, y, x, c.w);
         uint64_t sl = sgnn_hash64(key) & mask;
         while (true) {
@@ -442,10 +445,35 @@ SGNN_EXPORT int sgnn_rulebook_subm3_dense(const uint64_t *keys, const int32_t *v
   const VolDims d{dim_z, dim_y, dim_x, (int)(bcap > 65536 ? 65536 : bcap)};
   hipStream_t s = (hipStream_t)stream;
   const unsigned gn = (unsigned)((n + 255) / 256);
-  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev);
+  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev, (int32_t *)nullptr);
   SGNN_LAUNCH(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, keys, vals,
                      (uint64_t)(cap - 1), (const int4 *)coords, n, volume, d, nbr, ld, n_dev);
-  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev);
+  if (d.bcap > 0) SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev, (int32_t *)nullptr);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+// The same table for a level whose sites are KNOWN to lie inside the volume (generated levels: children of a dense coarse
+// volume, torch/model.py:192-207, bounded by the model's own sizes) — no hash grid of the level exists or is built: neighbours
+// outside the volume are absent by construction.  A site the volume does not cover breaks that promise and raises
+// SGNN_STATUS_COORD_RANGE in *status (the caller's deferred-error word) instead of producing a table with holes.
+SGNN_EXPORT int sgnn_rulebook_subm3_volume(const int32_t *coords, int64_t n, int dim_z, int dim_y, int dim_x, int32_t *volume,
+                                           int64_t volume_entries, int32_t *nbr, int64_t ld, const int64_t *n_dev,
+                                           int32_t *status, sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(n >= 0 && ld >= n && status && volume);
+  SGNN_CHECK_ARG(dim_z >= 1 && dim_y >= 1 && dim_x >= 1 && dim_z <= 65536 && dim_y <= 65536 && dim_x <= 65536);
+  if (n == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(coords && nbr);
+  const int64_t slab = (int64_t)dim_z * dim_y * dim_x;
+  const int64_t bcap = volume_entries / slab;
+  SGNN_CHECK_ARG(bcap >= 1);
+  const VolDims d{dim_z, dim_y, dim_x, (int)(bcap > 65536 ? 65536 : bcap)};
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned gn = (unsigned)((n + 255) / 256);
+  SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 0, n_dev, status);
+  SGNN_LAUNCH(k_rulebook_subm3_vol, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, (const uint64_t *)nullptr,
+                     (const int32_t *)nullptr, (uint64_t)0, (const int4 *)coords, n, volume, d, nbr, ld, n_dev);
+  SGNN_LAUNCH(k_vol_mark, dim3(gn), dim3(256), 0, s, (const int4 *)coords, n, volume, d, 1, n_dev, (int32_t *)nullptr);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

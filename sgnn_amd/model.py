@@ -254,6 +254,7 @@ class _DenseGeometry(object):
     def __init__(self, batch, dims, device):
         self.batch, self.dims, self.device = batch, dims, device
         self.coords = F_.dense_coords(batch, dims[0], dims[1], dims[2], device)
+        self.coords._sgnn_bounds = (int(batch), int(dims[0]), int(dims[1]), int(dims[2]))   # travels to every generated level
         self.grid = scn.Grid(self.coords)
         self._levels = {}
 

@@ -581,10 +581,11 @@ def compact_sigmoid_plan(logits, stride, n, coords_all, depth, teacher=None):
     _compact_call(logits, stride, n, coords_all, sel, rt, ws, wsb, teacher)
     locs_cap = torch.empty(n, 4, dtype=torch.int32, device=logits.device)
     _lib.call('sgnn_gather_rows_dn', ptr(coords_all), 4, ptr(sel), ptr(rt.state), n, ptr(locs_cap))
+    _inherit_bounds(locs_cap, coords_all)
     chain = MD.PendingChain(locs_cap, 0, True, depth)
     host = rt.read_counts()
     count = int(host[0])
-    locs = locs_cap[:count]
+    locs = _inherit_bounds(locs_cap[:count], coords_all)
     if MD.COUNT_LOG is not None:
         MD.COUNT_LOG.append(('gen', count, [int(v) for v in host[2:2 + chain.depth]]))
     if count:
@@ -607,7 +608,7 @@ def compact_capped(logits, stride, n_all, coords_all, depth, capacity, g, teache
     wsb = _lib.query('sgnn_compact_ws_bytes', n_all)
     ws = rt.workspace(wsb)
     kept, kept8 = cnt2[0:1], cnt2[1:2]
-    locs = torch.empty(K, 4, dtype=torch.int32, device=dev)
+    locs = _inherit_bounds(torch.empty(K, 4, dtype=torch.int32, device=dev), coords_all)
     if FUSED_GLUE:       # the kept sites' coordinates are written by the compaction's own write kernel
         if teacher is None:
             _lib.call('sgnn_compact_sigmoid_cap_locs', ptr(logits), stride, n_all, ptr(n_cnt), ptr(coords_all), ptr(sel),
@@ -644,11 +645,20 @@ def compact_mask(mask_u8, n):
     return sel[:count], count
 
 
+def _inherit_bounds(coords, parent, scale=1):
+    """A subset (scale = 1) or the 8-child expansion (scale = 2) of sites that lie in [0, Z) x [0, Y) x [0, X), b < B by
+    construction does so too: the bound travels with the coordinates (Grid.bounds: such a level needs no hash grid)."""
+    b = getattr(parent, '_sgnn_bounds', None)
+    if b is not None:
+        coords._sgnn_bounds = (int(b[0]), int(b[1]) * scale, int(b[2]) * scale, int(b[3]) * scale)
+    return coords
+
+
 def gather_coords(coords32, sel, m):
     """coords rows are 16-byte rows: reuse the fp32 row gather as a pure bit copy."""
     out = torch.empty(m, 4, dtype=torch.int32, device=coords32.device)
     _lib.call('sgnn_gather_rows', ptr(coords32), 4, ptr(sel), m, ptr(out))
-    return out
+    return _inherit_bounds(out, coords32)
 
 
 def expand8_coords(coords32, with_i64=False):
@@ -667,7 +677,7 @@ def expand8_coords(coords32, with_i64=False):
         out._sgnn_cnt = coords32._sgnn_cnt8
         if getattr(out, '_sgnn_i64', None) is not None:
             out._sgnn_i64._sgnn_cnt = out._sgnn_cnt
-    return out
+    return _inherit_bounds(out, coords32, 2)
 
 
 def dense_coords(batch, d0, d1, d2, device):

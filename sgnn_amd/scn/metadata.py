@@ -176,6 +176,9 @@ DENSE_RULEBOOK_MIN_ROWS = int(os.environ.get('SGNN_DENSE_RULEBOOK_MIN_ROWS', '16
 if DENSE_RULEBOOK_MIN_ROWS < 0:
     DENSE_RULEBOOK_MIN_ROWS = 1 << 62
 INDEX_VOLUME_ENTRIES = int(os.environ.get('SGNN_INDEX_VOLUME_MB', '128')) << 18
+# generated levels whose sites are inside the index volume by construction build their rulebook from the volume alone and
+# never build a hash grid of their own (Grid.bounds); SGNN_VOLUME_ONLY=0: hash grid + volume with hash fall-back (A/B, parity)
+VOLUME_ONLY = os.environ.get('SGNN_VOLUME_ONLY', '1') != '0'
 
 
 def _round_up(n, m):
@@ -196,6 +199,9 @@ class Grid(object):
         self._nbr = None
         self.ready = None      # see Down2.ready
         self.dims = None       # spatial size (z, y, x) of the level once a Metadata registers the grid
+        # (B, Z, Y, X): every site satisfies b < B, z < Z, ... BY CONSTRUCTION (generated levels: children of a dense coarse
+        # volume; the model passes the bound along with the coordinates) — such a level's rulebook needs no hash grid
+        self.bounds = getattr(coords32, '_sgnn_bounds', None)
         self.ld = _round_up(max(self.n, 1), 256)   # table leading dimension (conv kernels: multiple of 256)
 
     def hash(self):
@@ -220,11 +226,22 @@ class Grid(object):
     def subm_table(self):
         """3x3x3 neighbour table, int32 [27][ld] (cached; one build serves every conv of the level)."""
         if self._nbr is None:
+            d, vb = self.dims, self.bounds
+            dense = (d is not None and len(d) == 3 and self.n >= DENSE_RULEBOOK_MIN_ROWS
+                     and 0 < d[0] * d[1] * d[2] <= INDEX_VOLUME_ENTRIES and max(d) <= 65536)
+            if (dense and VOLUME_ONLY and vb is not None and self.keys is None and all(int(vb[1 + a]) <= int(d[a]) for a in range(3))
+                    and int(vb[0]) * d[0] * d[1] * d[2] <= INDEX_VOLUME_ENTRIES):
+                # every site lies inside the volume by construction: volume only — the level's hash grid is never built
+                # (sgnn_hash_build at 517 k sites: 50 us on the training queue between two stages)
+                rt = runtime(self.device)
+                self._nbr = torch.empty(27 * self.ld, dtype=torch.int32, device=self.device)
+                vol = rt.index_volume()
+                _lib.call('sgnn_rulebook_subm3_volume', ptr(self.coords), self.n, int(d[0]), int(d[1]), int(d[2]), ptr(vol),
+                          vol.numel(), ptr(self._nbr), self.ld, ptr(self.cnt), ptr(rt.status32))
+                return self._nbr
             keys, vals, cap = self.hash()
             self._nbr = torch.empty(27 * self.ld, dtype=torch.int32, device=self.device)
-            d = self.dims
-            if (d is not None and len(d) == 3 and self.n >= DENSE_RULEBOOK_MIN_ROWS
-                    and 0 < d[0] * d[1] * d[2] <= INDEX_VOLUME_ENTRIES and max(d) <= 65536):
+            if dense:
                 vol = runtime(self.device).index_volume()
                 _lib.call('sgnn_rulebook_subm3_dense', ptr(keys), ptr(vals), cap, ptr(self.coords), self.n, int(d[0]),
                           int(d[1]), int(d[2]), ptr(vol), vol.numel(), ptr(self._nbr), self.ld, ptr(self.cnt))
@@ -352,6 +369,7 @@ class PendingChain(object):
         """-> (grid of level 0, [Down2 level l -> l+1])."""
         counts = [int(v) for v in host_state[2:2 + self.depth]]
         fine = Grid(self.coords_cap[:n0])
+        fine.bounds = getattr(self.coords_cap, '_sgnn_bounds', None)
         grid0, downs = fine, []
         for l in range(self.depth):
             nc = counts[l]

@@ -153,8 +153,9 @@ int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_d
                      void *ws, int64_t ws_bytes, sgnn_stream_t stream);
 
 /* Capacity mode: the pyramid AND its tables in one submission — sgnn_down2_chain (row counts from *n0_dev, clamped to
- * level_caps, SGNN_STATUS_OVERFLOW) followed by sgnn_down2_tables of every level, as 5 launches per level + 1 instead of
- * 8 per level.  children[l] is (8 x ldc_l), ldc_l = roundup256(min(level_caps[l], cap)); ptable[l] is (8 x ldf_l),
+ * level_caps, SGNN_STATUS_OVERFLOW) followed by sgnn_down2_tables of every level, as 3 launches per level + 2 (round 5: insert,
+ * count, write kernel; the tables pass of a level shares a launch with the next level's insertion; 5 per level + 1 with
+ * sgnn_scan_set_inline(0) / sgnn_chain_set_merged(0)) instead of 8 per level.  children[l] is (8 x ldc_l), ldc_l = roundup256(min(level_caps[l], cap)); ptable[l] is (8 x ldf_l),
  * ldf_0 = roundup256(cap), ldf_l = ldc_{l-1}.  Only rows below roundup256(live count) of a table are written (and read). */
 int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth);
 int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_t *n0_dev, int64_t cap, int depth,

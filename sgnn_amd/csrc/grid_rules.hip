@@ -1121,7 +1121,8 @@ SGNN_EXPORT int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const i
 // ---------------------------------------------------------------------------
 // Capacity mode: the whole stride-2 pyramid INCLUDING its children / ptable tables in one submission with 5 launches
 // per level + 1 per chain (the step-by-step form above needs 8 per level: init, insert, count, scan, emit, parent,
-// children pre-fill, tables):
+// children pre-fill, tables) — 3 per level + 2 since round 5: the write kernel sums the block counts itself (no scan
+// launch, scan_offsets_inline) and the tables pass of level l shares a launch with the insertion of level l + 1:
 //   k_chain_init_all   every level's hash / owner / rank scratch (each level has its own scratch slice)
 //   per level: k_chain_insert, k_chain_count, k_scan_block_sums (clamps to the level capacity),
 //              k_chain_emit2 (also pre-fills the children table up to the live coarse rows),

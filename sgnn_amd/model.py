@@ -12,9 +12,11 @@ and the same module/attribute names, so a reference checkpoint's state_dict load
     the encoder level's existing grid followed by one fused gather+concat;
   * the dense 8^3 bottleneck (model.py:89-136) keeps its nn.Conv3d / BatchNorm3d
     modules as parameter holders (state-dict layout) but executes on the same HIP kernels: a dense volume
-    is a fully-active level, the k4/s2 (transposed) convolutions are rulebooks with 64 offsets, BatchNorm3d
+    is a fully-active level, the k4/s2 (transposed) convolutions are rulebook walks — 64 offsets seen from the
+    coarse side, 8 parity groups of 8 offsets on the coarse level's neighbour table seen from the fine side
+    (functions.DenseK4S2, K4S2_TAPS below) — the 1x1x1 convolutions K = 1 walks on the identity table, BatchNorm3d
     is the row BatchNorm.  (MIOpen fell back to naive 3D kernels here: ~45 % of the step in
-    profiles/r01a_bench_kernel_stats_first.csv.)  Only the 1x1x1 convolutions remain plain rocBLAS GEMMs.
+    profiles/r01a_bench_kernel_stats_first.csv.)
 """
 import os
 

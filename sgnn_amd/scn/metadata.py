@@ -319,7 +319,7 @@ class PendingChain(object):
         arr = lambda ts: np.ascontiguousarray(np.array([t.data_ptr() for t in ts], dtype=np.uint64))
         self._keep = [arr(self.ckeys), arr(self.cvals), arr(self.parent), arr(self.ccoords)]
         if counts is not None:
-            # capacity mode: pyramid AND its children / ptable tables in one submission (5 launches per level + 1)
+            # capacity mode: pyramid AND its children / ptable tables in one submission (3 launches per level + 2)
             assert n0_cnt is not None and level_caps is not None and len(level_caps) >= depth and counts.numel() >= depth
             caps = [min(int(c), cap) for c in level_caps[:depth]]
             caps_np = np.ascontiguousarray(np.array(caps, dtype=np.int64))

@@ -40,7 +40,27 @@ __global__ __launch_bounds__(256) void k_adam_flat(float *__restrict__ p, const 
                                                    AdamArgs a, const float *__restrict__ lr_dev, float beta1,
                                                    float beta2, float eps, float weight_decay, float grad_scale,
                                                    const int32_t *__restrict__ status) {
-  if (status && (*status & SGNN_STATUS_OVERFLOW)) return;
+  if (status && (*status & SGNN_STATUS_OVERFLOW)) return;      // (uniform over the launch: no barrier is skipped by a part of it)
+  // the bias corrections depend on the segment only: one thread per segment forms them for the workgroup (round 5: the two
+  // double-precision pow() per ELEMENT were most of this kernel — 19 us for 2.6 MB of parameters, on the serial tail of the step)
+  __shared__ float s_bc1[ADAM_MAX_SEG], s_bc2s[ADAM_MAX_SEG];
+  __shared__ int s_on[ADAM_MAX_SEG];
+  if (threadIdx.x < ADAM_MAX_SEG) {
+    const int t = threadIdx.x;
+    float b1 = 1.f, b2 = 1.f;
+    int on = 0;
+    if (t < a.nseg) {
+      on = seg_active(a.seg[t]) ? 1 : 0;
+      // the counter still holds the number of PREVIOUS updates (k_adam_steps bumps it after this kernel)
+      const double step = (double)(*a.seg[t].step) + 1.0;
+      b1 = (float)(1.0 - pow((double)beta1, step));
+      b2 = sqrtf((float)(1.0 - pow((double)beta2, step)));
+    }
+    s_bc1[t] = b1;
+    s_bc2s[t] = b2;
+    s_on[t] = on;
+  }
+  __syncthreads();
   const float lr = *lr_dev;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
@@ -52,11 +72,9 @@ __global__ __launch_bounds__(256) void k_adam_flat(float *__restrict__ p, const 
 #pragma unroll
       for (int t = 0; t < ADAM_MAX_SEG; ++t)
         if (t < a.nseg && i >= a.seg[t].begin && i < a.seg[t].end) si = t;
-      if (si < 0 || !seg_active(a.seg[si])) continue;
-      // the counter still holds the number of PREVIOUS updates (k_adam_steps bumps it after this kernel)
-      const double step = (double)(*a.seg[si].step) + 1.0;
-      const float bc1 = (float)(1.0 - pow((double)beta1, step));
-      const float bc2s = sqrtf((float)(1.0 - pow((double)beta2, step)));
+      if (si < 0 || !s_on[si]) continue;
+      const float bc1 = s_bc1[si];
+      const float bc2s = s_bc2s[si];
       float grad = g[i] * grad_scale;
       float par = p[i];
       if (weight_decay != 0.f) grad += par * weight_decay;

@@ -11,7 +11,10 @@ from . import HBM_PEAK_GBS, FP32_MFMA_PEAK_TF
 def conv_alg_bytes(kind, n_out, cin, cout, K):
     """Algorithmic HBM bytes of one conv launch: feature slab read once, output written once, the
     K x n_out int32 rule table, the weights.  The weight gradient reads x and dy and writes K*cin*cout: the same count."""
-    return 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
+    b = 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
+    if kind == 2:      # fused backward (csrc/conv_bwd_fused.hip): dy read, dx written, + the layer's input rows read, dW written
+        b += 4 * n_out * cout + 4 * K * cin * cout
+    return b
 
 
 def collect_prof(lib, valid_ratio=None, row_map=None):
@@ -38,7 +41,7 @@ def collect_prof(lib, valid_ratio=None, row_map=None):
         # ratio is not measured: left at 1, as before (an upper bound of the coarse-row count it is quoted on).
         ratio = valid_ratio.get((n_out.value, K.value), 1.0)
         assert 0.0 <= ratio <= 1.0 + 1e-9, 'more rules than table entries: %r' % ((n_out.value, K.value, ratio),)
-        fl_exec = 2.0 * live * K.value * cin.value * cout.value
+        fl_exec = 2.0 * live * K.value * cin.value * cout.value * (2 if kind.value == 2 else 1)   # kind 2: both products
         fl = fl_exec * ratio
         a['launches'] += 1
         a['ms'] += ms.value
@@ -53,7 +56,7 @@ def collect_prof(lib, valid_ratio=None, row_map=None):
         b['ms'] += ms.value
         # forward launches and data-gradient launches (SGNN_CONV_TRANSPOSE_W) of the same kernel, kept apart: the fused
         # backward epilogue once made the latter 25-45 % slower — this keeps the ratio visible
-        d = 'dx' if (kind.value == 0 and (flags.value & 1)) else 'fwd'
+        d = 'dx' if (kind.value in (0, 2) and (flags.value & 1)) else 'fwd'
         b['n_' + d] += 1
         b['ms_' + d] += ms.value
         b['flops'] += fl
@@ -133,7 +136,7 @@ def algorithmic_step(model, agg, n_prof_steps, row_map):
 
 
 def kernel_name(key):
-    return '%s<%d,%d>K%d' % ('conv_fwd' if key[0] == 0 else 'conv_dw', key[1], key[2], key[3])
+    return '%s<%d,%d>K%d' % ({0: 'conv_fwd', 1: 'conv_dw', 2: 'conv_bwd_fused'}[key[0]], key[1], key[2], key[3])
 
 
 def class_record(key, a):

@@ -261,6 +261,28 @@ int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy,
                          const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift, void *ws,
                          int64_t ws_bytes, sgnn_stream_t stream);
 
+/* Backward of a 3x3x3 SubmanifoldConvolution as ONE launch (round 6): data gradient and weight gradient from a single
+ * gather of dy (torch/model.py:38,40,180,255 under train.py:262).  dy: (n, cout) rows with stride ld_dy; x: the layer's input
+ * rows (n, cin), stride ldx; w: (27, cin, cout); table / ld: the level's neighbour table (sgnn_rulebook_subm3*);
+ * dx: (n, cin) rows with stride ld_dx = sum_k dy[table[k][i]] W[26 - k]^T, with the epilogue options of sgnn_conv_fwd_epi
+ * (addend, which may alias dx; stats = 2: BatchNorm-backward statistics partials, sgnn_conv_stats_blocks(n) x 2 x cin doubles);
+ * dw: (27, cin, cout) = what sgnn_conv_bwd_weight returns (another fixed summation order), through per-workgroup partials in
+ * ws (sgnn_conv_bwd_fused_ws_bytes) and the library's fixed-order reduce.  dx rows are bit-identical to
+ * sgnn_conv_fwd_epi(flags = TRANSPOSE_W | FLIP_K).  Served shapes: sgnn_conv_bwd_fused_supported (cin = cout = 16, K = 27,
+ * levels of at least sgnn_conv_set_bwd_fused_rows rows, default 40 960); others return SGNN_EINVAL.  Row strides multiples of
+ * 4 floats, bases 16-byte aligned.  n_dev: capacity mode (NULL = n is exact).  sgnn_conv_set_bwd_fused(1) makes
+ * sgnn_prog_backward use it (default 0: stand-alone it is 0.95x the two kernels it replaces, beside the weight-gradient
+ * lane's kernels it loses — profiles/r06_fused_backward.txt); set it before the first step (workspace sizes follow it). */
+int64_t sgnn_conv_bwd_fused_ws_bytes(int64_t n, int cin, int cout);
+int sgnn_conv_bwd_fused_supported(int64_t n, int cin, int cout, int K);
+int sgnn_conv_set_bwd_fused(int on);
+int64_t sgnn_conv_set_bwd_fused_rows(int64_t rows);
+int sgnn_conv_bwd_fused(const float *dy, int64_t n, int cout, int64_t ld_dy, const float *x, int cin, int64_t ldx,
+                        const float *w, const int32_t *table, int64_t ld, float *dx, int64_t ld_dx, const float *addend,
+                        int64_t ld_add, int stats, double *partial, const float *bn_x, int64_t ld_bnx, const float *mean,
+                        const float *invstd, const float *gamma, const float *beta, float leak, float *dw, void *ws,
+                        int64_t ws_bytes, const int64_t *n_dev, sgnn_stream_t stream);
+
 /* pre-summed weights of the generative up-sampling convolution and their gradient: Wc (64, cin, cout) from the layer's
  * W (27, cin, cout); dW from dWc (see sgnn_conv_fwd_ex) */
 int sgnn_expand_weights(const float *w, int cin, int cout, float *wc, sgnn_stream_t stream);
@@ -561,7 +583,6 @@ int sgnn_prog_set_side_stream(sgnn_stream_t stream2, void *ws2, int64_t ws2_byte
  * gradient — its first, widest convolution — otherwise holds up the next program's dependent chain for as long as it runs.
  * Returns the previous setting. */
 int sgnn_prog_defer_join(int on);
-
 /* ---------------------------------------------------------------------------
  * Optimizer step (torch/train.py:81 optim.Adam, :264 optimizer.step()) as one launch over flat buffers of all n
  * parameters.  seg: HOST array of nseg (<= 8) x 5 int64 = {begin, end, cnt, flag, step}: elements [begin, end) are

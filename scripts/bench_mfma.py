@@ -22,3 +22,36 @@ for mode, what in ((0, '8 independent accumulators'), (1, 'one accumulator (depe
         per_simd = cus * 4
         ghz = n / per_simd * 32 / ms / 1e6               # if the pipe were never idle
         print('%-36s %d waves/SIMD  %7.2f ms  %6.1f TFLOP/s  -> %.2f GHz x 32 cycles/MFMA' % (what, wgs_per_cu, ms, tf, ghz))
+
+# round 6: does the rate depend on the operand VALUES?  16 different operand pairs per iteration, four accumulators
+lib.mfma_peak_data.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+torch.manual_seed(0)
+for what, data, zero in (('random normal operands', torch.randn(32 * 256, device='cuda'), 0),
+                         ('small-magnitude operands (1e-3 * normal)', torch.randn(32 * 256, device='cuda') * 1e-3, 0),
+                         ('operands = 1.0', torch.ones(32 * 256, device='cuda'), 0),
+                         ('operands = 0.0', torch.zeros(32 * 256, device='cuda'), 1)):
+    for wgs_per_cu in (1, 2, 4):
+        blocks, iters = cus * wgs_per_cu, 20000 // wgs_per_cu
+        lib.mfma_peak_data(out.data_ptr(), data.data_ptr(), zero, blocks, 100, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); lib.mfma_peak_data(out.data_ptr(), data.data_ptr(), zero, blocks, iters, st); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        n = blocks * 4 * iters * 16
+        print('%-42s %d waves/SIMD  %7.2f ms  %6.1f TFLOP/s  -> %.2f GHz x 32 cycles/MFMA'
+              % (what, wgs_per_cu, ms, n * 2048 / ms / 1e9, n / (cus * 4) * 32 / ms / 1e6))
+
+# round 6: the MFMA stream of the fused backward kernel's offset walk, looped (small code) and unrolled over 27 offsets
+lib.mfma_peak_stage.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+data = torch.randn(64 * 256, device='cuda')
+for nk in (1, 27):
+    for wgs_per_cu in (1, 2):
+        blocks, iters = cus * wgs_per_cu, (27 * 400 // nk) // wgs_per_cu
+        lib.mfma_peak_stage(out.data_ptr(), data.data_ptr(), nk, blocks, 2, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); lib.mfma_peak_stage(out.data_ptr(), data.data_ptr(), nk, blocks, iters, st); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        n = blocks * 4 * iters * nk * 32
+        print('fused-backward stage stream, %2d offsets unrolled   %d waves/SIMD  %7.2f ms  %6.1f TFLOP/s  -> %.2f GHz x 32 cycles/MFMA'
+              % (nk, wgs_per_cu, ms, n * 2048 / ms / 1e9, n / (cus * 4) * 32 / ms / 1e6))

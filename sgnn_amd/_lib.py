@@ -52,6 +52,11 @@ PROTOTYPES = {
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'sgnn_conv_bwd_fused_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
+    'sgnn_conv_bwd_fused_supported': (c_i32, [c_i64, c_i32, c_i32, c_i32]),
+    'sgnn_conv_set_bwd_fused': (c_i32, [c_i32]),
+    'sgnn_conv_set_bwd_fused_rows': (c_i64, [c_i64]),
+    'sgnn_conv_bwd_fused': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),
     'sgnn_bn_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'sgnn_bn_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

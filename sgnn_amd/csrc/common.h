@@ -122,6 +122,14 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
                               int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr,
                               const BnPre *pre = nullptr);
+// conv_bwd_fused.hip: data gradient + weight gradient of a 3x3x3 submanifold layer from one gather of dy
+bool sgnn_conv_bwd_fused_ok(int64_t n, int cin, int cout, int K);
+bool sgnn_conv_bwd_fused_usable(int64_t n, int cin, int cout, int K, const ConvEpi &epi, const float *dx, const float *x,
+                                int64_t ldx);
+int64_t sgnn_conv_bwd_fused_ws(int64_t n, int cin, int cout);
+int sgnn_conv_bwd_fused_impl(const float *dy, int64_t n, int cout, const float *w, const int32_t *table, int64_t ld, int cin,
+                             float *dx, const ConvEpi &epi, const float *x, int64_t ldx, float *dw, void *ws, int64_t ws_bytes,
+                             sgnn_stream_t stream);
 int sgnn_expand_maps(const int32_t **S, const int32_t **ST, const int32_t **PAR);
 // linear.hip: heads whose weight rows / biases are separate tensors
 int sgnn_linear_fwd_rows(const float *x, int64_t n, int cin, const float *const *w, const float *const *b, int cout,

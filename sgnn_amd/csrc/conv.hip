@@ -1357,6 +1357,18 @@ int sgnn_dw_batch_flush(DwBatch *b, hipStream_t s) {
   return SGNN_OK;
 }
 
+// conv_bwd_fused.hip: the reduce of a fused backward launch's workgroup partials — deferred into the program's batch like
+// every other weight gradient of the call, or launched at once
+int sgnn_dw_reduce_or_defer(const float *partial, float *dw, int64_t nblk, int64_t elems, hipStream_t s) {
+  if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {
+    sgnn_dw_batch->d[sgnn_dw_batch->n++] = DwDesc{partial, dw, nblk, elems, 0};
+    return SGNN_OK;
+  }
+  SGNN_LAUNCH(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, partial, nblk, elems, dw);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
 // generic fallback: one workgroup per (k, ci, co) triple would be wasteful; instead one thread per
 // weight element loops over all rows (slow, correctness only)
 __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict__ x, int cin,

@@ -387,7 +387,14 @@ inline int64_t expand_dwc_bytes(int cin, int cout) { return (64 * (int64_t)cin *
 int64_t dw_slice(const View &v, int i) {   // workspace slice of op i's weight-gradient partials (256-byte multiple)
   const int32_t *o = v.ops + OPW * i;
   int64_t w = 0;
-  if (o[0] == OP_CONV_SUBM) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
+  if (o[0] == OP_CONV_SUBM) {
+    w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5]], 27, o[6], o[7]);
+    // the fused backward kernel keeps one partial per resident workgroup (conv_bwd_fused.hip)
+    if (sgnn_conv_bwd_fused_ok(v.lev_n[o[5]], o[6], o[7], 27)) {
+      const int64_t wf = sgnn_conv_bwd_fused_ws(v.lev_n[o[5]], o[6], o[7]);
+      if (wf > w) w = wf;
+    }
+  }
   if (o[0] == OP_CONV_DOWN) w = sgnn_conv_bwd_weight_ws_bytes(v.lev_n[o[5] + 1], 8, o[6], o[7]);
   if (o[0] == OP_EXPAND)   // partials + the 64 reduced slices themselves (they must not live in the shared gradient arena:
                            // with a deferred lane join the next program's backward pass would overwrite them)
@@ -786,7 +793,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   std::unique_lock<std::mutex> lane_lock(g_side_mu, std::try_to_lock);
   const bool side = lane_lock.owns_lock() && g_side.stream && g_side.stream != hs && g_side.ws &&
                     g_side.ws_bytes >= dw_ws_need(v);
-  bool forked = false;
+  bool forked = false, fused_any = false;
   auto dw_lane = [&]() -> hipStream_t {
     if (!side) return hs;
     (void)hipEventRecord(g_side.fork, hs);                 // dy of this op is final here (all its consumers ran)
@@ -841,7 +848,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         const int64_t ld_f = down ? lev_ld[lev + 1] : lev_ld[lev];
         const int32_t *tab_b = (const int32_t *)(down ? lev_ptable[lev] : lev_nbr[lev]);
         const int flags_b = down ? SGNN_CONV_TRANSPOSE_W : (SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K);
-        const hipStream_t lane = dw_lane();
+        // dX and dW from ONE kernel on the training stream where the shape allows (conv_bwd_fused.hip): no lane fork.  Otherwise
+        // the lane forks HERE, in front of the data-gradient launch: the weight gradient runs beside the dX kernel of its layer
+        bool fused_bwd = false;
+        const bool fused_try = !down && wants(in0) && g_fuse && n > 0 && !(fold == 1 && PL.pre_bn[i] >= 0) &&
+                               sgnn_conv_epi_supported(cout, cin) && sgnn_conv_bwd_fused_ok(n, cin, cout, K);
+        hipStream_t lane = fused_try ? hs : dw_lane();
         if (wants(in0)) {
           if (g_fuse && sgnn_conv_epi_supported(cout, cin) && n > 0) {
             // the data gradient lands in G(in0) directly: what the buffer (or its alias) already holds is added in the
@@ -870,8 +882,15 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             epi.ldx = ld_dy;
             epi.ldy = LD(in0);
             epi.n_dev = CNT(lev);
-            PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
-                                        nullptr, 1, 1, K, &epi, stream));
+            fused_bwd = fused_try && sgnn_conv_bwd_fused_usable(n, cin, cout, K, epi, G(in0), X(in0), LD(in0));
+            if (fused_bwd) {
+              PROG_TRY(sgnn_conv_bwd_fused_impl(dy, n, cout, P(par), tab_b, lev_ld[lev], cin, G(in0), epi, X(in0), LD(in0),
+                                                PG(par), dw_base + dw_off, dw_slice(v, i), stream));
+              fused_any = true;
+            } else {
+              PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
+                                          nullptr, 1, 1, K, &epi, stream));
+            }
             init[in0] = 1;
             alias[in0] = -1;
           } else {
@@ -884,7 +903,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             PROG_TRY(commit(in0, t));
           }
         }
-        {
+        if (!fused_bwd) {
+          if (fused_try) lane = dw_lane();      // (strides the fused kernel does not take: fork late)
           const float *xw = X(in0);
           int64_t ldxw = LD(in0);
           BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
@@ -1077,6 +1097,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       PROG_TRY(sgnn_fill32(G(b), 0u, L.buf_floats[b], hs));
   }
   {
+    if (side && fused_any) (void)dw_lane();           // the lane's reduce also reads partials the training stream wrote
     const hipStream_t lane = side ? g_side.stream : hs;
     PROG_TRY(sgnn_dw_batch_flush(&batch, lane));      // all deferred weight-gradient reduces: one launch
     for (const PendingExpand &pe : pending_expand)

@@ -85,16 +85,81 @@ int sgnn_hash_lookup(const uint64_t *keys, const int32_t *vals, int64_t cap, con
                      int64_t m, int32_t *rows, const int64_t *m_dev, sgnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Measurement switches: ONE table.  Every kernel variant / launch fusion that was ever A/B-measured is selected by a field of
+ * this struct; defaults are the measured winners.  No field changes results beyond fp32 / fp64 summation order (each entry
+ * says what stays bit-identical).  No reference counterpart.  Set by name: sgnn_tune_set("conv_wide_epi", 0) returns the
+ * previous value, SGNN_TUNE_UNKNOWN (with sgnn_last_error) for an unknown name or a value out of range; sgnn_tune_get reads;
+ * sgnn_tune_names = the comma-separated field names; sgnn_tune_current = the live table (read-only).  Process-global, not
+ * thread-safe: set them before the work they steer (workspace sizes follow conv_bwd_fused / conv_bwd_fused_rows).
+ * Host layer: sgnn_amd._lib.tune(name, value); environment SGNN_TUNE="name=value,name=value" at load.
+ * ------------------------------------------------------------------------- */
+#define SGNN_TUNE_UNKNOWN INT64_MIN
+typedef struct sgnn_tune {
+  /* levels below conv_small_rows run a latency-oriented kernel (16 rows per workgroup, the four waves split the offsets);
+   * 0 = the 64-row variant of the big kernel.  The two sum the offsets in different orders (fp32 round-off).  Default 1. */
+  int64_t conv_small;
+  /* row count below which the small-level kernel is used.  Default 40 960. */
+  int64_t conv_small_rows;
+  /* levels above that run the wide-row 27-offset layers and every 8-offset walk as straight-line code (conv_unrolled.hip:
+   * exact s_waitcnt counts, rule entries loaded up front); 0 = the looped kernel everywhere.  Bit-identical.  Default 1. */
+  int64_t conv_unrolled;
+  /* large levels: every workgroup of the rulebook walk takes as many consecutive 256-row tiles as it needs for ALL live
+   * workgroups to be resident at once (no partial second round); 0 = one tile per workgroup.  Rows bit-identical; BatchNorm
+   * statistics partials are summed per workgroup, so their fp64 grouping differs.  The tile count follows the workgroups of
+   * the kernel the DEVICE holds at once (occupancy x compute units, queried per device on first use): statistics are
+   * bit-reproducible for a given device model, driver and compiler, not across them.  Default 1. */
+  int64_t conv_one_round;
+  /* epilogue of the 256-row walk for output rows of 8 / 12 / 16 channels (torch/model.py:38-42, 180, 255, forward and data
+   * gradient): 1 = the tile leaves the MFMA layout through a quad transpose, so the residual addend, the BatchNorm input of
+   * the backward statistics and the output rows move as row-contiguous 16-byte accesses; 0 = one 4-byte access per
+   * accumulator element.  Used when every row stride is a multiple of 4 floats and the bases are 16-byte aligned.  Stored
+   * rows AND statistics partials bit-identical.  Default 1. */
+  int64_t conv_wide_epi;
+  /* row blocks a weight-gradient launch aims for (1 .. 4096; the launch is row blocks x offset groups workgroups).  Same
+   * per-block sums in the same order for a given setting; the blocks' partial sums are added in block order.  Default 256. */
+  int64_t conv_dw_blocks;
+  /* weight gradient of a one-channel input (1 -> 8, the network's first convolution): 1 = the register-accumulating VALU
+   * kernel, 0 = the MFMA kernel of the other shapes.  Different summation order (fp32 round-off).  Default 1. */
+  int64_t conv_dw_c1;
+  /* 1 = sgnn_prog_backward runs 16-channel 3x3x3 layers on levels of >= conv_bwd_fused_rows rows through the fused backward
+   * kernel (sgnn_conv_bwd_fused: dX and dW from one gather of dy).  dX rows bit-identical, dW another fixed summation
+   * order.  Default 0: 0.95x the two kernels stand-alone, slower in the step (profiles/r06_fused_backward.txt). */
+  int64_t conv_bwd_fused;
+  int64_t conv_bwd_fused_rows;   /* >= 256.  Default 40 960. */
+  /* 1 = the 3x3x3 rulebook builder hashes the voxel index of a 768-row window around each 256-row tile into LDS (global
+   * table only for neighbours not found there); 0 = the global-probe kernel, faster on MI355X (96.7 vs 123.9 us at N =
+   * 366 k).  Identical tables.  Default 0. */
+  int64_t rulebook_lds;
+  /* compactions / stride-2 levels: 1 = the write kernels sum the (<= 4096) raw block counts themselves, 0 = a scan launch
+   * between the count and the write kernel.  Identical results.  Default 1. */
+  int64_t scan_inline;
+  /* sgnn_down2_chain_tables: 1 = the tables pass of level l and the hash insertion of level l + 1 in one launch.
+   * Identical results.  Default 1. */
+  int64_t chain_merged;
+  /* sgnn_prog_forward / _backward: 0 switches the epilogue fusions off (conv -> AddTable, conv -> BatchNorm statistics,
+   * in-place JoinTable): the per-layer launch sequence, identical arithmetic.  Default 1. */
+  int64_t prog_fusion;
+  /* a per-site linear head that is the only reader of a BatchNormReLU (the surface head): 1 = its data gradient dy w is
+   * formed inside the two BatchNorm backward passes instead of being written and read back (bit-identical values); 0 =
+   * k_linear_bwd writes it.  Applies to programs planned after the change.  Default 1. */
+  int64_t prog_lin_bn;
+  /* a per-site linear head whose input rows already carry a gradient when its backward pass runs (a Refinement's two heads,
+   * torch/model.py:230-243): 1 = the head's kernel writes dy w + that gradient in one pass; 0 = an add launch over the level
+   * follows.  Same sums (one fp32 addition per element either way).  Default 1. */
+  int64_t prog_lin_add;
+} sgnn_tune;
+int64_t sgnn_tune_set(const char *name, int64_t value);
+int64_t sgnn_tune_get(const char *name);
+const char *sgnn_tune_names(void);
+const sgnn_tune *sgnn_tune_current(void);
+
+/* ---------------------------------------------------------------------------
  * Rulebooks
  * ------------------------------------------------------------------------- */
 
 /* 3x3x3 submanifold rulebook (scn.SubmanifoldConvolution, torch/model.py:32,38,40,179,186,254):
  * nbr[k*ld + j] = row of the site at p_j + d_k, k = (dz+1)*9+(dy+1)*3+(dx+1), else -1.
  * ld >= n; entries j in [n, ld) are written as -1. */
-/* 1 selects the LDS-window builder (voxel index of a 768-row window around each 256-row tile hashed into LDS, global
- * table only for neighbours not found there); default 0 = the global-probe kernel, which measured faster on MI355X
- * (96.7 vs 123.9 us at N = 366 k).  Both produce identical tables.  Returns the previous setting. */
-int sgnn_rulebook_set_lds(int on);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         const int64_t *n_dev, sgnn_stream_t stream);
@@ -155,7 +220,7 @@ int sgnn_down2_chain(const int32_t *fine_coords, int64_t n0, const int64_t *n0_d
 /* Capacity mode: the pyramid AND its tables in one submission — sgnn_down2_chain (row counts from *n0_dev, clamped to
  * level_caps, SGNN_STATUS_OVERFLOW) followed by sgnn_down2_tables of every level, as 3 launches per level + 2 (round 5: insert,
  * count, write kernel; the tables pass of a level shares a launch with the next level's insertion; 5 per level + 1 with
- * sgnn_scan_set_inline(0) / sgnn_chain_set_merged(0)) instead of 8 per level.  children[l] is (8 x ldc_l), ldc_l = roundup256(min(level_caps[l], cap)); ptable[l] is (8 x ldf_l),
+ * sgnn_tune.scan_inline = 0 / chain_merged = 0) instead of 8 per level.  children[l] is (8 x ldc_l), ldc_l = roundup256(min(level_caps[l], cap)); ptable[l] is (8 x ldf_l),
  * ldf_0 = roundup256(cap), ldf_l = ldc_{l-1}.  Only rows below roundup256(live count) of a table are written (and read). */
 int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth);
 int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_t *n0_dev, int64_t cap, int depth,
@@ -217,37 +282,6 @@ int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, const float *
  * partial holds sgnn_conv_stats_blocks(n_out) * 2 * cout doubles; sgnn_bn_fwd_ex / sgnn_bn_bwd_ex accept it as
  * pre_partial.  Only for the compiled (cin, cout) shapes; SGNN_EINVAL otherwise. */
 int64_t sgnn_conv_stats_blocks(int64_t n_out);
-/* levels below ~40 k rows run a latency-oriented kernel (16 rows per workgroup, the four waves split the offsets);
- * 0 switches back to the 64-row variant of the big kernel (A/B measurements).  Returns the previous setting. */
-int sgnn_conv_set_small(int on);
-/* row count below which the small-level kernel is used (default ~41 k); returns the previous threshold */
-int64_t sgnn_conv_set_small_rows(int64_t rows);
-/* levels above that threshold run the plain rulebook walk (K = 27 / 8) as straight-line code (conv_unrolled.hip: exact
- * s_waitcnt counts, rule entries loaded up front); 0 = the looped kernel everywhere (A/B measurements).  Same arithmetic and
- * summation order: bit-identical results.  Returns the previous setting. */
-int sgnn_conv_set_unrolled(int on);
-/* row blocks a weight-gradient launch aims for (default 256; the launch is row blocks x offset groups workgroups, every
- * workgroup walks its rows in 256-row rounds).  Same per-block sums in the same order for a given setting; the partial sums
- * of the blocks are added in block order.  Returns the previous setting. */
-int sgnn_conv_set_dw_blocks(int blocks);
-/* weight gradient of a one-channel input (1 -> 8, the network's first convolution): 1 (default) = the register-accumulating
- * VALU kernel, 0 = the MFMA kernel of the other shapes.  Different summation order (fp32 round-off).  Returns the previous setting. */
-int sgnn_conv_set_dw_c1(int on);
-/* large levels: every workgroup of the rulebook walk takes as many consecutive 256-row tiles as it needs for ALL live
- * workgroups to be resident at once (no partial second round of workgroups; default on).  0 = one tile per workgroup.
- * Outputs are bit-identical either way; BatchNorm statistics partials are summed per workgroup, so their grouping
- * (fp64) differs.  The tile count per workgroup follows the number of workgroups of the kernel the DEVICE holds at once
- * (occupancy x compute units, queried per device on first use): statistics are bit-reproducible for a given device model,
- * driver and compiler, not across them.  Returns the previous setting. */
-int sgnn_conv_set_one_round(int on);
-/* epilogue of the 256-row rulebook walk for output rows of 8 / 12 / 16 channels (every FullyConvolutionalNet layer,
- * torch/model.py:38-42, 180, 255, forward and data gradient): 1 (default) = the tile leaves the MFMA layout through a
- * quad transpose, so the residual addend, the BatchNorm input of the backward statistics and the output rows move as
- * row-contiguous 16-byte accesses, the operand loads issued under the last offset of the tile; 0 = one 4-byte access
- * per accumulator element.  Used when every row stride involved is a multiple of 4 floats and the bases are 16-byte
- * aligned (otherwise the element-wise form runs).  Stored rows are bit-identical; the fp64 statistics partials are
- * summed in another fixed order.  Returns the previous setting. */
-int sgnn_conv_set_wide_epi(int on);
 int sgnn_conv_fwd_epi(const float *x, int64_t n_in, int cin, int64_t ldx, const float *w, int K,
                       const int32_t *table, int64_t ld, int64_t n_out, int cout, float *y, int64_t ldy, int flags,
                       const float *addend, int64_t ld_add, int stats, double *partial, const float *bn_x,
@@ -269,14 +303,12 @@ int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy,
  * dw: (27, cin, cout) = what sgnn_conv_bwd_weight returns (another fixed summation order), through per-workgroup partials in
  * ws (sgnn_conv_bwd_fused_ws_bytes) and the library's fixed-order reduce.  dx rows are bit-identical to
  * sgnn_conv_fwd_epi(flags = TRANSPOSE_W | FLIP_K).  Served shapes: sgnn_conv_bwd_fused_supported (cin = cout = 16, K = 27,
- * levels of at least sgnn_conv_set_bwd_fused_rows rows, default 40 960); others return SGNN_EINVAL.  Row strides multiples of
- * 4 floats, bases 16-byte aligned.  n_dev: capacity mode (NULL = n is exact).  sgnn_conv_set_bwd_fused(1) makes
+ * levels of at least sgnn_tune.conv_bwd_fused_rows rows, default 40 960); others return SGNN_EINVAL.  Row strides multiples of
+ * 4 floats, bases 16-byte aligned.  n_dev: capacity mode (NULL = n is exact).  sgnn_tune.conv_bwd_fused = 1 makes
  * sgnn_prog_backward use it (default 0: stand-alone it is 0.95x the two kernels it replaces, beside the weight-gradient
  * lane's kernels it loses — profiles/r06_fused_backward.txt); set it before the first step (workspace sizes follow it). */
 int64_t sgnn_conv_bwd_fused_ws_bytes(int64_t n, int cin, int cout);
 int sgnn_conv_bwd_fused_supported(int64_t n, int cin, int cout, int K);
-int sgnn_conv_set_bwd_fused(int on);
-int64_t sgnn_conv_set_bwd_fused_rows(int64_t rows);
 int sgnn_conv_bwd_fused(const float *dy, int64_t n, int cout, int64_t ld_dy, const float *x, int cin, int64_t ldx,
                         const float *w, const int32_t *table, int64_t ld, float *dx, int64_t ld_dx, const float *addend,
                         int64_t ld_add, int stats, double *partial, const float *bn_x, int64_t ld_bnx, const float *mean,
@@ -406,12 +438,6 @@ int sgnn_compact_sigmoid_cap_locs(const float *logits, int64_t stride, int64_t n
 int sgnn_compact_dense_cap_locs(const int32_t *coords, int64_t n, const int64_t *n_dev, const float *vol, int batch, int d0,
                                 int d1, int d2, int32_t *sel, int32_t *locs, int64_t *count2, int64_t keep_cap,
                                 int32_t *status, void *ws, int64_t ws_bytes, sgnn_stream_t stream);
-/* A/B switches of the compaction / stride-2 pipelines (defaults 1; identical results; return the previous setting):
- * sgnn_scan_set_inline — the write kernels sum the (<= 4096) raw block counts themselves instead of a scan launch between
- * the count and the write kernel; sgnn_chain_set_merged — sgnn_down2_chain_tables runs the tables pass of level l and the
- * hash insertion of level l + 1 in one launch */
-int sgnn_scan_set_inline(int on);
-int sgnn_chain_set_merged(int on);
 
 /* scn.SparseToDense (torch/model.py:47): dense (B, C, d0, d1, d2) zero-filled here */
 int sgnn_sparse_to_dense(const float *feats, const int32_t *coords, int64_t n, int c, float *dense,
@@ -515,33 +541,8 @@ int sgnn_loss_levels_bwd(const int64_t *levels, int n, const float *coef_host, c
  * materialises the convolution's own output buffer unless it is flagged; a JoinTable whose inputs can be produced in
  * place gets no copy (its inputs live in column ranges of the join buffer and are read / written through a row
  * stride).  The same `keep` must be passed to the arena / offset queries and to the backward call (the layout depends
- * on it).  sgnn_prog_set_fusion(0) switches the fusions off (A/B measurements, parity tests); it returns the previous
- * setting.
+ * on it).  sgnn_tune.prog_fusion = 0 switches the fusions off (A/B measurements, parity tests).
  * ------------------------------------------------------------------------- */
-int sgnn_prog_set_fusion(int on);
-/* a per-site linear head that is the only reader of a BatchNormReLU (the surface head): 1 (default) = its data gradient
- * dy w is formed inside the two BatchNorm backward passes instead of being written and read back (bit-identical values);
- * 0 = k_linear_bwd writes it.  Applies to programs planned after the call.  Returns the previous setting. */
-int sgnn_prog_set_lin_bn(int on);
-/* a per-site linear head whose input rows already carry a gradient when its backward pass runs (a Refinement's two heads: the
- * rows the next level reads brought theirs, torch/model.py:230-243): 1 (default) = the head's kernel writes dy w + that
- * gradient in one pass; 0 = it writes dy w and an add launch over the level follows.  Same sums (one fp32 addition per
- * element either way).  Returns the previous setting. */
-int sgnn_prog_set_lin_add(int on);
-/* BatchNormReLU -> convolution (torch/model.py:37-42, 181, 187, 256: every scn.BatchNormReLU in front of a
- * SubmanifoldConvolution / Convolution).  sgnn_prog_set_bn_fold(1): when the convolution is the only reader of the
- * BatchNorm output, the executor launches no apply pass — the convolution (forward, and its weight gradient in backward)
- * reads the BatchNorm's INPUT rows and applies (x - mean) * invstd * gamma + beta and the ReLU in its gather, rows of missing
- * rules staying zero.  2 = the exact A/B reference of 1: the same statistics (finalised by the same kernel), an apply pass
- * and the convolution on the stored rows — bit-identical results.  0 (DEFAULT) = every BatchNorm applies itself (on small
- * levels its apply kernel also finalises the statistics).  The fold is built and tested but measured neutral (it moves an
- * HBM streaming pass into the VALU work of two gather-bound kernels), hence not the default.
- * A training forward call remembers the setting (and the rows threshold below) it ran with under its arena's address and
- * the backward call of that arena uses the remembered one: flipping the switch between a forward pass and its backward
- * pass cannot desynchronise the pair.  Returns the previous setting. */
-int sgnn_prog_set_bn_fold(int on);
-/* rows class size from which the fold applies (default 0 = every level); returns the previous value */
-int64_t sgnn_prog_set_bn_fold_rows(int64_t rows);
 /* mode 0: floats of the gradient arena sgnn_prog_backward needs (buffers + per-op areas + backward scratch);
  * mode 1: floats of the arena sgnn_prog_forward needs (buffers + per-op areas);
  * mode 2: the same for an INFERENCE call (sgnn_prog_forward with training = 2): no backward pass may follow, so a

@@ -1,5 +1,5 @@
 # same-box comparison of several settings of one environment switch on the working tree, two interleaved rounds:
-#   scripts/ab_env_n.sh VAR V1 V2 [V3 ...]      e.g.  scripts/ab_env_n.sh SGNN_TUNE sgnn_conv_set_dw_blocks=256 sgnn_conv_set_dw_blocks=128
+#   scripts/ab_env_n.sh VAR V1 V2 [V3 ...]      e.g.  scripts/ab_env_n.sh SGNN_TUNE conv_dw_blocks=256 conv_dw_blocks=128
 # prints: setting, blocks/s, ms/step, library launches per step, convolution ms per step (HIP events, eager roofline leg)
 VAR=$1; shift
 for round in 1 2; do

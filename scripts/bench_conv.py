@@ -43,11 +43,11 @@ lib = _lib.load()
 nbr = torch.empty(27 * g.ld, dtype=torch.int32, device=dev)
 keys, vals, cap = g.hash()
 for on in (1, 0):
-    lib.sgnn_rulebook_set_lds(on)
+    _lib.tune('rulebook_lds', on)
     us = timeit(lambda: _lib.call('sgnn_rulebook_subm3', keys.data_ptr(), vals.data_ptr(), cap, g.coords.data_ptr(), g.n,
                                   nbr.data_ptr(), g.ld, None), 20)
     print('rulebook_subm3 (%s): %.1f us  (%.1f GB/s on 16N+108N bytes)' % ('LDS window' if on else 'global probes', us, g.n * 124 / us / 1e3))
-lib.sgnn_rulebook_set_lds(0)
+_lib.tune('rulebook_lds', 0)
 dv = d if args.kind == 'surface' else 2 * d      # children live on the next finer lattice
 vol = torch.full((dv ** 3 * args.batch,), -1, dtype=torch.int32, device=dev)
 us = timeit(lambda: _lib.call('sgnn_rulebook_subm3_dense', keys.data_ptr(), vals.data_ptr(), cap, g.coords.data_ptr(), g.n,

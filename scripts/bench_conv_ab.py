@@ -43,7 +43,7 @@ for cin, cout in ((16, 16), (8, 8), (12, 12), (26, 16), (16, 26), (48, 16), (16,
     outs = {}
     for flags in (0, 3):     # forward; data gradient (transposed weights, flipped offsets)
         for on in (0, 1):
-            lib.sgnn_conv_set_unrolled(on)
+            _lib.tune('conv_unrolled', on)
             ww = w if flags == 0 else w.transpose(1, 2).contiguous()   # (K, Cout, Cin) of the forward weights
             if flags and cin != cout:
                 continue
@@ -63,11 +63,11 @@ for cin, cout in ((8, 12), (16, 16)):
     w = torch.randn(8, cin, cout, device=dev) * 0.1
     outs = {}
     for on in (0, 1):
-        lib.sgnn_conv_set_unrolled(on)
+        _lib.tune('conv_unrolled', on)
         y = F_.conv_fwd_raw(x, cin, w, 8, d.children, d.ldc, d.coarse.n, cout, 0, 0)
         us = timeit(lambda: F_.conv_fwd_raw(x, cin, w, 8, d.children, d.ldc, d.coarse.n, cout, 0, 0))
         outs[on] = y.clone()
         print('conv_down<%d,%d> K8 (%d -> %d rows)  %-16s %7.1f us' % (cin, cout, g.n, d.coarse.n, 'unrolled kernel' if on else 'looped kernel', us))
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
     print('   bit-identical: True')
-lib.sgnn_conv_set_unrolled(1)
+_lib.tune('conv_unrolled', 1)

@@ -25,7 +25,7 @@ g = Grid(coords_from_locs(data['input'][0], dev))
 tab = g.subm_table()
 n = g.n
 print('sites %d' % n)
-has_switch = hasattr(lib, 'sgnn_conv_set_wide_epi')
+has_switch = hasattr(lib, 'sgnn_tune_set')
 
 
 def timeit(fn, iters=args.iters):
@@ -63,7 +63,7 @@ for c in (16, 8, 12):
 
     for wide in ((0, 1) if has_switch else (None,)):
         if wide is not None:
-            lib.sgnn_conv_set_wide_epi(wide)
+            _lib.tune('conv_wide_epi', wide)
         t = [timeit(lambda: run(0, False, 0)), timeit(lambda: run(0, False, 1)), timeit(lambda: run(FL, False, 0)),
              timeit(lambda: run(FL, True, 2))]
         print('<%d,%d> K27 %-12s fwd plain %6.1f us | fwd+stats %6.1f | dX plain %6.1f | dX+add+stats2 %6.1f   (dX full / fwd+stats = %.2f)'
@@ -71,7 +71,7 @@ for c in (16, 8, 12):
     if has_switch:      # the two epilogues store the same rows and agree on the statistics to summation order
         outs = []
         for wide in (0, 1):
-            lib.sgnn_conv_set_wide_epi(wide)
+            _lib.tune('conv_wide_epi', wide)
             acc2 = torch.full((n, c), 0.5, device=dev)
             part.zero_()
             _lib.call('sgnn_conv_fwd_epi', x.data_ptr(), n, c, 0, w.data_ptr(), 27, tab.data_ptr(), g.ld, n, c,

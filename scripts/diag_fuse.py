@@ -9,7 +9,7 @@ from sgnn_amd.scn import program as P
 lib = _lib.load()
 def run(enabled, fused):
     P.ENABLED = enabled
-    lib.sgnn_prog_set_fusion(int(fused))
+    _lib.tune('prog_fusion', int(fused))
     dims, cfg = (32, 32, 32), 17
     data = synth.make_batch(2, dims, cfg=cfg, occupancy=0.08)
     m = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(True).cuda()

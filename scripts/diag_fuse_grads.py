@@ -6,7 +6,7 @@ from sgnn_amd import synth, _lib, loss as L
 from sgnn_amd.model import GenModel
 lib = _lib.load()
 def run(fused, small=1):
-    lib.sgnn_prog_set_fusion(int(fused)); lib.sgnn_conv_set_small(small)
+    _lib.tune('prog_fusion', int(fused)); _lib.tune('conv_small', small)
     dims, cfg = (32, 32, 32), 17
     data = synth.make_batch(2, dims, cfg=cfg, occupancy=0.08)
     m = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train(True).cuda()

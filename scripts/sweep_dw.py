@@ -1,5 +1,5 @@
 """Weight-gradient kernel on small levels (needs GPU): one offset per workgroup (default below 16 k rows) against the
-9-offsets-per-workgroup layout of the large levels.  <16,16>, K = 27, surface sites; sgnn_conv_set_small(0) = A/B."""
+9-offsets-per-workgroup layout of the large levels.  <16,16>, K = 27, surface sites; sgnn_tune.conv_small(0) = A/B."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from sgnn_amd import synth, _lib
@@ -24,9 +24,9 @@ for batch, dim in ((1, 8), (1, 16), (2, 24), (2, 32), (4, 32), (2, 64), (4, 64))
         args = (x.data_ptr(), g.n, cin, dy.data_ptr(), cout, tab.data_ptr(), g.ld, 27, g.n, dw.data_ptr(), 0, ws.data_ptr(), wsb)
         res = []
         for on in (0, 1):
-            lib.sgnn_conv_set_small(on)
+            _lib.tune('conv_small', on)
             t = timeit(lambda: _lib.call('sgnn_conv_bwd_weight', *args))
             res.append((t, dw.clone()))
-        lib.sgnn_conv_set_small(1)
+        _lib.tune('conv_small', 1)
         print('N %6d <%d,%d>  9 offsets/WG %.1f us   1 offset/WG %.1f us   identical %s' %
               (g.n, cin, cout, res[0][0], res[1][0], bool(torch.equal(res[0][1], res[1][1]))))

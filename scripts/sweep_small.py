@@ -23,8 +23,8 @@ for nb, dim in ((1, 32), (4, 32), (1, 64), (2, 64), (4, 64), (8, 64), (16, 64), 
         args = (x.data_ptr(), g.n, cin, w.data_ptr(), 27, tab.data_ptr(), g.ld, g.n, cout, y.data_ptr(), 0, 0)
         res = []
         for thr in (1 << 30, 0):
-            lib.sgnn_conv_set_small_rows(thr)
+            _lib.tune('conv_small_rows', thr)
             res.append(timeit(lambda: _lib.call('sgnn_conv_fwd', *args)))
-        lib.sgnn_conv_set_small_rows(160 * 256)
+        _lib.tune('conv_small_rows', 160 * 256)
         fl = 2.0 * int((tab.view(27, g.ld)[:, :g.n] >= 0).sum()) * cin * cout
         print('rows %7d <%d,%d>  small %7.1f us (%5.1f TF)   big %7.1f us (%5.1f TF)' % (g.n, cin, cout, res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6))

@@ -19,14 +19,15 @@ PROTOTYPES = {
     'sgnn_last_error': (c_cp, []),
     'sgnn_version': (c_i32, []),
     'sgnn_arch': (c_cp, []),
+    'sgnn_tune_set': (c_i64, [c_cp, c_i64]),
+    'sgnn_tune_get': (c_i64, [c_cp]),
+    'sgnn_tune_names': (c_cp, []),
+    'sgnn_tune_current': (c_vp, []),
     'sgnn_hash_capacity': (c_i64, [c_i64]),
     'sgnn_coords_from_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_coords_to_i64': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
-    'sgnn_rulebook_set_lds': (c_i32, [c_i32]),
-    'sgnn_scan_set_inline': (c_i32, [c_i32]),
-    'sgnn_chain_set_merged': (c_i32, [c_i32]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_rulebook_subm3_volume': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -42,20 +43,11 @@ PROTOTYPES = {
     'sgnn_conv_fwd_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     'sgnn_conv_bwd_weight_ex': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_conv_stats_blocks': (c_i64, [c_i64]),
-    'sgnn_conv_set_small': (c_i32, [c_i32]),
-    'sgnn_conv_set_small_rows': (c_i64, [c_i64]),
-    'sgnn_conv_set_unrolled': (c_i32, [c_i32]),
-    'sgnn_conv_set_dw_blocks': (c_i32, [c_i32]),
-    'sgnn_conv_set_dw_c1': (c_i32, [c_i32]),
-    'sgnn_conv_set_one_round': (c_i32, [c_i32]),
-    'sgnn_conv_set_wide_epi': (c_i32, [c_i32]),
     'sgnn_conv_fwd_epi': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     'sgnn_conv_bwd_weight_ws_bytes': (c_i64, [c_i64, c_i32, c_i32, c_i32]),
     'sgnn_conv_bwd_weight': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'sgnn_conv_bwd_fused_ws_bytes': (c_i64, [c_i64, c_i32, c_i32]),
     'sgnn_conv_bwd_fused_supported': (c_i32, [c_i64, c_i32, c_i32, c_i32]),
-    'sgnn_conv_set_bwd_fused': (c_i32, [c_i32]),
-    'sgnn_conv_set_bwd_fused_rows': (c_i64, [c_i64]),
     'sgnn_conv_bwd_fused': (c_i32, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_bn_ws_bytes': (c_i64, [c_i64, c_i32]),
     'sgnn_bn_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -108,11 +100,6 @@ PROTOTYPES = {
     'sgnn_prog_ws_bytes': (c_i64, [c_vp, c_i32, c_vp, c_i32]),
     'sgnn_prog_buffer_offset': (c_i64, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32]),
     'sgnn_prog_set_side_stream': (c_i32, [c_vp, c_vp, c_i64]),
-    'sgnn_prog_set_fusion': (c_i32, [c_i32]),
-    'sgnn_prog_set_lin_bn': (c_i32, [c_i32]),
-    'sgnn_prog_set_lin_add': (c_i32, [c_i32]),
-    'sgnn_prog_set_bn_fold': (c_i32, [c_i32]),
-    'sgnn_prog_set_bn_fold_rows': (c_i64, [c_i64]),
     'sgnn_prog_defer_join': (c_i32, [c_i32]),
     'sgnn_prog_forward': (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                   c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
@@ -170,23 +157,33 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        # measurements only: SGNN_TUNE="sgnn_conv_set_dw_blocks=341,sgnn_prog_set_bn_fold=1" calls the listed integer
-        # switches once (scripts/ab_env2.sh SGNN_TUNE a=1 a=2 compares two settings on one box)
+        # measurements only: SGNN_TUNE="conv_dw_blocks=341,prog_lin_bn=0" sets the listed fields of the library's switch table
+        # (include/sgnn_hip.h, struct sgnn_tune) once at load (scripts/ab_env2.sh SGNN_TUNE a=1 a=2 compares two settings)
         for item in filter(None, os.environ.get('SGNN_TUNE', '').split(',')):
             name, _, val = item.partition('=')
-            proto = PROTOTYPES.get(name)
-            # a switch = an entry point named *_set_* that takes exactly one integer (sgnn_prog_set_side_stream takes pointers)
-            if proto is None or '_set_' not in name or list(proto[1]) not in ([c_i32], [c_i64]):
-                raise SgnnError('SGNN_TUNE: %r is not an integer switch of the library' % name)
-            if not hasattr(lib, name):
-                raise SgnnError('SGNN_TUNE: the library at %s does not export %s' % (LIB_PATH, name))
             try:
                 ival = int(val)
             except ValueError:
                 raise SgnnError('SGNN_TUNE: %s=%r is not an integer' % (name, val))
-            getattr(lib, name)(ival)
+            if not hasattr(lib, 'sgnn_tune_set'):
+                raise SgnnError('SGNN_TUNE: the library at %s has no switch table' % LIB_PATH)
+            if lib.sgnn_tune_set(name.encode(), ival) == TUNE_UNKNOWN:
+                raise SgnnError('SGNN_TUNE: %s' % lib.sgnn_last_error().decode())
         _lib = lib
     return _lib
+
+
+TUNE_UNKNOWN = -(1 << 63)
+
+
+def tune(name, value=None):
+    """One switch of the library's measurement table (struct sgnn_tune, include/sgnn_hip.h): set it (returns the previous
+    value) or, with value None, read it.  Raises on an unknown name / a value out of range."""
+    lib = load()
+    r = lib.sgnn_tune_get(name.encode()) if value is None else lib.sgnn_tune_set(name.encode(), int(value))
+    if r == TUNE_UNKNOWN:
+        raise SgnnError(lib.sgnn_last_error().decode())
+    return r
 
 
 def require_gpu():

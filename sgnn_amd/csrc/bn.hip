@@ -530,12 +530,8 @@ static int bn_apply_grid(int64_t n, const BnGeom &g) {
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
                      float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
-                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev,
-                     int skip_apply) {
-  // skip_apply bit 0: statistics only — the consuming convolution normalises the rows in its gather (BnPre); bit 1: finalise
-  // in the separate kernel even where the apply pass could (the exact A/B reference of the folded path: same statistics)
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
   hipStream_t s = (hipStream_t)stream;
-  const bool no_apply = (skip_apply & 1) != 0, own_finalize = skip_apply != 0;
   SGNN_CHECK_ARG(n >= 0 && c >= 1 && (c % 4 == 0 ? c <= 1024 : c <= 256) && save_mean && save_invstd);
   SGNN_CHECK_ARG(training || (running_mean && running_var));
   if (ldx <= 0) ldx = c;
@@ -563,7 +559,7 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
                            g.cq, g.rpb, nullptr, nullptr, nullptr, nullptr, 0.f, (double *)ws, n_dev, BnLin{});
       partial = (const double *)ws;
     }
-    if (!own_finalize && bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
+    if (bn_fuse_ok(nblk, c, bn_apply_grid(n, g)))   // small level: k_bn_apply finalises
       fuse = BnFuse{partial, (int)nblk, eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
     else
       SGNN_LAUNCH(k_bn_finalize_fwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, eps, momentum,
@@ -575,7 +571,7 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
     SGNN_LAUNCH(k_bn_eval_stats, dim3(1), dim3(256), 0, s, (const float *)running_mean,
                        (const float *)running_var, c, eps, save_mean, save_invstd);
   }
-  if (n > 0 && !no_apply) {
+  if (n > 0) {
     SGNN_CHECK_ARG(x && y);
     const int grid = bn_apply_grid(n, g);
     if (g.vec == 4)

@@ -7,6 +7,8 @@
 
 #define SGNN_EXPORT extern "C" __attribute__((visibility("default")))
 
+extern sgnn_tune g_tune;   // tune.hip: the library's one table of measurement switches (include/sgnn_hip.h documents every field)
+
 void sgnn_set_error(const char *fmt, ...);
 // prof.hip: optional HIP-event timing of conv launches (slot < 0 = not recording)
 int sgnn_prof_begin_launch(int kind, int64_t n_out, int cin, int cout, int K, int flags, hipStream_t s);
@@ -20,14 +22,7 @@ void sgnn_prof_end_launch(int slot, hipStream_t s);
 //    stats = 2: y is the gradient reaching a BatchNormReLU output; column sums of dz and dz*xhat with
 //    dz = y * (bn_out > 0 ? 1 : leak), xhat from bn_x / mean / invstd (what BatchNorm backward reduces first).
 //    partial[blk][2][COUT] doubles, blk = workgroup; summed later in fixed order (deterministic).
-// BatchNormReLU folded into the CONSUMER's gather (round 4): the convolution reads the BatchNorm's INPUT rows and
-// applies y = act(((x - mean) * invstd) * gamma + beta) per gathered value, exactly the arithmetic of bn.hip's apply pass
-// (sgnn_bn_act below), with rows of missing rules (-1) kept at zero.  mean == NULL: x rows are used as they are.
-struct BnPre {
-  const float *mean, *invstd, *gamma, *beta;
-  float leak;
-};
-
+// the arithmetic of BatchNormReLU's apply pass (bn.hip)
 __device__ __forceinline__ float sgnn_bn_act(float x, float mean, float invstd, float gamma, float beta, float leak) {
   const float xh = (x - mean) * invstd;
   const float t = fmaf(xh, gamma, beta);
@@ -46,7 +41,6 @@ struct ConvEpi {
   // capacity mode: the output row count lives in device memory (*n_dev, clamped to the n_out the launch was sized
   // for); NULL = the host value is exact.  Lets a whole training step be captured in a HIP graph.
   const int64_t *n_dev;
-  BnPre pre;      // pre.mean != NULL: the input rows are normalised on load (see BnPre)
 };
 
 // conv.hip internals used by prog.hip
@@ -70,8 +64,7 @@ struct BnLin {
 int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float *gamma, const float *beta,
                      float *running_mean, float *running_var, float eps, float momentum, int training, float leak,
                      float *save_mean, float *save_invstd, float *y, int64_t ldy, const double *pre_partial,
-                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr,
-                     int skip_apply = 0);
+                     int64_t pre_nblk, void *ws, int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy, int64_t n, int c, const float *gamma,
                      const float *beta, const float *save_mean, const float *save_invstd, int training, float leak,
                      const float *addend, int64_t ld_add, float *dx, int64_t ld_dx, float *dgamma, float *dbeta,
@@ -120,8 +113,7 @@ int sgnn_concat3_rows_bwd_dn(const float *ddst, int ca, const int32_t *ia, int c
 int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
                               const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
-                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr,
-                              const BnPre *pre = nullptr);
+                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev = nullptr);
 // conv_bwd_fused.hip: data gradient + weight gradient of a 3x3x3 submanifold layer from one gather of dy
 bool sgnn_conv_bwd_fused_ok(int64_t n, int cin, int cout, int K);
 bool sgnn_conv_bwd_fused_usable(int64_t n, int cin, int cout, int K, const ConvEpi &epi, const float *dx, const float *x,

@@ -22,13 +22,13 @@
 
 #include "conv_common.h"
 
-#define CONV_SMALL_GRID g_small_grid       // below this many 256-row workgroups the latency-oriented small-level kernel runs
-static int g_small_grid = 160;             // ~40 k rows (sgnn_conv_set_small_rows: measurements)
+// below this many 256-row workgroups the latency-oriented small-level kernel runs (sgnn_tune.conv_small_rows, ~40 k rows)
+#define CONV_SMALL_GRID ((int64_t)((g_tune.conv_small_rows + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK))
 
 // EX = false: plain rulebook walk (ex is ignored; keeps the register budget of the hot instantiations)
 // WEPI: the wide (row-contiguous, 16-byte) epilogue of conv_common.h instead of the element-wise one
 // (the body of k_conv_fwd and k_conv_fwd_w below)
-template <int CIN, int COUT, int M, bool EX, bool PRE, bool WEPI>
+template <int CIN, int COUT, int M, bool EX, bool WEPI>
 __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64_t n_in,
                                               const float *__restrict__ w, const int32_t *__restrict__ table,
                                               int64_t ld, int K, int64_t n_out, float *y, int flags,
@@ -112,28 +112,10 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
       return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0) >> in_shift;
     }
   };
-  // BatchNormReLU of the producing layer folded into this gather (ConvEpi.pre): the lane's V channels' constants
-  // (PRE is a template parameter: the constants and the per-tile flags cost 4 V + M registers, which the plain
-  //  instantiations — every launch whose input is not a folded BatchNorm — must not pay in occupancy)
-  constexpr int PV = PRE ? V : 1, PM = PRE ? M : 1;
-  float pm[PV], pi[PV], pg[PV], pb[PV];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int s = 0; s < V; ++s) {
-      const int c = q * V + s;
-      const bool okc = c < CIN;
-      pm[s] = okc ? epi.pre.mean[c] : 0.f;
-      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
-      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
-      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
-    }
-  }
-  // ok[m]: 1.0 where tile m's rule exists (a missing rule's row must stay zero after the normalisation)
-  auto gather = [&](int32_t iv, float(&a)[M][V], float(&ok)[PM]) {
+  auto gather = [&](int32_t iv, float(&a)[M][V]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
-      if constexpr (PRE) ok[m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[m]);
     }
   };
@@ -148,13 +130,7 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
       for (int s = 0; s < V; ++s) b[nt][s] = bp[s];
     }
   };
-  auto mma_b = [&](float(&a)[M][V], const float(&ok)[PM], const float(&b)[NT][V]) {
-    if constexpr (PRE) {
-#pragma unroll
-      for (int m = 0; m < M; ++m)
-#pragma unroll
-        for (int s = 0; s < V; ++s) a[m][s] = sgnn_bn_act(a[m][s], pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * ok[m];
-    }
+  auto mma_b = [&](float(&a)[M][V], const float(&b)[NT][V]) {
     if constexpr (CINP != CIN) {  // the last quarter reads past the row end: those slots must be exact zeros
 #pragma unroll
       for (int m = 0; m < M; ++m)
@@ -170,10 +146,10 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
         for (int nt = 0; nt < NT; ++nt)
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[nt][s], acc[m][nt], 0, 0, 0);
   };
-  auto mma = [&](int kk, float(&a)[M][V], const float(&ok)[PM]) {
+  auto mma = [&](int kk, float(&a)[M][V]) {
     float b[NT][V];
     load_b(kk, b);
-    mma_b(a, ok, b);
+    mma_b(a, b);
   };
 
   // software pipeline, unrolled by two with ping-pong registers: rule entries run three offsets ahead, gathered rows
@@ -200,61 +176,61 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
   if constexpr (V <= 4 && (NT >= 2 || M == 1)) {
     // narrow rows, several output tiles (long MFMA phase per offset): three register sets, rows gathered TWO offsets
     // ahead of their MFMAs.  Measured at N = 366 k: <16,48> 228 -> 187 us; <16,16> (NT = 1) is 3 % faster with two sets
-    float a0[M][V], a1[M][V], a2[M][V], o0[PM], o1[PM], o2[PM];
+    float a0[M][V], a1[M][V], a2[M][V];
     for (int k0 = 0; k0 < K; k0 += KC) {      // one pass per staged weight chunk (a single one for the 3x3x3 16->16 layers)
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       if (restage) stage(k0);
-      gather(idx_at(k0), a0, o0);
-      gather(idx_at(k0 + 1), a1, o1);
+      gather(idx_at(k0), a0);
+      gather(idx_at(k0 + 1), a1);
       int32_t iv2 = idx_at(k0 + 2), iv3 = idx_at(k0 + 3), iv4 = idx_at(k0 + 4);
       int kk = 0;
       for (; kk + 2 < kc; kk += 3) {
         // sched_barrier: the machine scheduler otherwise sinks the gathers to half an offset before their use
-        gather(iv2, a2, o2);                    // rows of offset k0+kk+2
+        gather(iv2, a2);                        // rows of offset k0+kk+2
         iv2 = idx_at(k0 + kk + 5);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk, a0, o0);
+        mma(kk, a0);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv3, a0, o0);                    // rows of offset k0+kk+3 (dropped if that is past this chunk)
+        gather(iv3, a0);                        // rows of offset k0+kk+3 (dropped if that is past this chunk)
         iv3 = idx_at(k0 + kk + 6);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 1, a1, o1);
+        mma(kk + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv4, a1, o1);                    // rows of offset k0+kk+4
+        gather(iv4, a1);                        // rows of offset k0+kk+4
         iv4 = idx_at(k0 + kk + 7);
         __builtin_amdgcn_sched_barrier(0);
-        mma(kk + 2, a2, o2);
+        mma(kk + 2, a2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < kc) mma(kk, a0, o0);
-      if (kk + 1 < kc) mma(kk + 1, a1, o1);
+      if (kk < kc) mma(kk, a0);
+      if (kk + 1 < kc) mma(kk + 1, a1);
     }
   } else {
     // (round 4: the B fragments run one offset ahead too — their ds_read is issued before the MFMAs of the current offset
     //  instead of right in front of its own, where every offset paid the LDS latency behind an lgkmcnt(0))
-    float a0[M][V], a1[M][V], o0[PM], o1[PM], b0[NT][V], b1[NT][V];
+    float a0[M][V], a1[M][V], b0[NT][V], b1[NT][V];
     // (WEPI launches have K <= KC — the dispatcher checks: ONE chunk, so that the epilogue operands loaded under its last
     //  offset are not values carried around a loop, which would keep their 32 registers allocated across the whole walk)
     for (int k0 = 0; k0 < (WEPI ? 1 : K); k0 += KC) {
       const int kc = (K - k0) < KC ? (K - k0) : KC;
       if (restage) stage(k0);
       int32_t iv1 = idx_at(k0 + 1), iv2 = idx_at(k0 + 2);
-      gather(idx_at(k0), a0, o0);
+      gather(idx_at(k0), a0);
       load_b(0, b0);
       int kk = 0;
       for (; kk + 1 < kc; kk += 2) {
-        gather(iv1, a1, o1);                    // rows of offset k0+kk+1
+        gather(iv1, a1);                        // rows of offset k0+kk+1
         const int32_t iv3 = idx_at(k0 + kk + 3);
         load_b(kk + 1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_b(a0, o0, b0);
+        mma_b(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        gather(iv2, a0, o0);                    // rows of offset k0+kk+2 (dropped if that is past this chunk)
+        gather(iv2, a0);                        // rows of offset k0+kk+2 (dropped if that is past this chunk)
         iv1 = iv3;
         iv2 = idx_at(k0 + kk + 4);
         load_b(kk + 2 < kc ? kk + 2 : kc - 1, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mma_b(a1, o1, b1);
+        mma_b(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (WEPI) {
@@ -263,7 +239,7 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
         if constexpr (SGNN_WEPI_EARLY != 0) conv_epi_wide_prefetch<COUT, M>(erows, row0, n_out, epi, epi.stats, x, SGNN_WEPI_EARLY);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kk < kc) mma_b(a0, o0, b0);
+      if (kk < kc) mma_b(a0, b0);
     }
   }
 
@@ -275,12 +251,12 @@ __device__ __forceinline__ void conv_fwd_body(const float *__restrict__ x, int64
   conv_epilogue_stats<COUT, NT>(s1, s2, epi, EX ? 0 : epi.stats, sred, blockIdx.x);
 }
 
-template <int CIN, int COUT, int M, bool EX, bool PRE = false>
+template <int CIN, int COUT, int M, bool EX>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float *__restrict__ x, int64_t n_in,
                                                  const float *__restrict__ w, const int32_t *__restrict__ table,
                                                  int64_t ld, int K, int64_t n_out, float *y, int flags,
                                                  int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
-  conv_fwd_body<CIN, COUT, M, EX, PRE, false>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
+  conv_fwd_body<CIN, COUT, M, EX, false>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
 }
 
 // The 256-row kernel with the wide epilogue (plain walk, <= 16 channels either side, K <= 27).  Four waves per SIMD like the
@@ -291,7 +267,7 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_fwd_w(
     const float *__restrict__ x, int64_t n_in, const float *__restrict__ w, const int32_t *__restrict__ table, int64_t ld,
     int K, int64_t n_out, float *y, int flags, int in_shift, ConvEx ex, ConvEpi epi, int wg_cap) {
-  conv_fwd_body<CIN, COUT, CONV_MREP, false, false, true>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
+  conv_fwd_body<CIN, COUT, CONV_MREP, false, true>(x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi, wg_cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -303,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // accumulators, and the four partial tiles are summed through LDS.  Same arithmetic per (row, offset); the summation
 // order over offsets differs from the big kernel (fp32 round-off only).  Plain rulebook walk only.
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT, bool PRE = false>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x, int64_t n_in,
                                                    const float *__restrict__ w, const int32_t *__restrict__ table,
                                                    int64_t ld, int K, int64_t n_out, float *y, int flags, int in_shift,
@@ -347,19 +323,6 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
   float a[KW][V];
 #pragma unroll
   for (int kk = 0; kk < KW; ++kk) buf_load_floats<V>(rs_x, (uint32_t)id[kk] * ldx4 + (uint32_t)(q * V * 4), a[kk]);
-  constexpr int PV = PRE ? V : 1;     // PRE: BatchNormReLU of the producing layer folded into the gather (BnPre)
-  float pm[PV], pi[PV], pg[PV], pb[PV];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int s = 0; s < V; ++s) {
-      const int c = q * V + s;
-      const bool okc = c < CIN;
-      pm[s] = okc ? epi.pre.mean[c] : 0.f;
-      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
-      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
-      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
-    }
-  }
   float b[KW][NT][V];
   if (transpose) {
     // data gradient: the weights are read as (K, COUT, CIN), so a lane's V channels are CONTIGUOUS — one wide load per
@@ -449,14 +412,6 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x,
           b[kk][nt][s] = v;
         }
       }
-    }
-  }
-  if constexpr (PRE) {
-#pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-      const float okr = id[kk] >= 0 ? 1.f : 0.f;
-#pragma unroll
-      for (int s = 0; s < V; ++s) a[kk][s] = sgnn_bn_act(a[kk][s], pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * okr;
     }
   }
   if constexpr (CINP != CIN) {
@@ -554,8 +509,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
                                                          const float *__restrict__ w, int K,
                                                          const int32_t *__restrict__ table, int64_t ld,
                                                          int64_t n_out, int cout, float *__restrict__ y,
-                                                         int flags, int in_shift, ConvEx ex, const int64_t *n_dev,
-                                                         BnPre pre) {
+                                                         int flags, int in_shift, ConvEx ex, const int64_t *n_dev) {
   n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_out * ex.groups * cout) return;
@@ -573,9 +527,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_generic(const float *__restric
     const int ks = flip ? (K - 1 - k) : k;
     for (int c = 0; c < cin; ++c) {
       const float wv = transpose ? w[((int64_t)ks * cout + n) * cin + c] : w[((int64_t)ks * cin + c) * cout + n];
-      float xv = xr[c];
-      if (pre.mean) xv = sgnn_bn_act(xv, pre.mean[c], pre.invstd[c], pre.gamma ? pre.gamma[c] : 1.f, pre.beta ? pre.beta[c] : 0.f, pre.leak);
-      acc = fmaf(xv, wv, acc);
+      acc = fmaf(xr[c], wv, acc);
     }
   }
   y[t] = acc;
@@ -599,66 +551,36 @@ int64_t sgnn_conv_grid_blocks(int64_t n_out, int cin, int cout, int K) {
   return grid4;
 }
 
-SGNN_EXPORT int64_t sgnn_conv_set_small_rows(int64_t rows) {
-  const int64_t prev = (int64_t)g_small_grid * CONV_ROWS_PER_BLOCK;
-  const int64_t g = rows < 0 ? 0 : (rows > (1ll << 36) ? (1ll << 28) : (rows + CONV_ROWS_PER_BLOCK - 1) / CONV_ROWS_PER_BLOCK);
-  g_small_grid = (int)g;
-  return prev;
-}
 
 // conv_unrolled.hip: the large-level kernel as straight-line code (plain rulebook walk, K = 27 / 8)
 bool sgnn_conv_u_supported(int cin, int cout, int K);
 bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                         int64_t n_out, int cout, float *y, int flags, int in_shift, const ConvEpi &epi, hipStream_t s);
-static int g_unrolled_kernel = 1;   // sgnn_conv_set_unrolled: 0 = the looped kernel on every level (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_unrolled(int on) {
-  const int prev = g_unrolled_kernel;
-  g_unrolled_kernel = on ? 1 : 0;
-  return prev;
-}
 
-int g_conv_one_round = 1;   // sgnn_conv_set_one_round: 0 = one 256-row tile per workgroup on every level (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_one_round(int on) {
-  const int prev = g_conv_one_round;
-  g_conv_one_round = on ? 1 : 0;
-  return prev;
-}
-int g_conv_wide_epi = 1;     // sgnn_conv_set_wide_epi: 0 = the element-wise epilogue on every launch (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_wide_epi(int on) {
-  const int prev = g_conv_wide_epi;
-  g_conv_wide_epi = on ? 1 : 0;
-  return prev;
-}
 // the wide epilogue moves whole 16-byte chunks of a row: every row stride it touches must be a multiple of 4 floats and
 // the bases 16-byte aligned (views into a JoinTable buffer start at multiples of 16 columns; odd test strides fall back)
 bool conv_wide_epi_ok(const ConvEpi &epi, const float *y, int K) {
-  if (!g_conv_wide_epi || K > 27 || (epi.ldy & 3) || ((uintptr_t)y & 15)) return false;   // (27 = ConvCfg::KC for <= 16 channels)
+  if (!g_tune.conv_wide_epi || K > 27 || (epi.ldy & 3) || ((uintptr_t)y & 15)) return false;   // (27 = ConvCfg::KC for <= 16 channels)
   if (epi.addend && ((epi.ld_add & 3) || ((uintptr_t)epi.addend & 15))) return false;
   if (epi.stats == 2 && ((epi.ld_bnx & 3) || ((uintptr_t)epi.bn_x & 15))) return false;
   return true;
 }
 // the 256-row kernel of a level: wide epilogue where the shape and the strides allow it
-template <int CI, int CO, bool EXV, bool PREV>
+template <int CI, int CO, bool EXV>
 static void conv_launch_big(unsigned grid4, hipStream_t s, const float *x, int64_t n_in, const float *w, const int32_t *table,
                             int64_t ld, int K, int64_t n_out, float *y, int flags, int in_shift, const ConvEx &ex,
                             const ConvEpi &epi) {
-  if constexpr (!EXV && !PREV && CO % 4 == 0 && CO <= 16 && CI <= 16) {
+  if constexpr (!EXV && CO % 4 == 0 && CO <= 16 && CI <= 16) {
     static_assert(ConvCfg<CI, CO>::KC >= 27, "one weight chunk holds a 3x3x3 filter");
     if (conv_wide_epi_ok(epi, y, K)) {
       SGNN_LAUNCH((k_conv_fwd_w<CI, CO>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, K, n_out, y, flags, in_shift,
-                  ex, epi, !g_conv_one_round ? 0 : conv_wg_capacity<k_conv_fwd_w<CI, CO>>());
+                  ex, epi, !g_tune.conv_one_round ? 0 : conv_wg_capacity<k_conv_fwd_w<CI, CO>>());
       return;
     }
   }
-  SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, K, n_out, y,
+  SGNN_LAUNCH((k_conv_fwd<CI, CO, CONV_MREP, EXV>), dim3(grid4), dim3(256), 0, s, x, n_in, w, table, ld, K, n_out, y,
               flags, in_shift, ex, epi,
-              (EXV || !g_conv_one_round) ? 0 : conv_wg_capacity<k_conv_fwd<CI, CO, CONV_MREP, EXV, PREV>>());
-}
-static int g_small_kernel = 1;   // sgnn_conv_set_small: 0 = the 64-row variant of the big kernel (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_small(int on) {
-  const int prev = g_small_kernel;
-  g_small_kernel = on ? 1 : 0;
-  return prev;
+              (EXV || !g_tune.conv_one_round) ? 0 : conv_wg_capacity<k_conv_fwd<CI, CO, CONV_MREP, EXV>>());
 }
 
 bool sgnn_conv_epi_supported(int cin, int cout) {
@@ -688,7 +610,6 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   if (epi.ld_bnx <= 0) epi.ld_bnx = cout;
   const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
   const bool has_epi = epi.ldx != cin || epi.ldy != cout || epi.addend || epi.stats;
-  SGNN_CHECK_ARG(!epi.pre.mean || epi.pre.invstd);
   SGNN_CHECK_ARG(epi.ldx >= cin && epi.ldx <= 1024 && epi.ldy >= cout && epi.ldy <= 1024 && epi.ld_add >= cout &&
                  epi.ld_add <= 1024 && epi.ld_bnx >= cout && epi.ld_bnx <= 1024);
   SGNN_CHECK_ARG(epi.stats >= 0 && epi.stats <= 2 && (!epi.stats || (plain && epi.partial)));
@@ -709,46 +630,28 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
   const bool small = grid4 < CONV_SMALL_GRID;   // too few 256-row workgroups for 256 CUs: 64-row workgroups
   bool done = false;
   const int prof = sgnn_prof_begin_launch(0, n_out * groups, cin, cout, K, flags, s);
-#define LAUNCH_FWD_P(CI, CO, EXV, PREV)                                                                 \
+#define LAUNCH_FWD(CI, CO, EXV)                                                                         \
   do {                                                                                                  \
-    if (small && !EXV && K <= 28 && (g_small_kernel || epi.stats))                                      \
-      SGNN_LAUNCH((k_conv_small<CI, CO, PREV>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,   \
+    if (small && !EXV && K <= 28 && (g_tune.conv_small || epi.stats))                                      \
+      SGNN_LAUNCH((k_conv_small<CI, CO>), dim3((unsigned)((n_out + 15) / 16)), dim3(256), 0, s,         \
                          x, n_in, w, table, ld, K, n_out, y, flags, in_shift, epi);                     \
     else if (small)                                                                                     \
-      SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV, PREV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table,  \
+      SGNN_LAUNCH((k_conv_fwd<CI, CO, 1, EXV>), dim3(grid1), dim3(256), 0, s, x, n_in, w, table,        \
                          ld, K, n_out, y, flags, in_shift, ex, epi, 0);                                 \
     else                                                                                                \
-      conv_launch_big<CI, CO, EXV, PREV>(grid4, s, x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi); \
+      conv_launch_big<CI, CO, EXV>(grid4, s, x, n_in, w, table, ld, K, n_out, y, flags, in_shift, ex, epi); \
     done = true;                                                                                        \
   } while (0)
-// (the BatchNorm-folding instantiations exist for the shapes the planner folds: BN_FOLD_* lists below)
-#define LAUNCH_FWD(CI, CO, EXV)                  \
-  do {                                           \
-    LAUNCH_FWD_P(CI, CO, EXV, false);            \
-  } while (0)
-  if (plain && !small && g_unrolled_kernel && sgnn_conv_u_supported(cin, cout, K))
+  if (plain && !small && g_tune.conv_unrolled && sgnn_conv_u_supported(cin, cout, K))
     done = sgnn_conv_u_launch(x, n_in, cin, w, K, table, ld, n_out, cout, y, flags, in_shift, epi, s);
-  const bool has_pre = epi.pre.mean != nullptr;
-#define X(CI, CO)                                                  \
-  if (!done && plain && cin == CI && cout == CO) {                 \
-    if (has_pre)                                                   \
-      LAUNCH_FWD_P(CI, CO, false, true);                           \
-    else                                                           \
-      LAUNCH_FWD_P(CI, CO, false, false);                          \
-  }
+#define X(CI, CO) \
+  if (!done && plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, false);
   CONV_FWD_CASES(X)
 #undef X
 #define X(CI, CO) \
-  if (!done && !plain && !has_pre && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, true);
+  if (!done && !plain && cin == CI && cout == CO) LAUNCH_FWD(CI, CO, true);
   CONV_EX_CASES(X)
 #undef X
-  // the up-sampling convolution behind a folded BatchNormReLU (prog.hip expand_shape_ok)
-  if (!done && !plain && has_pre && cin == 48 && cout == 16) LAUNCH_FWD_P(48, 16, true, true);
-  if (!done && !plain && has_pre && cin == 24 && cout == 8) LAUNCH_FWD_P(24, 8, true, true);
-  if (!done && !plain && has_pre) {
-    sgnn_set_error("sgnn_conv_fwd: no BatchNorm-folding kernel for the grouped (%d, %d) walk", cin, cout);
-    return SGNN_EINVAL;
-  }
   if (!done) {
     if (has_epi) {
       sgnn_set_error("sgnn_conv_fwd_epi: strided / fused epilogues need one of the compiled (cin, cout) shapes, got (%d, %d)", cin, cout);
@@ -756,7 +659,7 @@ int sgnn_conv_fwd_impl(const float *x, int64_t n_in, int cin, const float *w, in
     }
     const int64_t total = n_out * groups * cout;
     SGNN_LAUNCH(k_conv_fwd_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, cin, w, K,
-                       table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev, epi.pre);
+                       table, ld, n_out, cout, y, flags, in_shift, ex, epi.n_dev);
   }
   sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
@@ -896,12 +799,12 @@ struct DwCfg {
 #ifndef DW_PAIR
 #define DW_PAIR 1
 #endif
-template <int CIN, int COUT, bool EX, int KPBT = 0, bool PRE = false>
+template <int CIN, int COUT, bool EX, int KPBT = 0>
 __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, int64_t n_in,
                                                 const float *__restrict__ dy, const int32_t *__restrict__ table,
                                                 int64_t ld, int K, int64_t n_out, float *__restrict__ partial,
                                                 int64_t rows_per_block, int in_shift, ConvEx ex, int64_t ldx,
-                                                int64_t ld_dy, const int64_t *n_dev, BnPre pre) {
+                                                int64_t ld_dy, const int64_t *n_dev) {
   if (n_dev) {   // capacity mode: spread the LIVE rows over all row blocks of the (capacity-sized) launch
     n_out = sgnn_dyn_n(n_out, n_dev);
     const int64_t per = (n_out + gridDim.x - 1) / gridDim.x;
@@ -917,7 +820,7 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   // (A rows 0..7 = the channels of offset 2p, rows 8..15 = those of offset 2p+1, from two LDS tiles; B = dy for both):
   // half the MFMAs and half the fragment reads for the <8,8> / <8,12> gradients.  Same products, same order of
   // additions per (offset, channel pair): bit-identical to the unpaired form.
-  constexpr bool PAIR = DW_PAIR && MT * NT == 1 && CIN == 8 && KPBT == 0 && !EX && !PRE;
+  constexpr bool PAIR = DW_PAIR && MT * NT == 1 && CIN == 8 && KPBT == 0 && !EX;
   constexpr int XT = PAIR ? 2 : 1;                       // x tiles per wave
   constexpr int RED = DW_KPB * MT * 16 * NT * 16;
   constexpr int LDS_FLOATS = (4 * (XT * XS + YS) > RED) ? 4 * (XT * XS + YS) : RED;
@@ -962,9 +865,6 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
 
   // wide (16 B / lane) gathers like the forward kernel, transposed through LDS so that the site index lands on
   // the MFMA contraction axis: A[i = ci][kslot = j] = x[table[k][R + j]][ci], B[kslot = j][co] = dy[R + j][co]
-  // the convolution's input rows may be the INPUT of a folded BatchNormReLU (BnPre): the gather then normalises them, with
-  // the rows of missing rules kept at zero (ok[m]); applied where the rows are written to LDS (norm_rows), not at the load
-  // (PRE is a template parameter: the plain instantiations do not pay its registers)
   // Row-contiguous gathers (round 4, scripts/kernels/gather_bench.hip): a gather instruction whose 16-lane quarter-waves
   // each touch 16 different rows (the MFMA-fragment mapping: lane (row = lane & 15, quarter = lane >> 4)) costs the texture
   // path 41 cycles per KiB; with lanes 4g .. 4g+3 covering one whole 64-byte row it costs 28 (32-byte rows: 2 lanes per
@@ -974,34 +874,14 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
   constexpr bool RCX = (CIN == 16 || CIN == 8);
   constexpr int LPR = RCX ? CIN / 4 : 1, RPI = 64 / LPR, NI = RCX ? LPR : 4, GW = RCX ? 4 : V;   // NI loads of GW floats
   const int rc_row = lane / LPR, rc_chunk = lane % LPR;
-  constexpr int PV = PRE ? GW : 1, PM = PRE ? NI : 1;
-  float pm[PV], pi[PV], pg[PV], pb[PV];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int s = 0; s < GW; ++s) {
-      const int c = RCX ? rc_chunk * 4 + s : q * V + s;
-      const bool okc = c < CIN;
-      pm[s] = okc ? pre.mean[c] : 0.f;
-      pi[s] = okc ? pre.invstd[c] : 0.f;
-      pg[s] = okc ? (pre.gamma ? pre.gamma[c] : 1.f) : 0.f;
-      pb[s] = okc ? (pre.beta ? pre.beta[c] : 0.f) : 0.f;
-    }
-  }
-  auto gather = [&](int32_t iv, float(&g)[NI][GW], float(&ok)[PM]) {
+  auto gather = [&](int32_t iv, float(&g)[NI][GW]) {
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute((RCX ? m * RPI + rc_row : m * 16 + i16) * 4, iv);
-      if constexpr (PRE) ok[m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<GW>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(RCX ? rc_chunk * 16 : q * V * 4), g[m]);
     }
   };
-  auto norm_rows = [&](float(&g)[NI][GW], const float(&ok)[PM]) {
-    if constexpr (PRE) {
-#pragma unroll
-      for (int m = 0; m < NI; ++m)
-#pragma unroll
-        for (int s = 0; s < GW; ++s) g[m][s] = sgnn_bn_act(g[m][s], pm[s], pi[s], pg[s], pb[s], pre.leak) * ok[m];
-    }
+  auto norm_rows = [&](float(&g)[NI][GW]) {   // the last quarter reads past the row end: those slots must be exact zeros
     if constexpr (CINP != CIN) {
 #pragma unroll
       for (int m = 0; m < NI; ++m)
@@ -1122,15 +1002,15 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
     if constexpr (PAIR) {
       static_assert(RCX, "the paired path stores row-contiguous gathers");
       // two offsets per MFMA tile; the rows of the next pair are gathered before the MFMA block of the current one
-      float ga[2][NI][GW], gb[2][NI][GW], kd[PM];
+      float ga[2][NI][GW], gb[2][NI][GW];
       auto idx_of = [&](int kk) { return kk < DW_KPB ? idxv[kk < DW_KPB ? kk : 0] : -1; };   // past the group: no rule
-      gather(idx_of(0), ga[0], kd);
-      gather(idx_of(1), gb[0], kd);
+      gather(idx_of(0), ga[0]);
+      gather(idx_of(1), gb[0]);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         if (p + 1 < NP) {
-          gather(idx_of(2 * p + 2), ga[(p + 1) & 1], kd);
-          gather(idx_of(2 * p + 3), gb[(p + 1) & 1], kd);
+          gather(idx_of(2 * p + 2), ga[(p + 1) & 1]);
+          gather(idx_of(2 * p + 3), gb[(p + 1) & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         store_rows_to(ga[p & 1], xs);
@@ -1140,20 +1020,20 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       }
     } else if constexpr (MT * NT == 1) {
       // narrow layers: little MFMA work per gather -> prefetch the next offset's rows (ping-pong registers)
-      float g0[NI][GW], g1[NI][GW], k0_[PM], k1_[PM];
-      gather(idxv[0], g0, k0_);
+      float g0[NI][GW], g1[NI][GW];
+      gather(idxv[0], g0);
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; kk += 2) {
-        if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1, k1_);          // compile-time conditions only
+        if (kk + 1 < DW_KPB) gather(idxv[kk + 1], g1);               // compile-time conditions only
         __builtin_amdgcn_sched_barrier(0);
-        norm_rows(g0, k0_);
+        norm_rows(g0);
         store_rows(g0);
         mma_chunk(kk, b);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < DW_KPB) {
-          if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0, k0_);
+          if (kk + 2 < DW_KPB) gather(idxv[kk + 2], g0);
           __builtin_amdgcn_sched_barrier(0);
-          norm_rows(g1, k1_);
+          norm_rows(g1);
           store_rows(g1);
           mma_chunk(kk + 1, b);
           __builtin_amdgcn_sched_barrier(0);
@@ -1161,11 +1041,11 @@ __global__ __launch_bounds__(256) void k_conv_dw(const float *__restrict__ x, in
       }
     } else {
       // wide layers: 3+ MFMA tiles per gathered row hide the latency; one register set keeps occupancy up
-      float g0[NI][GW], k0_[PM];
+      float g0[NI][GW];
 #pragma unroll
       for (int kk = 0; kk < DW_KPB; ++kk) {
-        gather(idxv[kk], g0, k0_);
-        norm_rows(g0, k0_);
+        gather(idxv[kk], g0);
+        norm_rows(g0);
         store_rows(g0);
         mma_chunk(kk, b);
       }
@@ -1375,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
                                                         const float *__restrict__ dy, int cout,
                                                         const int32_t *__restrict__ table, int64_t ld, int K,
                                                         int64_t n_out, float *__restrict__ dw, int in_shift,
-                                                        ConvEx ex, const int64_t *n_dev, BnPre pre) {
+                                                        ConvEx ex, const int64_t *n_dev) {
   n_out = sgnn_dyn_n(n_out, n_dev);
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)ex.groups * K * cin * cout) return;
@@ -1385,8 +1265,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
   for (int64_t j = 0; j < n_out; ++j) {
     const int32_t id = table[(int64_t)(ex.kmap ? ex.kmap[grp * K + k] : k) * ld + j];
     if (id >= 0) {
-      float xv = x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin + ci];
-      if (pre.mean) xv = sgnn_bn_act(xv, pre.mean[ci], pre.invstd[ci], pre.gamma ? pre.gamma[ci] : 1.f, pre.beta ? pre.beta[ci] : 0.f, pre.leak);
+      const float xv = x[((int64_t)(id >> in_shift) * ex.in_mul + (ex.kadd ? ex.kadd[grp * K + k] : 0)) * cin + ci];
       s = fmaf(xv, dy[(j * ex.groups + grp) * cout + co], s);
     }
   }
@@ -1394,20 +1273,8 @@ __global__ __launch_bounds__(256) void k_conv_dw_generic(const float *__restrict
 }
 
 #define DW_FINE_ROWS 16384   // below: one offset per weight-gradient workgroup
-static int g_dw_c1_kernel = 1;   // sgnn_conv_set_dw_c1: 0 = the MFMA kernel for one-channel inputs too (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_dw_c1(int on) {
-  const int prev = g_dw_c1_kernel;
-  g_dw_c1_kernel = on ? 1 : 0;
-  return prev;
-}
-static int g_dw_blocks = 256;       // sgnn_conv_set_dw_blocks: row blocks a weight-gradient launch aims for (A/B measurements)
-SGNN_EXPORT int sgnn_conv_set_dw_blocks(int blocks) {
-  const int prev = g_dw_blocks;
-  if (blocks >= 1 && blocks <= 4096) g_dw_blocks = blocks;
-  return prev;
-}
 static int64_t dw_rows_per_block(int64_t n_out) {
-  int64_t rpb = (n_out + g_dw_blocks - 1) / g_dw_blocks;   // <= g_dw_blocks row blocks
+  int64_t rpb = (n_out + g_tune.conv_dw_blocks - 1) / g_tune.conv_dw_blocks;   // <= g_tune.conv_dw_blocks row blocks
   rpb = ((rpb + 255) / 256) * 256;             // whole 256-row wave rounds
   if (rpb < 256) rpb = 256;
   return rpb;
@@ -1445,10 +1312,8 @@ SGNN_EXPORT int sgnn_conv_bwd_weight_ex(const float *x, int64_t n_in, int cin, c
 int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx, const float *dy, int cout, int64_t ld_dy,
                               const int32_t *table, int64_t ld, int K, int64_t n_out, float *dw, int in_shift,
                               const int32_t *kmap, const int32_t *kadd, int in_mul, int groups, int table_rows, void *ws,
-                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev, const BnPre *pre_in) {
+                              int64_t ws_bytes, sgnn_stream_t stream, const int64_t *n_dev) {
   SGNN_CHECK_ARG(ldx >= cin && ldx <= 1024 && ld_dy >= cout && ld_dy <= 1024);
-  const BnPre pre = pre_in ? *pre_in : BnPre{nullptr, nullptr, nullptr, nullptr, 0.f};
-  SGNN_CHECK_ARG(!pre.mean || pre.invstd);
   SGNN_CHECK_ARG(cin >= 1 && cout >= 1 && K >= 1 && K <= 64 && n_out >= 0 && ld >= n_out && dw &&
                  in_shift >= 0 && in_shift < 31 && in_mul >= 1 && groups >= 1 && groups <= 64 && table_rows >= 1 &&
                  table_rows <= 64 && (kmap || table_rows >= K));
@@ -1470,7 +1335,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
   const int64_t rpb = dw_rows_per_block(n_out);
   const int64_t nblk = (n_out + rpb - 1) / rpb;
   const bool plain = !kmap && !kadd && in_mul == 1 && groups == 1 && table_rows == K;
-#define LAUNCH_DW(CI, CO, EXV, PREV)                                                                       \
+#define LAUNCH_DW(CI, CO, EXV)                                                                             \
   do {                                                                                                     \
     if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, groups * K, cin, cout)) {                   \
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");                                         \
@@ -1481,17 +1346,17 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     if constexpr (!EXV && kpb_ == 9) {                                                                     \
       /* small level of a narrow layer: 256 rows x 9 offsets per workgroup leaves most CUs idle and makes */ \
       /* every wave walk 9 dependent gather rounds -> one offset per workgroup (same sums, same order)     */ \
-      if (n_out < DW_FINE_ROWS && g_small_kernel)                                                          \
-        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 1, PREV>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
-                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev, pre); \
+      if (n_out < DW_FINE_ROWS && g_tune.conv_small)                                                          \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 1>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, s, \
+                           x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
       else                                                                                                 \
-        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 0, PREV>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
+        SGNN_LAUNCH((k_conv_dw<CI, CO, false, 0>), dim3((unsigned)nblk, (unsigned)((K + kpb_ - 1) / kpb_)), \
                            dim3(256), 0, s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift,  \
-                           ex, ldx, ld_dy, n_dev, pre);                                                    \
+                           ex, ldx, ld_dy, n_dev);                                                         \
     } else {                                                                                               \
-      SGNN_LAUNCH((k_conv_dw<CI, CO, EXV, 0, PREV>),                                                \
+      SGNN_LAUNCH((k_conv_dw<CI, CO, EXV, 0>),                                                \
                          dim3((unsigned)nblk, (unsigned)(groups * ((K + kpb_ - 1) / kpb_))), dim3(256), 0, \
-                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev, pre); \
+                         s, x, n_in, dy, table, ld, K, n_out, (float *)ws, rpb, in_shift, ex, ldx, ld_dy, n_dev); \
     }                                                                                                      \
     sgnn_prof_end_launch(prof, s);                                                                         \
     if (sgnn_dw_batch && sgnn_dw_batch->n < DW_BATCH_MAX) {                                                \
@@ -1502,8 +1367,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
     }                                                                                                      \
     done = true;                                                                                           \
   } while (0)
-  const bool has_pre = pre.mean != nullptr;
-  if (plain && !has_pre && cin == 1 && cout == 8 && g_dw_c1_kernel) {   // one-channel input: the VALU kernel (k_conv_dw_c1)
+  if (plain && cin == 1 && cout == 8 && g_tune.conv_dw_c1) {   // one-channel input: the VALU kernel (k_conv_dw_c1)
     if (!ws || ws_bytes < sgnn_conv_bwd_weight_ws_bytes(n_out, K, cin, cout)) {
       sgnn_set_error("sgnn_conv_bwd_weight: workspace too small");
       return SGNN_ENOWS;
@@ -1518,22 +1382,12 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       SGNN_LAUNCH(k_dw_reduce, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, (const float *)ws, nblk, elems, dw);
     done = true;
   }
-#define X(CI, CO)                                  \
-  if (!done && plain && cin == CI && cout == CO) { \
-    if (has_pre)                                   \
-      LAUNCH_DW(CI, CO, false, true);              \
-    else                                           \
-      LAUNCH_DW(CI, CO, false, false);             \
-  }
+#define X(CI, CO) \
+  if (!done && plain && cin == CI && cout == CO) LAUNCH_DW(CI, CO, false);
   CONV_DW_CASES(X)
 #undef X
-#define X(CI, CO)                                   \
-  if (!done && !plain && cin == CI && cout == CO) { \
-    if (has_pre)                                    \
-      LAUNCH_DW(CI, CO, true, true);                \
-    else                                            \
-      LAUNCH_DW(CI, CO, true, false);               \
-  }
+#define X(CI, CO) \
+  if (!done && !plain && cin == CI && cout == CO) LAUNCH_DW(CI, CO, true);
   X(48, 16) X(24, 8) X(64, 32) X(56, 28)   // up-sampling convolution; dense ConvTranspose3d(k4,s2) by parity groups (model.DenseK4S2)
 #undef X
   if (!done) {
@@ -1542,7 +1396,7 @@ int sgnn_conv_bwd_weight_impl(const float *x, int64_t n_in, int cin, int64_t ldx
       return SGNN_EINVAL;
     }
     SGNN_LAUNCH(k_conv_dw_generic, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, x, cin, dy,
-                       cout, table, ld, K, n_out, dw, in_shift, ex, n_dev, pre);
+                       cout, table, ld, K, n_out, dw, in_shift, ex, n_dev);
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;

@@ -329,22 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-extern int g_conv_one_round;
 bool conv_wide_epi_ok(const ConvEpi &epi, const float *y, int K);                      // conv.hip
 int sgnn_dw_reduce_or_defer(const float *partial, float *dw, int64_t nblk, int64_t elems, hipStream_t s);   // conv.hip
 
-static int g_bwd_fused = 0;                    // sgnn_conv_set_bwd_fused: 1 = sgnn_prog_backward uses the fused kernel (off: it loses in the step, see the header)
-static int64_t g_bwd_fused_min_rows = 40960;   // sgnn_conv_set_bwd_fused_rows: smallest level the fused kernel serves
-SGNN_EXPORT int sgnn_conv_set_bwd_fused(int on) {
-  const int prev = g_bwd_fused;
-  g_bwd_fused = on ? 1 : 0;
-  return prev;
-}
-SGNN_EXPORT int64_t sgnn_conv_set_bwd_fused_rows(int64_t rows) {
-  const int64_t prev = g_bwd_fused_min_rows;
-  if (rows >= 256) g_bwd_fused_min_rows = rows;
-  return prev;
-}
 
 #define FUSED_MAX_BLOCKS 512         // workspace bound: partial slots a launch may need (resident workgroups of the kernel: 2 per CU)
 
@@ -352,7 +339,7 @@ static int fused_wg_cap() { return conv_wg_capacity<k_conv_bwd_fused<16>>(); }
 
 // the shapes / sizes the fused kernel serves: plain 27-offset walk, 16 -> 16 channels, a level large enough for the 256-row kernel
 bool sgnn_conv_bwd_fused_ok(int64_t n, int cin, int cout, int K) {
-  if (!g_bwd_fused || !g_conv_one_round || K != FUSED_K || cin != 16 || cout != 16 || n < g_bwd_fused_min_rows) return false;
+  if (!g_tune.conv_bwd_fused || !g_tune.conv_one_round || K != FUSED_K || cin != 16 || cout != 16 || n < g_tune.conv_bwd_fused_rows) return false;
   const int cap = fused_wg_cap();
   return cap > 0 && cap <= FUSED_MAX_BLOCKS;
 }
@@ -360,7 +347,7 @@ bool sgnn_conv_bwd_fused_ok(int64_t n, int cin, int cout, int K) {
 // everything sgnn_conv_bwd_fused_impl checks, without raising an error (prog.hip: fall back to the two-kernel path)
 bool sgnn_conv_bwd_fused_usable(int64_t n, int cin, int cout, int K, const ConvEpi &epi, const float *dx, const float *x,
                                 int64_t ldx) {
-  if (!sgnn_conv_bwd_fused_ok(n, cin, cout, K) || epi.pre.mean || (epi.stats != 0 && epi.stats != 2)) return false;
+  if (!sgnn_conv_bwd_fused_ok(n, cin, cout, K) || (epi.stats != 0 && epi.stats != 2)) return false;
   if ((ldx & 3) || ((uintptr_t)x & 15) || (epi.ldx & 3)) return false;
   return conv_wide_epi_ok(epi, dx, K);
 }
@@ -387,7 +374,6 @@ int sgnn_conv_bwd_fused_impl(const float *dy, int64_t n, int cout, const float *
   SGNN_CHECK_ARG(ldx >= cin && ldx <= 1024 && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0);
   SGNN_CHECK_ARG(epi.ldx >= cout && epi.ldx <= 1024 && epi.ldy >= cin && epi.ldy <= 1024);
   SGNN_CHECK_ARG(epi.stats == 0 || (epi.stats == 2 && epi.partial && epi.bn_x && epi.mean && epi.invstd));
-  SGNN_CHECK_ARG(!epi.pre.mean);
   SGNN_CHECK_ARG(conv_wide_epi_ok(epi, dx, FUSED_K));
   const int64_t lmax = epi.ldy > epi.ld_add ? (epi.ldy > epi.ld_bnx ? epi.ldy : epi.ld_bnx)
                                             : (epi.ld_add > epi.ld_bnx ? epi.ld_add : epi.ld_bnx);

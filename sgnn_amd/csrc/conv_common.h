@@ -58,7 +58,6 @@ static int conv_wg_capacity() {
   if (dev < 16) cache[slot].store(per_cu * cus + 1, std::memory_order_relaxed);
   return per_cu * cus;
 }
-extern int g_conv_one_round;
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));

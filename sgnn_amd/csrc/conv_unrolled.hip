@@ -19,7 +19,7 @@
 
 // WEPI: the wide (row-contiguous, 16-byte) epilogue of conv_common.h (output rows of 8 / 12 / 16 channels)
 // (the body of k_conv_fwd_u and k_conv_fwd_uw below)
-template <int CIN, int COUT, int K, bool PRE, bool WEPI>
+template <int CIN, int COUT, int K, bool WEPI>
 __device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
                                                 const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
                                                 int flags, int in_shift, const ConvEpi &epi, int wg_cap) {
@@ -28,7 +28,7 @@ __device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int
   constexpr int KC = C::KC < K ? C::KC : K;            // offsets per staged weight chunk
   __shared__ __attribute__((aligned(16))) float wl[KC * C::PER_K];
   __shared__ double sred[4 * 2 * NT * 16];             // statistics scratch (the weight tile stays live across row tiles)
-  static_assert(!WEPI || (NT == 1 && COUT % 4 == 0 && !PRE), "wide epilogue: one column tile of whole 16-byte chunks");
+  static_assert(!WEPI || (NT == 1 && COUT % 4 == 0), "wide epilogue: one column tile of whole 16-byte chunks");
   __shared__ float ecst[WEPI ? 64 : 1];                // WEPI: per-column BatchNorm constants of the backward statistics
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,27 +66,11 @@ __device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int
   f32x4 acc[M][NT];
   if constexpr (WEPI) conv_epi_wide_constants<COUT>(ecst, epi, epi.stats);   // (visible after the barriers of the first stage())
 
-  // BatchNormReLU of the producing layer folded into the gather (ConvEpi.pre, see BnPre): the lane's V channels' constants
-  // (a template parameter: the plain instantiations do not pay the 4 V + 2 M registers)
-  constexpr int PV = PRE ? V : 1, PM = PRE ? M : 1;
-  float pm[PV], pi[PV], pg[PV], pb[PV];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int s = 0; s < V; ++s) {
-      const int c = q * V + s;
-      const bool okc = c < CIN;
-      pm[s] = okc ? epi.pre.mean[c] : 0.f;
-      pi[s] = okc ? epi.pre.invstd[c] : 0.f;
-      pg[s] = okc ? (epi.pre.gamma ? epi.pre.gamma[c] : 1.f) : 0.f;
-      pb[s] = okc ? (epi.pre.beta ? epi.pre.beta[c] : 0.f) : 0.f;
-    }
-  }
-  float a[2][M][V], ok[2][PM];    // ping-pong register sets: rows of offset k in a[k & 1]; ok = 1.0 where the rule exists
+  float a[2][M][V];               // ping-pong register sets: rows of offset k in a[k & 1]
   auto gather = [&](int k) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], idx[k]);
-      if constexpr (PRE) ok[k & 1][m] = id >= 0 ? 1.f : 0.f;
       buf_load_floats<V>(rs_x, (uint32_t)id * ldx4 + (uint32_t)(q * V * 4), a[k & 1][m]);
     }
   };
@@ -110,7 +94,6 @@ __device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         float av = a[k & 1][m][s];
-        if constexpr (PRE) av = sgnn_bn_act(av, pm[s], pi[s], pg[s], pb[s], epi.pre.leak) * ok[k & 1][m];
         if constexpr (CINP != CIN)       // the last quarter reads past the row end: those slots must be exact zeros
           if (3 * V + s >= CIN) av = (q == 3) ? 0.f : av;
 #pragma unroll
@@ -158,11 +141,11 @@ __device__ __forceinline__ void conv_fwd_u_body(const float *__restrict__ x, int
   conv_epilogue_stats<COUT, NT>(s1, s2, epi, epi.stats, sred, blockIdx.x);
 }
 
-template <int CIN, int COUT, int K, bool PRE>
+template <int CIN, int COUT, int K>
 __global__ __launch_bounds__(256) void k_conv_fwd_u(const float *__restrict__ x, int64_t n_in, const float *__restrict__ w,
                                                    const int32_t *__restrict__ table, int64_t ld, int64_t n_out, float *y,
                                                    int flags, int in_shift, ConvEpi epi, int wg_cap) {
-  conv_fwd_u_body<CIN, COUT, K, PRE, false>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
+  conv_fwd_u_body<CIN, COUT, K, false>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
 }
 
 // the stride-2 (8-offset) walks with the wide epilogue: with 32 gathers per 64-row tile the element-wise epilogue's 16-48
@@ -172,7 +155,7 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_fwd_uw(
     const float *__restrict__ x, int64_t n_in, const float *__restrict__ w, const int32_t *__restrict__ table, int64_t ld,
     int64_t n_out, float *y, int flags, int in_shift, ConvEpi epi, int wg_cap) {
-  conv_fwd_u_body<CIN, COUT, 8, false, true>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
+  conv_fwd_u_body<CIN, COUT, 8, true>(x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, wg_cap);
 }
 
 // Shapes: where the straight-line form wins on the 366 k-row level (profiles/r04c_conv_ab.txt, same box, bit-identical
@@ -203,36 +186,28 @@ static void conv_u_launch_plain(unsigned grid, hipStream_t s, const float *x, in
   if constexpr (KK == 8 && CO % 4 == 0 && CO <= 16) {
     if (conv_wide_epi_ok(epi, y, KK)) {
       SGNN_LAUNCH((k_conv_fwd_uw<CI, CO>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi,
-                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_uw<CI, CO>>() : 0);
+                  g_tune.conv_one_round ? conv_wg_capacity<k_conv_fwd_uw<CI, CO>>() : 0);
       return;
     }
   }
-  SGNN_LAUNCH((k_conv_fwd_u<CI, CO, KK, false>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift,
-              epi, g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, KK, false>>() : 0);
+  SGNN_LAUNCH((k_conv_fwd_u<CI, CO, KK>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift,
+              epi, g_tune.conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, KK>>() : 0);
 }
 
 bool sgnn_conv_u_launch(const float *x, int64_t n_in, int cin, const float *w, int K, const int32_t *table, int64_t ld,
                         int64_t n_out, int cout, float *y, int flags, int in_shift, const ConvEpi &epi, hipStream_t s) {
   const unsigned grid = (unsigned)((n_out + 255) / 256);
-#define X(CI, CO)                                                                                                        \
-  if (K == 27 && cin == CI && cout == CO) {                                                                              \
-    if (epi.pre.mean)                                                                                                    \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 27, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
-                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 27, true>>() : 0); \
-    else                                                                                                                 \
-      conv_u_launch_plain<CI, CO, 27>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);                   \
-    return true;                                                                                                         \
+#define X(CI, CO)                                                                                    \
+  if (K == 27 && cin == CI && cout == CO) {                                                          \
+    conv_u_launch_plain<CI, CO, 27>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    return true;                                                                                     \
   }
   CONV_U_CASES_27(X)
 #undef X
-#define X(CI, CO)                                                                                                        \
-  if (K == 8 && cin == CI && cout == CO) {                                                                               \
-    if (epi.pre.mean)                                                                                                    \
-      SGNN_LAUNCH((k_conv_fwd_u<CI, CO, 8, true>), dim3(grid), dim3(256), 0, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi, \
-                  g_conv_one_round ? conv_wg_capacity<k_conv_fwd_u<CI, CO, 8, true>>() : 0); \
-    else                                                                                                                 \
-      conv_u_launch_plain<CI, CO, 8>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi);                    \
-    return true;                                                                                                         \
+#define X(CI, CO)                                                                                   \
+  if (K == 8 && cin == CI && cout == CO) {                                                          \
+    conv_u_launch_plain<CI, CO, 8>(grid, s, x, n_in, w, table, ld, n_out, y, flags, in_shift, epi); \
+    return true;                                                                                    \
   }
   CONV_U_CASES_8(X)
 #undef X

@@ -478,12 +478,6 @@ SGNN_EXPORT int sgnn_rulebook_subm3_volume(const int32_t *coords, int64_t n, int
   return SGNN_OK;
 }
 
-static int g_rulebook_lds = 0;   // sgnn_rulebook_set_lds(1) selects the LDS-window kernel (parity test, A/B)
-SGNN_EXPORT int sgnn_rulebook_set_lds(int on) {
-  const int prev = g_rulebook_lds;
-  g_rulebook_lds = on ? 1 : 0;
-  return prev;
-}
 
 SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                                     const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
@@ -491,7 +485,7 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
   SGNN_CHECK_ARG(n >= 0 && ld >= n && keys && vals && cap >= 2 && (cap & (cap - 1)) == 0);
   if (n == 0) return SGNN_OK;
   SGNN_CHECK_ARG(coords && nbr);
-  if (g_rulebook_lds) {
+  if (g_tune.rulebook_lds) {
     SGNN_LAUNCH(k_rulebook_subm3_lds, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
                        vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
     SGNN_CHECK_LAUNCH();
@@ -580,13 +574,7 @@ static const ScanLimit kNoLimit{-1, nullptr, 0, nullptr};
 // compactions).  Integer sums: the offsets and counts are the scan kernel's, bit for bit.  ScanInline.nblk == 0 keeps the
 // three-launch form (block_sums already hold exclusive offsets).
 #define SCAN_INLINE_MAX 4096
-static int g_scan_inline = 1;   // sgnn_scan_set_inline: 0 = the separate scan launch everywhere (A/B measurements, parity test)
-SGNN_EXPORT int sgnn_scan_set_inline(int on) {
-  const int prev = g_scan_inline;
-  g_scan_inline = on ? 1 : 0;
-  return prev;
-}
-static inline bool scan_inline_ok(int64_t nblk) { return g_scan_inline && nblk >= 1 && nblk <= SCAN_INLINE_MAX; }
+static inline bool scan_inline_ok(int64_t nblk) { return g_tune.scan_inline && nblk >= 1 && nblk <= SCAN_INLINE_MAX; }
 
 struct ScanInline {
   int64_t nblk;      // > 0: block_sums are raw counts, this many of them
@@ -1255,12 +1243,6 @@ __global__ __launch_bounds__(256) void k_chain_tables_insert(ChainTables t, unsi
   chain_insert_rows(coarse, t.nc_dev, n_host_next, ckeys_next, owner_next, mask, slot_of_next);
 }
 
-static int g_chain_merged = 1;   // sgnn_chain_set_merged: 0 = one launch per pass (A/B measurements, parity test)
-SGNN_EXPORT int sgnn_chain_set_merged(int on) {
-  const int prev = g_chain_merged;
-  g_chain_merged = on ? 1 : 0;
-  return prev;
-}
 
 SGNN_EXPORT int64_t sgnn_down2_chain_tables_ws_bytes(int64_t cap, int depth) {
   const int64_t nblk = (cap + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -1306,7 +1288,7 @@ SGNN_EXPORT int sgnn_down2_chain_tables(const int32_t *fine_coords, const int64_
   const int64_t *n_dev = n0_dev;
   int64_t fine_cap = cap;
   const int g = sgnn_grid_for(cap, 256, 8192);
-  const bool inl = scan_inline_ok(nblk), merged = g_chain_merged != 0;
+  const bool inl = scan_inline_ok(nblk), merged = g_tune.chain_merged != 0;
   for (int l = 0; l < depth; ++l) {
     const int64_t ccap_l = level_caps[l] < cap ? level_caps[l] : cap;
     const int64_t ldc = ((ccap_l + 255) / 256) * 256, ldf = ((fine_cap + 255) / 256) * 256;

@@ -10,7 +10,6 @@
 // per stage and direction replaces ~12 Python autograd nodes and their tensor allocations.
 // Host-side code only: no kernels here.
 #include <mutex>
-#include <unordered_map>
 #include <vector>
 #include "common.h"
 
@@ -57,39 +56,10 @@ std::vector<int> count_readers(const View &v) {
   return r;
 }
 
-bool g_fuse = true;   // sgnn_prog_set_fusion: A/B switch for the epilogue fusions (tests, measurements)
-bool g_lin_add = true; // sgnn_prog_set_lin_add: a head's data gradient is added to the gradient its input already carries inside the head's kernel
-bool g_lin_bn = true; // sgnn_prog_set_lin_bn: the head's data gradient formed inside the BatchNorm backward passes (BnLin)
-// sgnn_prog_set_bn_fold(1): BatchNormReLU layers whose only reader is a convolution launch no apply pass — the convolution
-// normalises the rows in its gather (BnPre).  2 = its exact A/B reference: the same statistics (finalised in the same
-// kernel), an apply pass, the convolution on the stored rows — bit-identical results.  0 (default) = the round-3 path: the
-// apply kernel of a small level also finalises the statistics.  Measured (profiles/r04d_ab3*.txt, same box): folding all 39
-// eligible layers 6.63 vs 6.64 ms per step, folding the 9 on levels >= 40 k rows 6.61 vs 6.57 — the apply pass it removes is
-// an 8 TB/s streaming pass (8-12 us at 366 k rows) and comes back as five VALU operations per gathered value in TWO
-// gather-bound kernels (the forward convolution +4-10 us, its weight gradient), while the finalise launch stays.  Not a win:
-// built, bit-identical, tested (tests/test_gpu_bn_fold.py), off by default.
-int g_bn_fold = 0;    // 0 (default): every BatchNorm applies itself; 1: folded into the consumer's gather; 2: exact reference of 1
-int64_t g_bn_fold_min_rows = 0;           // fold only rows classes of at least this size (sgnn_prog_set_bn_fold_rows)
-// The fold decides which buffers a forward pass WRITES (a folded BatchNorm's output rows never exist) and which rows its
-// backward pass re-reads, so a forward / backward pair must agree on it whatever the switches say in between: a
-// training forward call remembers the setting it ran with under its arena's address, the backward call of that arena uses it.
-struct FoldMode {
-  int fold;
-  int64_t min_rows;
-};
-std::mutex g_fold_mu;
-std::unordered_map<const void *, FoldMode> g_fold_of_arena;
-void remember_fold(const void *arena, FoldMode m) {
-  std::lock_guard<std::mutex> hold(g_fold_mu);
-  if (g_fold_of_arena.size() > 4096) g_fold_of_arena.clear();   // arenas come and go with the allocator: bounded
-  g_fold_of_arena[arena] = m;
-}
-FoldMode fold_of(const void *arena) {
-  std::lock_guard<std::mutex> hold(g_fold_mu);
-  auto it = g_fold_of_arena.find(arena);
-  return it != g_fold_of_arena.end() ? it->second : FoldMode{g_bn_fold, g_bn_fold_min_rows};
-}
-
+// (the executor's switches live in the library's one table, sgnn_tune: prog_fusion, prog_lin_add, prog_lin_bn — tune.hip)
+#define g_fuse (g_tune.prog_fusion != 0)
+#define g_lin_add (g_tune.prog_lin_add != 0)
+#define g_lin_bn (g_tune.prog_lin_bn != 0)
 // What the executor decides once per call, identically in forward and backward:
 //  * add_dst[i] >= 0: convolution i writes straight into the output of the AddTable right behind it (fused add);
 //  * views: a JoinTable whose inputs can be produced in place gets no copy — its inputs LIVE in column ranges of the
@@ -100,21 +70,14 @@ struct Plan {
   std::vector<int> root, col;    // per buffer: storage owner and column offset inside it
   std::vector<int64_t> ld;       // per buffer: row stride in floats
   std::vector<char> join_view;   // per op: this JoinTable is in place
-  std::vector<int> bn_fold;      // per op: a BatchNorm folded into the gather of convolution bn_fold[j] (-1: applies itself)
-  std::vector<int> pre_bn;       // per op: the BatchNorm folded into this convolution's gather (-1: none)
   std::vector<int> lin_bn;       // per op: a LINEAR head whose data gradient is formed inside the backward pass of BatchNorm lin_bn[i] (BnLin; -1: written)
 };
 
-// shapes of the grouped / remapped walk the up-sampling convolution uses (conv.hip CONV_EX_CASES) with a compiled weight gradient
-inline bool expand_shape_ok(int cin, int cout) { return (cin == 48 && cout == 16) || (cin == 24 && cout == 8); }
 
-
-void make_plan(const View &v, const int32_t *keep, Plan &P, int64_t fold_min_rows = g_bn_fold_min_rows) {
+void make_plan(const View &v, const int32_t *keep, Plan &P) {
   P.add_dst.assign(v.nops, -1);
   P.skip.assign(v.nops, 0);
   P.join_view.assign(v.nops, 0);
-  P.bn_fold.assign(v.nops, -1);
-  P.pre_bn.assign(v.nops, -1);
   P.lin_bn.assign(v.nops, -1);
   P.root.resize(v.nbuf);
   P.col.assign(v.nbuf, 0);
@@ -196,33 +159,6 @@ void make_plan(const View &v, const int32_t *keep, Plan &P, int64_t fold_min_row
     P.root[o[2]] = o[3];
     P.col[o[2]] = o[6];        // cin = channels of in0
   }
-  // BatchNormReLU -> convolution: the normalise + ReLU pass moves into the convolution's gather when the convolution is the
-  // only reader of the BatchNorm output (forward: rows read once; backward: the weight gradient re-reads them the same way,
-  // the data gradient's statistics epilogue and the BatchNorm backward pass read the BatchNorm INPUT anyway)
-  // (planned whatever sgnn_prog_set_bn_fold says: with the fold switched off these layers run as its exact reference)
-  for (int j = 0; j < v.nops; ++j) {
-      const int32_t *bo = v.ops + OPW * j;
-      if (bo[0] != OP_BN) continue;
-      const int o = bo[3];
-      if (o < v.n_ext || (keep && keep[o]) || readers[o] != 1 || P.root[o] != o || last_reader[o] <= j) continue;
-      // Large levels only (the rows class runs the 256-row kernels): there the apply pass is a full read + write of the level
-      // (12-20 us at 366-600 k rows) behind a finalise launch that exists anyway.  On a small level the apply kernel finalises
-      // the statistics itself — folding would swap one launch for another (the finalise kernel) and charge the convolution and
-      // its weight gradient five VALU operations per gathered value for it: measured neutral to slightly negative
-      // (profiles/r04d_ab3b.txt), so small levels keep their apply pass.
-      if (v.lev_n && v.lev_n[bo[5]] < fold_min_rows) continue;
-      const int i = last_reader[o];
-      const int32_t *co = v.ops + OPW * i;
-      if (P.skip[i] || co[1] != o || co[6] != bo[6]) continue;
-      bool ok = false;
-      if (co[0] == OP_CONV_SUBM || co[0] == OP_CONV_DOWN)
-        ok = sgnn_conv_epi_supported(co[6], co[7]) && dw_shape_ok(co[6], co[7]);
-      else if (co[0] == OP_EXPAND)
-        ok = expand_shape_ok(co[6], co[7]);
-      if (!ok) continue;
-      P.bn_fold[j] = i;
-      P.pre_bn[i] = j;
-    }
   for (int b = 0; b < v.nbuf; ++b) {   // nested joins: resolve to the outermost storage
     int r = b, c = 0;
     while (P.root[r] != r) {
@@ -264,7 +200,6 @@ int make_layout_infer(const View &v, const Plan &P, const int32_t *keep, Layout 
     if (o[0] == OP_CONCAT_IN) touch(o[8], i);
     if (P.add_dst[i] >= 0) touch(P.add_dst[i], i);   // fused AddTable: the convolution writes the sum buffer itself
     else touch(o[3], i);
-    if (g_bn_fold == 1 && P.pre_bn[i] >= 0) touch(v.ops[OPW * P.pre_bn[i] + 1], i);   // reads the folded BatchNorm's INPUT rows
   }
   for (int b = v.n_ext; b < v.nbuf; ++b)
     if (keep && keep[b]) last[P.root[b]] = never;
@@ -481,33 +416,6 @@ SGNN_EXPORT int sgnn_prog_defer_join(int on) {
   return prev;
 }
 
-SGNN_EXPORT int sgnn_prog_set_bn_fold(int on) {
-  const int prev = g_bn_fold;
-  g_bn_fold = on < 0 ? 0 : (on > 2 ? 2 : on);
-  return prev;
-}
-
-SGNN_EXPORT int64_t sgnn_prog_set_bn_fold_rows(int64_t rows) {
-  const int64_t prev = g_bn_fold_min_rows;
-  g_bn_fold_min_rows = rows < 0 ? 0 : rows;
-  return prev;
-}
-
-SGNN_EXPORT int sgnn_prog_set_lin_bn(int on) {
-  const int prev = g_lin_bn ? 1 : 0;
-  g_lin_bn = on != 0;
-  return prev;
-}
-SGNN_EXPORT int sgnn_prog_set_lin_add(int on) {
-  const int prev = g_lin_add ? 1 : 0;
-  g_lin_add = on != 0;
-  return prev;
-}
-SGNN_EXPORT int sgnn_prog_set_fusion(int on) {
-  const int prev = g_fuse ? 1 : 0;
-  g_fuse = on != 0;
-  return prev;
-}
 
 #define PROG_TRY(call)           \
   do {                           \
@@ -554,13 +462,10 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || ext));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Plan PL;
-  const FoldMode fm{g_bn_fold, g_bn_fold_min_rows};
-  const int fold = fm.fold;
-  make_plan(v, keep, PL, fm.min_rows);
+  make_plan(v, keep, PL);
   Layout L;
   const bool infer = (training & 2) != 0;     // inference layout: no backward call may follow
   training &= 1;
-  if (!infer) remember_fold(arena, fm);
   SGNN_CHECK_ARG(make_layout(v, PL, L, infer, keep) == 0);
   if (arena_floats < L.fwd_total) {
     sgnn_set_error("sgnn_prog_forward: arena too small (%lld < %lld floats)", (long long)arena_floats,
@@ -629,16 +534,7 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         epi.ldx = LD(in0);
         epi.ldy = LD(dst_buf);
         epi.n_dev = CNT(down ? lev + 1 : lev);
-        const float *xin = B(in0);
-        if (fold == 1 && PL.pre_bn[i] >= 0) {     // the BatchNormReLU in front of this convolution lives in its gather: read the raw rows
-          const int jb = PL.pre_bn[i];
-          const int32_t *bo = ops + OPW * jb;
-          const float *save = arena + L.aux_off[jb];
-          epi.pre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
-          xin = B(bo[1]);
-          epi.ldx = LD(bo[1]);
-        }
-        PROG_TRY(sgnn_conv_fwd_impl(xin, n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
+        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, P(par), down ? 8 : 27, table, ld, n_out, cout, B(dst_buf), 0, 0, nullptr,
                                     nullptr, 1, 1, down ? 8 : 27, &epi, stream));
         break;
       }
@@ -648,11 +544,9 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       case OP_BN: {
         float *save = arena + L.aux_off[i];
-        // folded into its consumer's gather: statistics only; fold switched off: the exact A/B reference (own finalise kernel)
-        const int mode = (PL.bn_fold[i] >= 0 && fold) ? (fold == 1 ? 3 : 2) : 0;
         PROG_TRY(sgnn_bn_fwd_impl(B(in0), LD(in0), n, cin, P(par), P(par + 1), P(par + 2), P(par + 3), opf[4 * i],
                                   opf[4 * i + 1], training, opf[4 * i + 2], save, save + cin, B(out), LD(out), pre[i],
-                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev), mode));
+                                  pre_nblk[i], ws, ws_bytes, stream, CNT(lev)));
         break;
       }
       case OP_ADD:
@@ -671,23 +565,14 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
         break;
       }
       case OP_EXPAND: {   // out rows = 8 * n (child row 8p + parity), features of the parents never replicated
-        SGNN_CHECK_ARG(ROWS(out) == 8 * n && (LD(in0) == cin || (fold == 1 && PL.pre_bn[i] >= 0)) && LD(out) == cout);
+        SGNN_CHECK_ARG(ROWS(out) == 8 * n && LD(in0) == cin && LD(out) == cout);
         const int32_t *S, *ST, *PAR;
         PROG_TRY(sgnn_expand_maps(&S, &ST, &PAR));
         float *wc = arena + L.aux_off[i];
         PROG_TRY(sgnn_expand_weights(P(par), cin, cout, wc, stream));
         ConvEpi xepi{};
         xepi.n_dev = CNT(lev);
-        const float *xin = B(in0);
-        if (fold == 1 && PL.pre_bn[i] >= 0) {
-          const int jb = PL.pre_bn[i];
-          const int32_t *bo = ops + OPW * jb;
-          const float *save = arena + L.aux_off[jb];
-          xepi.pre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
-          xin = B(bo[1]);
-          xepi.ldx = LD(bo[1]);
-        }
-        PROG_TRY(sgnn_conv_fwd_impl(xin, n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
+        PROG_TRY(sgnn_conv_fwd_impl(B(in0), n, cin, wc, 8, (const int32_t *)lev_nbr[lev], lev_ld[lev], n, cout, B(out), 0,
                                     0, S, nullptr, 1, 8, 27, &xepi, stream));
         break;
       }
@@ -725,9 +610,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
                  n_ext >= 0 && n_ext <= nbuf && (n_ext == 0 || (ext && gext)));
   View v{ops, opf, nops, bufs, nbuf, n_ext, lev_n, lev_ld, lev_nbr, lev_children, lev_ptable, lev_parent, nlev};
   Plan PL;
-  const FoldMode fm = fold_of(arena);   // the fold setting of the forward call that filled this arena
-  const int fold = fm.fold;
-  make_plan(v, keep, PL, fm.min_rows);  // the same decisions the forward call took (same inputs)
+  make_plan(v, keep, PL);               // the same decisions the forward call took (same inputs)
   Layout L;
   SGNN_CHECK_ARG(make_layout(v, PL, L) == 0);
   if (arena_floats < L.total || ws_bytes < ws_need(v)) {
@@ -851,7 +734,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         // dX and dW from ONE kernel on the training stream where the shape allows (conv_bwd_fused.hip): no lane fork.  Otherwise
         // the lane forks HERE, in front of the data-gradient launch: the weight gradient runs beside the dX kernel of its layer
         bool fused_bwd = false;
-        const bool fused_try = !down && wants(in0) && g_fuse && n > 0 && !(fold == 1 && PL.pre_bn[i] >= 0) &&
+        const bool fused_try = !down && wants(in0) && g_fuse && n > 0 &&
                                sgnn_conv_epi_supported(cout, cin) && sgnn_conv_bwd_fused_ok(n, cin, cout, K);
         hipStream_t lane = fused_try ? hs : dw_lane();
         if (wants(in0)) {
@@ -905,20 +788,9 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         }
         if (!fused_bwd) {
           if (fused_try) lane = dw_lane();      // (strides the fused kernel does not take: fork late)
-          const float *xw = X(in0);
-          int64_t ldxw = LD(in0);
-          BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
-          if (fold == 1 && PL.pre_bn[i] >= 0) {       // the rows this convolution saw = BatchNormReLU of the stored rows: recomputed in the gather
-            const int jb = PL.pre_bn[i];
-            const int32_t *bo = ops + OPW * jb;
-            const float *save = arena + L.aux_off[jb];
-            bpre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
-            xw = X(bo[1]);
-            ldxw = LD(bo[1]);
-          }
-          PROG_TRY(sgnn_conv_bwd_weight_impl(xw, n, cin, ldxw, dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
+          PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, LD(in0), dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
                                              nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
-                                             (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev), &bpre));
+                                             (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev)));
         }
         dw_off += dw_slice(v, i);
         break;
@@ -1022,7 +894,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         float *dwc = side ? (float *)(dw_base + dw_off + dw_slice(v, i) - expand_dwc_bytes(cin, cout)) : garena + L.bextra;
         float *part = garena + L.bextra + round64(64 * (int64_t)cin * cout);
         const hipStream_t lane = dw_lane();
-        SGNN_CHECK_ARG(ld_dy == cout && (LD(in0) == cin || (fold == 1 && PL.pre_bn[i] >= 0)));
+        SGNN_CHECK_ARG(ld_dy == cout && LD(in0) == cin);
         if (wants(in0) && n > 0) {
           // 64 offsets per parent row, cut into G slices that run as conv groups; the slices are then added
           const int Gs = EXPAND_DX_SPLIT;
@@ -1035,19 +907,8 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           PROG_TRY(commit(in0, t));
         }
         {
-          const float *xw = X(in0);
-          int64_t ldxw = cin;
-          BnPre bpre{nullptr, nullptr, nullptr, nullptr, 0.f};
-          if (fold == 1 && PL.pre_bn[i] >= 0) {
-            const int jb = PL.pre_bn[i];
-            const int32_t *bo = ops + OPW * jb;
-            const float *save = arena + L.aux_off[jb];
-            bpre = BnPre{save, save + cin, P(bo[4]), P(bo[4] + 1), opf[4 * jb + 2]};
-            xw = X(bo[1]);
-            ldxw = LD(bo[1]);
-          }
-          PROG_TRY(sgnn_conv_bwd_weight_impl(xw, n, cin, ldxw, dy, cout, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1,
-                                             8, 27, dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane, CNT(lev), &bpre));
+          PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, cin, dy, cout, cout, nbr, lev_ld[lev], 8, n, dwc, 0, S, nullptr, 1,
+                                             8, 27, dw_base + dw_off, dw_slice(v, i), (sgnn_stream_t)lane, CNT(lev)));
         }
         dw_off += dw_slice(v, i);
         pending_expand.push_back(PendingExpand{dwc, cin, cout, PG(par)});   // dwc is final after the batched reduce

@@ -24,7 +24,6 @@ SIDE_PRIORITY = int(os.environ.get('SGNN_SIDE_PRIORITY', '0'))
 # are issued on a third stream (scratch lane 2) and joined inside sgnn_prog_forward right before the program's first
 # Convolution(2,2): they overlap the level's hash / rulebook build and its first convolutions instead of preceding them.
 SIDE_PYRAMID = os.environ.get('SGNN_SIDE_PYRAMID', '1') != '0'
-PYRAMID_REPEAT = int(os.environ.get('SGNN_DEBUG_PYRAMID_REPEAT', '0'))   # measurement only: repeat the pyramid lane's work
 PYRAMID_LANE = 2
 
 
@@ -341,24 +340,11 @@ class PendingChain(object):
                 self.side.wait_stream(torch.cuda.current_stream(dev))
             else:
                 ws = rt.workspace(wsb)
-            if PYRAMID_REPEAT:      # MEASUREMENT ONLY (scratch copies of the lane's outputs, allocated on the training stream)
-                dk, dv = [mk(self.ccap, torch.int64) for _ in range(depth)], [mk(self.ccap, torch.int32) for _ in range(depth)]
-                dp, dc = [mk(max(cap, 1), torch.int32) for _ in range(depth)], [mk((max(cap, 1), 4), torch.int32) for _ in range(depth)]
-                dch, dpt = [mk(8 * ld[l + 1], torch.int32) for l in range(depth)], [mk(8 * ld[l], torch.int32) for l in range(depth)]
-                self._dup = ([arr(dk), arr(dv), arr(dp), arr(dc), arr(dch), arr(dpt)], (dk, dv, dp, dc, dch, dpt),
-                             torch.zeros(max(depth, 1), dtype=torch.int64, device=dev))
             with (torch.cuda.stream(self.side) if self.side is not None else _nullcontext()):
                 _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth,
                           self._keep[0].ctypes.data, self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data,
                           self._keep[3].ctypes.data, ptr(counts), caps_np.ctypes.data, self._keep[4].ctypes.data,
                           self._keep[5].ctypes.data, ptr(rt.status32), ptr(ws), wsb)
-                # MEASUREMENT ONLY (SGNN_DEBUG_PYRAMID_REPEAT=n): issue the lane's work n more times into
-                # scratch copies of its outputs — what does another 0.9 ms of pyramid-lane kernels cost the step?
-                for _ in range(PYRAMID_REPEAT):
-                    a, _t, dcnt = self._dup
-                    _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth, a[0].ctypes.data,
-                              a[1].ctypes.data, self.ccap, a[2].ctypes.data, a[3].ctypes.data, ptr(dcnt), caps_np.ctypes.data,
-                              a[4].ctypes.data, a[5].ctypes.data, ptr(rt.status32), ptr(ws), wsb)
             return
         _lib.call('sgnn_down2_chain', ptr(coords_cap), 0 if n0_on_device else int(n0),
                   rt.state.data_ptr() if n0_on_device else None, cap, depth, self._keep[0].ctypes.data,
@@ -388,26 +374,17 @@ class PendingChain(object):
             assert coarse.ld * 8 == self.children[l].numel() and fine.ld * 8 == self.ptable[l].numel()
             downs.append(Down2(fine, coarse, self.parent[l][:fine.n], self.children[l], coarse.ld, self.ptable[l], fine.ld))
             fine = coarse
-        if getattr(self, '_dup', None) is not None and downs:
-            downs[0]._dup_keep = self._dup         # (measurement only) the lane still writes them: keep them as long as the tables
         if getattr(self, 'side', None) is not None:
             # the coarse levels' 3x3x3 rulebooks on the same lane (hash builder: the dense index volume belongs to the
             # training stream), then the event the consuming program waits for
             for d in downs:
                 g = d.coarse
                 g._nbr = torch.empty(27 * g.ld, dtype=torch.int32, device=g.device)        # training-stream allocation
-                if PYRAMID_REPEAT:
-                    g._nbr_dup = torch.empty(27 * g.ld, dtype=torch.int32, device=g.device)
             with torch.cuda.stream(self.side):
                 for d in downs:
                     g = d.coarse
                     _lib.call('sgnn_rulebook_subm3', ptr(g.keys), ptr(g.vals), g.cap, ptr(g.coords), g.n, ptr(g._nbr),
                               g.ld, ptr(g.cnt))
-                for _ in range(PYRAMID_REPEAT):          # measurement only, see __init__
-                    for d in downs:
-                        g = d.coarse
-                        _lib.call('sgnn_rulebook_subm3', ptr(g.keys), ptr(g.vals), g.cap, ptr(g.coords), g.n, ptr(g._nbr_dup),
-                                  g.ld, ptr(g.cnt))
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             for d in downs:

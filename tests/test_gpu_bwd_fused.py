@@ -18,15 +18,15 @@ C, K = 16, 27
 def small_levels():
     """the fused kernel serves levels >= 40 960 rows by default; let it run on test-sized levels"""
     from sgnn_amd import _lib
-    prev = _lib.query('sgnn_conv_set_bwd_fused_rows', 256)
-    prev_on = _lib.query('sgnn_conv_set_bwd_fused', 1)
+    prev = _lib.tune('conv_bwd_fused_rows', 256)
+    prev_on = _lib.tune('conv_bwd_fused', 1)
     # ... and hold it against the 256-row kernel it shares its walk with (k_conv_small, which test-sized levels would get,
     # sums the offsets in another order)
-    prev_small = _lib.query('sgnn_conv_set_small_rows', 0)
+    prev_small = _lib.tune('conv_small_rows', 0)
     yield
-    _lib.query('sgnn_conv_set_small_rows', prev_small)
-    _lib.query('sgnn_conv_set_bwd_fused', prev_on)
-    _lib.query('sgnn_conv_set_bwd_fused_rows', prev)
+    _lib.tune('conv_small_rows', prev_small)
+    _lib.tune('conv_bwd_fused', prev_on)
+    _lib.tune('conv_bwd_fused_rows', prev)
 
 
 def _level(batch, dim, occ, seed, surface=True):
@@ -209,7 +209,7 @@ def test_training_step_with_and_without_the_fused_kernel(small_levels):
     lw = np.ones(5, dtype=np.float32)
     outs = []
     for on in (1, 0):
-        prev = _lib.query('sgnn_conv_set_bwd_fused', on)
+        prev = _lib.tune('conv_bwd_fused', on)
         try:
             m = param_fill(GenModel(8, dims, 1, 16, 16, 4, True, True, 1, 1), cfg).train().cuda()
             t = L.compute_targets(data['sdf'].clone().cuda(), [h.clone().cuda() for h in data['hierarchy']], 4, 3, True,
@@ -230,7 +230,7 @@ def test_training_step_with_and_without_the_fused_kernel(small_levels):
             lib.sgnn_prof_disable()
             outs.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()}, kinds.count(2)))
         finally:
-            _lib.query('sgnn_conv_set_bwd_fused', prev)
+            _lib.tune('conv_bwd_fused', prev)
     (la, ga, na), (lb, gb, nb) = outs
     assert na > 0 and nb == 0, 'fused launches: %d with the switch on, %d with it off' % (na, nb)
     assert la == lb

@@ -147,7 +147,7 @@ def test_epilogue_rejects_uncompiled_shapes():
 
 @pytest.mark.parametrize('cin,cout', [(16, 16), (26, 16)])
 def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
-    """Large levels run as ONE round of workgroups, each taking J consecutive 256-row tiles (sgnn_conv_set_one_round,
+    """Large levels run as ONE round of workgroups, each taking J consecutive 256-row tiles (sgnn_tune.conv_one_round,
     k_conv_fwd / k_conv_fwd_u).  Against one tile per workgroup on a level large enough for J = 2: output rows bit-identical
     (same arithmetic per row), BatchNorm statistics equal to fp64 round-off (the partial rows are grouped differently), and
     the partial blocks past the live workgroups hold exact zeros."""
@@ -165,7 +165,7 @@ def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
     lib = _lib.load()
 
     def run(one_round):
-        prev = lib.sgnn_conv_set_one_round(one_round)
+        prev = _lib.tune('conv_one_round', one_round)
         try:
             y = torch.empty(n, cout, device=DEV)
             partial = torch.full((nblk, 2, cout), float('nan'), dtype=torch.float64, device=DEV)
@@ -173,7 +173,7 @@ def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
                       y.data_ptr(), cout, 0, None, 0, 1, partial.data_ptr(), None, 0, None, None, None, None, 0.0)
             torch.cuda.synchronize()
         finally:
-            lib.sgnn_conv_set_one_round(prev)
+            _lib.tune('conv_one_round', prev)
         return y, partial
     y1, p1 = run(1)
     y0, p0 = run(0)
@@ -189,7 +189,7 @@ def test_one_round_tiling_gives_the_same_rows_and_statistics(cin, cout):
 
 @pytest.mark.parametrize('c', [16, 8, 12])
 def test_wide_epilogue_is_bit_identical_and_falls_back_on_odd_strides(c):
-    """Round 5: the wide (quad-transposed, 16-byte) epilogue of the 256-row kernels (sgnn_conv_set_wide_epi) against the
+    """Round 5: the wide (quad-transposed, 16-byte) epilogue of the 256-row kernels (sgnn_tune.conv_wide_epi) against the
     element-wise one — forward with residual + statistics and data gradient with in-place accumulation + BatchNorm-backward
     statistics: rows AND fp64 statistics partials bit-identical (the arithmetic stays in the MFMA layout); with a row stride
     that is not a multiple of four floats the dispatcher must fall back to the element-wise form by itself."""
@@ -220,13 +220,13 @@ def test_wide_epilogue_is_bit_identical_and_falls_back_on_odd_strides(c):
                   gamma.data_ptr() if stats == 2 else None, beta.data_ptr() if stats == 2 else None, 0.0)
         return y, part
 
-    prev = lib.sgnn_conv_set_wide_epi(1)
+    prev = _lib.tune('conv_wide_epi', 1)
     try:
         for ldy, col0 in ((c, 0), (c + 8, 4), (c + 1, 0), (c + 3, 2)):       # aligned, aligned view, odd strides (fallback)
             for stats, fl in ((1, 0), (2, flags)):
-                lib.sgnn_conv_set_wide_epi(0)
+                _lib.tune('conv_wide_epi', 0)
                 y0, p0 = run(ldy, col0, stats, fl)
-                lib.sgnn_conv_set_wide_epi(1)
+                _lib.tune('conv_wide_epi', 1)
                 y1, p1 = run(ldy, col0, stats, fl)
                 assert torch.equal(y0, y1), (ldy, col0, stats)
                 assert torch.equal(p0, p1), (ldy, col0, stats)
@@ -235,4 +235,4 @@ def test_wide_epilogue_is_bit_identical_and_falls_back_on_odd_strides(c):
                     want = F_.conv_fwd_raw(x, c, w, 27, tab, g.ld, n, c) + add
                     assert torch.equal(y1[:, col0:col0 + c], want)
     finally:
-        lib.sgnn_conv_set_wide_epi(prev)
+        _lib.tune('conv_wide_epi', prev)

@@ -1,9 +1,9 @@
 """Round 5 launch fusions of the geometry / glue kernels (csrc/grid_rules.hip): every one of them has a switch, and the
 switch must not change a single bit of any table, site list or count —
 
-* sgnn_scan_set_inline      the write kernels of the compactions / stride-2 levels sum the raw block counts themselves
+* sgnn_tune.scan_inline      the write kernels of the compactions / stride-2 levels sum the raw block counts themselves
                             (no scan launch between the count and the write kernel);
-* sgnn_chain_set_merged     tables pass of level l + hash insertion of level l + 1 in one launch;
+* sgnn_tune.chain_merged     tables pass of level l + hash insertion of level l + 1 in one launch;
 * SGNN_FUSED_GLUE / functions.FUSED_GLUE   kept coordinates written by the compaction's write kernel, children and
                             their int64 rows in one pass;
 * SGNN_VOLUME_ONLY / metadata.VOLUME_ONLY  generated levels build their 3x3x3 rulebook from the dense index volume alone
@@ -40,7 +40,7 @@ def test_compaction_with_locs_equals_compaction_plus_gather(keep_cap):
     K = min(keep_cap, n_cap)
     results = []
     for inline in (1, 0):
-        prev = lib.sgnn_scan_set_inline(inline)
+        prev = L.tune('scan_inline', inline)
         try:
             for fused in (True, False):
                 sel = torch.full((n_cap,), -7, dtype=torch.int32, device=dev)
@@ -59,7 +59,7 @@ def test_compaction_with_locs_equals_compaction_plus_gather(keep_cap):
                 kept = int(cnt2[0])
                 results.append((sel[:want_all.shape[0]].clone(), locs[:kept].clone(), cnt2.clone(), int(status[0])))
         finally:
-            lib.sgnn_scan_set_inline(prev)
+            L.tune('scan_inline', prev)
     total = int(want_all.shape[0])
     for sel, locs, cnt2, status in results:
         assert torch.equal(sel.cpu(), want_all.cpu())
@@ -168,13 +168,14 @@ def test_capacity_forward_is_bit_identical_with_the_fusions_off():
     from test_gpu_capacity import _batch, _model, _classic, _capped
     from sgnn_amd.scn.capacity import Capacity
     from sgnn_amd.scn import functions as F_
+    from sgnn_amd import _lib as L
     lib = _lib()
     lw = np.ones(5, dtype=np.float32)
     batch = _batch(3)
     _, _, _, log = _classic(_model(), batch, lw)
     runs = []
     for on in (True, False):
-        prev = (lib.sgnn_scan_set_inline(int(on)), lib.sgnn_chain_set_merged(int(on)), F_.FUSED_GLUE)
+        prev = (L.tune('scan_inline', int(on)), L.tune('chain_merged', int(on)), F_.FUSED_GLUE)
         F_.FUSED_GLUE = on
         try:
             m = _model()
@@ -185,8 +186,8 @@ def test_capacity_forward_is_bit_identical_with_the_fusions_off():
             grads = [p.grad.clone() for p in m.parameters()]
             runs.append((osdf, oocc, loss.detach().clone(), live, grads))
         finally:
-            lib.sgnn_scan_set_inline(prev[0])
-            lib.sgnn_chain_set_merged(prev[1])
+            L.tune('scan_inline', prev[0])
+            L.tune('chain_merged', prev[1])
             F_.FUSED_GLUE = prev[2]
     from sgnn_amd.scn.capacity import trim
     (sa, oa, la, lva, ga), (sb, ob, lb, lvb, gb) = runs

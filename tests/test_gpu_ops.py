@@ -214,12 +214,12 @@ def test_lds_window_rulebook_equals_global_probe_rulebook(order):
         coords = F_.expand8_coords(coords)
     tabs = []
     for on in (1, 0):
-        prev = lib.sgnn_rulebook_set_lds(on)
+        prev = _lib.tune('rulebook_lds', on)
         try:
             g = Grid(coords)
             tabs.append(g.subm_table().clone())
         finally:
-            lib.sgnn_rulebook_set_lds(prev)
+            _lib.tune('rulebook_lds', prev)
     assert torch.equal(tabs[0], tabs[1])
     assert int((tabs[0].view(27, -1)[:, :coords.shape[0]] >= 0).sum()) > 27 * coords.shape[0] // 4
 

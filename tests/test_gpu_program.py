@@ -43,11 +43,11 @@ def _run(enabled, train=True):
 @pytest.mark.parametrize('train,fused', [(True, True), (True, False), (False, True)])
 def test_program_path_equals_layer_path(train, fused):
     from sgnn_amd import _lib
-    prev = _lib.load().sgnn_prog_set_fusion(int(fused))
+    prev = _lib.tune('prog_fusion', int(fused))
     try:
         ma, sa, oa, la = _run(True, train)
     finally:
-        _lib.load().sgnn_prog_set_fusion(prev)
+        _lib.tune('prog_fusion', prev)
     mb, sb, ob, lb = _run(False, train)
     tol = 3e-5 if (fused and train) else 1e-6
     assert ma.encoder._sparse_program() is not None

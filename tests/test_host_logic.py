@@ -394,13 +394,13 @@ def test_sgnn_tune_calls_the_named_switches_and_rejects_anything_else():
     import subprocess
     import sys
     code = ("from sgnn_amd import _lib; lib = _lib.load(); "
-            "print(lib.sgnn_conv_set_one_round(1), lib.sgnn_conv_set_dw_blocks(256), lib.sgnn_prog_set_lin_bn(1))")
-    env = dict(os.environ, SGNN_TUNE='sgnn_conv_set_one_round=0,sgnn_conv_set_dw_blocks=341,sgnn_prog_set_lin_bn=0')
+            "print(_lib.tune('conv_one_round', 1), _lib.tune('conv_dw_blocks', 256), _lib.tune('prog_lin_bn', 1))")
+    env = dict(os.environ, SGNN_TUNE='conv_one_round=0,conv_dw_blocks=341,prog_lin_bn=0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == ['0', '341', '0']          # the setters return what SGNN_TUNE had installed
     # not a switch; unknown; a *_set_* entry point that takes pointers; a value that is not an integer
-    for bad in ('sgnn_conv_fwd=1', 'no_such_switch=1', 'sgnn_prog_set_side_stream=1', 'sgnn_conv_set_one_round=on'):
+    for bad in ('sgnn_conv_fwd=1', 'no_such_switch=1', 'sgnn_prog_set_side_stream=1', 'conv_one_round=on'):
         env = dict(os.environ, SGNN_TUNE=bad)
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
         assert out.returncode != 0 and 'SgnnError' in out.stderr and 'SGNN_TUNE' in out.stderr, (bad, out.stderr[-500:])

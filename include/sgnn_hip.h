@@ -49,7 +49,8 @@ extern "C" {
 #define SGNN_ENOWS (-4)     /* workspace too small */
 
 /* status bits written (atomically OR-ed) into the device `status` word */
-#define SGNN_STATUS_COORD_RANGE 1 /* a coordinate was outside the supported range */
+#define SGNN_STATUS_COORD_RANGE 1 /* a coordinate was outside the supported range ([0, 65535], batch [0, 32767]) — or, from
+                                   * sgnn_rulebook_subm3_volume, outside the volume bounds the caller declared */
 #define SGNN_STATUS_DUPLICATE 2   /* InputLayer(mode=0) saw the same site twice */
 #define SGNN_STATUS_OVERFLOW 4    /* capacity mode: a level produced more rows than its buffers hold (step discarded) */
 

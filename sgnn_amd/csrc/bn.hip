@@ -292,31 +292,63 @@ struct BnFuse {
 // Per-channel totals of the block partials, computed by the whole workgroup: 256/c threads share a channel (strided
 // partial sums), their pieces are added in thread order — a fixed order, identical in every workgroup.
 // tot[0..c) = sum_a, tot[c..2c) = sum_b;  scratch: 512 doubles.  Contains two barriers.
+// Round 6: what this costs is the NUMBER of dependent load rounds, ~0.75 us each (the table was written by the producing
+// kernel's workgroups on all eight XCDs: every first touch misses this XCD's L2) — 6 rounds for the 684 16-row partials of a
+// 11 k-row level with one 8-byte load per value and 8 blocks in flight (k_bn_apply 7.4 us there against 4.5 us on a 60 k-row
+// level with 236 partials).  Even channel counts read two channels per 16-byte load and keep 32 loads in flight: the same
+// table in 2 rounds.  The kernels that call this are the FUSE instantiations (small levels only), so the 64 + 64 registers
+// cost the streaming instantiations nothing.  Any fixed order is a valid order: deterministic per (nblk, c).
+#ifndef BN_TOTALS_WIDE
+#define BN_TOTALS_WIDE 1     // 0: the one-value-per-load form everywhere (scripts/build_variant.sh A/B builds)
+#endif
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bn_fuse_totals(const BnFuse &f, int c, double *scratch, double *tot) {
   const int tid = threadIdx.x;
   const int tpc = 256 / c;                       // >= 4 for c <= BN_FUSE_MAXC
-  const int ch = tid % c, part = tid / c;
-  double a = 0.0, b = 0.0;
-  if (part < tpc)
-    // eight independent loads in flight per thread (the table is L2-resident; a load -> add chain would pay one L2
-    // round trip per block partial); the additions keep their order, missing entries add an exact 0.0
-    for (int blk = part; blk < f.nblk; blk += 8 * tpc) {
-      double va[8], vb[8];
+  if (BN_TOTALS_WIDE && (c & 1) == 0 && (((uintptr_t)f.partial) & 15) == 0) {
+    // thread = (part, which, channel pair): sums `which` (0: sum_a, 1: sum_b) of channels 2 p, 2 p + 1 over blocks part, part + tpc, ...
+    const int hp = c >> 1;
+    const int p2 = tid % hp, which = (tid / hp) & 1, part = tid / c;
+    f64x2 acc = {0.0, 0.0};
+    if (part < tpc) {
+      constexpr int U = 32;
+      for (int blk = part; blk < f.nblk; blk += U * tpc) {
+        f64x2 v[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int bi = blk + u * tpc;
-        const bool ok = bi < f.nblk;
-        va[u] = ok ? f.partial[((size_t)bi * 2 + 0) * c + ch] : 0.0;
-        vb[u] = ok ? f.partial[((size_t)bi * 2 + 1) * c + ch] : 0.0;
-      }
+        for (int u = 0; u < U; ++u) {
+          const int bi = blk + u * tpc;
+          v[u] = bi < f.nblk ? *reinterpret_cast<const f64x2 *>(f.partial + ((size_t)bi * 2 + which) * c + 2 * p2) : f64x2{0.0, 0.0};
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        a += va[u];
-        b += vb[u];
+        for (int u = 0; u < U; ++u) acc += v[u];
       }
+      scratch[which * 256 + part * c + 2 * p2] = acc[0];
+      scratch[which * 256 + part * c + 2 * p2 + 1] = acc[1];
     }
-  scratch[tid] = a;
-  scratch[256 + tid] = b;
+  } else {
+    const int ch = tid % c, part = tid / c;
+    double a = 0.0, b = 0.0;
+    if (part < tpc) {
+      // eight independent loads in flight per thread; the additions keep their order, missing entries add an exact 0.0
+      for (int blk = part; blk < f.nblk; blk += 8 * tpc) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bi = blk + u * tpc;
+          const bool ok = bi < f.nblk;
+          va[u] = ok ? f.partial[((size_t)bi * 2 + 0) * c + ch] : 0.0;
+          vb[u] = ok ? f.partial[((size_t)bi * 2 + 1) * c + ch] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a += va[u];
+          b += vb[u];
+        }
+      }
+      scratch[part * c + ch] = a;
+      scratch[256 + part * c + ch] = b;
+    }
+  }
   __syncthreads();
   if (tid < c) {
     double s1 = 0.0, s2 = 0.0;
@@ -332,7 +364,7 @@ __device__ __forceinline__ void bn_fuse_totals(const BnFuse &f, int c, double *s
 
 // Thread mapping of the apply passes = the one of the statistics pass: a thread owns one column group (VEC channels, its
 // constants live in registers) and walks rows row0 + i*step, BN_U rows in flight; ldx / ldy = row strides (floats).
-template <int VEC>
+template <int VEC, bool FUSE>
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t ldx, int64_t n, int c, int cq,
                                                  int rpb, const float *__restrict__ mean,
                                                  const float *__restrict__ invstd,
@@ -344,7 +376,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   n = sgnn_dyn_n(n, n_dev);
   if (n <= 0) return;        // capacity mode, empty level (whole grid: no barrier is skipped by a part of a workgroup)
-  if (fuse.partial) {
+  if constexpr (FUSE) {
     bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
       const double s1 = s_tot[ch], s2 = s_tot[c + ch];
@@ -418,7 +450,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_bwd(const double *__restric
   }
 }
 
-template <int VEC, bool LIN = false>
+template <int VEC, bool LIN, bool FUSE>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, int64_t ldx,
                                                      const float *__restrict__ dy, int64_t ld_dy, int64_t n, int c,
                                                      int cq, int rpb, const float *__restrict__ mean,
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
   __shared__ float s_coef[2 * BN_FUSE_MAXC];
   __shared__ double s_scratch[512], s_tot[2 * BN_FUSE_MAXC];
   n = sgnn_dyn_n(n, n_dev);
-  if (fuse.partial) {
+  if constexpr (FUSE) {
     bn_fuse_totals(fuse, c, s_scratch, s_tot);
     for (int ch = threadIdx.x; ch < c; ch += 256) {
       const double s1 = s_tot[ch], s2 = s_tot[c + ch];
@@ -574,12 +606,14 @@ int sgnn_bn_fwd_impl(const float *x, int64_t ldx, int64_t n, int c, const float 
   if (n > 0) {
     SGNN_CHECK_ARG(x && y);
     const int grid = bn_apply_grid(n, g);
-    if (g.vec == 4)
-      SGNN_LAUNCH((k_bn_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
-                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
-    else
-      SGNN_LAUNCH((k_bn_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,
-                         (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev);
+#define BN_APPLY(VECV, FUSEV)                                                                                 \
+  SGNN_LAUNCH((k_bn_apply<VECV, FUSEV>), dim3(grid), dim3(256), 0, s, x, ldx, n, c, g.cq, g.rpb,              \
+              (const float *)save_mean, (const float *)save_invstd, gamma, beta, leak, y, ldy, fuse, n_dev)
+    if (g.vec == 4 && fuse.partial) BN_APPLY(4, true);
+    else if (g.vec == 4) BN_APPLY(4, false);
+    else if (fuse.partial) BN_APPLY(1, true);
+    else BN_APPLY(1, false);
+#undef BN_APPLY
   }
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
@@ -683,18 +717,16 @@ int sgnn_bn_bwd_impl(const float *x, int64_t ldx, const float *dy, int64_t ld_dy
   else
     SGNN_LAUNCH(k_bn_finalize_bwd, dim3(c), dim3(256), 0, s, partial, (int)nblk, n, c, dgamma, dbeta, coef, n_dev);
   const int grid = bn_apply_grid(n, g);
-  if (lin && g.vec == 4)
-    SGNN_LAUNCH((k_bn_bwd_apply<4, true>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, *lin);
-  else if (lin)
-    SGNN_LAUNCH((k_bn_bwd_apply<1, true>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, *lin);
-  else if (g.vec == 4)
-    SGNN_LAUNCH((k_bn_bwd_apply<4>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, BnLin{});
-  else
-    SGNN_LAUNCH((k_bn_bwd_apply<1>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean,
-                       save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev, BnLin{});
+#define BN_BWD_APPLY(VECV, LINV, FUSEV)                                                                                       \
+  SGNN_LAUNCH((k_bn_bwd_apply<VECV, LINV, FUSEV>), dim3(grid), dim3(256), 0, s, x, ldx, dy, ld_dy, n, c, g.cq, g.rpb, save_mean, \
+              save_invstd, gamma, beta, leak, training, (const float *)coef, dx, ld_dx, fuse, addend, ld_add, n_dev,              \
+              LINV ? *lin : BnLin{})
+  const bool fz = fuse.partial != nullptr;
+  if (lin && g.vec == 4) { if (fz) BN_BWD_APPLY(4, true, true); else BN_BWD_APPLY(4, true, false); }
+  else if (lin) { if (fz) BN_BWD_APPLY(1, true, true); else BN_BWD_APPLY(1, true, false); }
+  else if (g.vec == 4) { if (fz) BN_BWD_APPLY(4, false, true); else BN_BWD_APPLY(4, false, false); }
+  else { if (fz) BN_BWD_APPLY(1, false, true); else BN_BWD_APPLY(1, false, false); }
+#undef BN_BWD_APPLY
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -29,8 +29,11 @@ SGNN_EXPORT int64_t sgnn_hash_capacity(int64_t n) {
   // LENGTH of the longest probe sequence in a wave — every step of it one more dependent memory round trip (1.5-2 us) — not
   // the table's cache footprint.  k_rulebook_subm3 on 2.5 k / 9 k / 33 k rows: 19.0 / 18.6 / 21.8 -> 13.5 / 11.1 / 12.5 us
   // (round 5; rocprofv3, isolated launches).  What remains is the chain coords -> keys -> values -> walk -> stores itself.
+  // Monotone in n (a table sized from an upper bound must never be smaller than one sized from a live count):
+  // target = max(2 n, min(4 n, 262 144)) — 4 n below 64 k sites as measured, flat at 256 k slots up to 128 k, 2 n beyond.
+  const int64_t want = 4 * n < 262144 ? 4 * n : (2 * n > 262144 ? 2 * n : 262144);
   int64_t cap = 1024;
-  while (cap < (n < 65536 ? 4 : 2) * n) cap <<= 1;
+  while (cap < want) cap <<= 1;
   return cap;
 }
 

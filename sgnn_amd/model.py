@@ -60,6 +60,17 @@ def _k4s2_maps():
 
 K4S2_TAPS, K4S2_NBR = _k4s2_maps()
 K4S2_SLOT = [K4S2_TAPS.index(t) for t in range(64)]     # slot of tap (kz*4+ky)*4+kx
+_K4S2_INDEX = {}
+
+
+def _k4s2_index(which, device):
+    """K4S2_TAPS / K4S2_SLOT as an index tensor on `device`, built once per device (torch.tensor(list, device=...) is a
+    synchronous pageable H2D copy: a host sync per layer, and illegal inside a stream capture — ADVICE r5)."""
+    key = (which, str(device))
+    t = _K4S2_INDEX.get(key)
+    if t is None:
+        t = _K4S2_INDEX[key] = torch.tensor(K4S2_TAPS if which == 'taps' else K4S2_SLOT, device=device)
+    return t
 # 8 parity groups on the coarse rulebook (default) / 0: the 64-tap walk over the fine rows (A/B measurements, parity test)
 DENSE_PARITY = os.environ.get('SGNN_DENSE_PARITY', '1') != '0'
 
@@ -89,13 +100,13 @@ class DenseConv(nn.Module):
         perm = (2, 3, 4, 0, 1) if self.transposed else (2, 3, 4, 1, 0)
         w = w.permute(*perm).reshape(self.k ** 3, self.cin, self.cout)
         if self.parity_order:
-            w = w[torch.tensor(K4S2_TAPS, device=w.device)]
+            w = w[_k4s2_index('taps', w.device)]
         return w.contiguous()
 
     def to_torch(self, w):       # (K, Cin, Cout) -> torch layout
         k = self.k
         if self.parity_order:
-            w = w[torch.tensor(K4S2_SLOT, device=w.device)]
+            w = w[_k4s2_index('slot', w.device)]
         w = w.reshape(k, k, k, self.cin, self.cout)
         return (w.permute(3, 4, 0, 1, 2) if self.transposed else w.permute(4, 3, 0, 1, 2)).contiguous()
 
@@ -275,7 +286,7 @@ class _DenseGeometry(object):
                 raise ValueError('dense level dims %s are not even' % (fd,))
             cd = [d // 2 for d in fd]
             dev, B = self.device, self.batch
-            taps = torch.tensor(K4S2_TAPS, device=dev)
+            taps = _k4s2_index('taps', dev)
             kz, ky, kx = (taps // 16).view(64, 1), ((taps // 4) % 4).view(64, 1), (taps % 4).view(64, 1)
 
             def unravel(n, d):
@@ -347,7 +358,7 @@ def _dense_conv(rows, conv, tables, down):
             wk = w.permute(2, 3, 4, 1, 0).reshape(64, w.shape[1], w.shape[0])
         else:        # nn.ConvTranspose3d (Cin, Cout, 4,4,4) -> (64 taps, Cin, Cout)
             wk = w.permute(2, 3, 4, 0, 1).reshape(64, w.shape[0], w.shape[1])
-        wk = wk[torch.tensor(K4S2_TAPS, device=w.device)]
+        wk = wk[_k4s2_index('taps', w.device)]
     return F_.DenseK4S2.apply(rows, wk, tables, bool(down), DENSE_PARITY)
 
 

@@ -108,7 +108,8 @@ class _Runtime(object):
             self.state[1] = 0
             msgs = []
             if status & 1:
-                msgs.append('coordinate outside [0,65535] (batch outside [0,32767])')
+                msgs.append('coordinate outside [0,65535] (batch outside [0,32767]), or — a level whose rulebook is read off the '
+                            'dense index volume alone — a site outside the bounds the level declared')
             if status & 2:
                 msgs.append('InputLayer(mode=0): duplicate coordinates are a caller error')
             if status & 4 and not (status & 3):

@@ -2,6 +2,8 @@
 synthetic data layout."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -404,3 +406,49 @@ def test_sgnn_tune_calls_the_named_switches_and_rejects_anything_else():
         env = dict(os.environ, SGNN_TUNE=bad)
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd=ROOT)
         assert out.returncode != 0 and 'SgnnError' in out.stderr and 'SGNN_TUNE' in out.stderr, (bad, out.stderr[-500:])
+
+
+def test_hash_capacity_is_monotone_and_keeps_its_load_factors():
+    """a table sized from an upper bound must never be smaller than one sized from a live count (n = 65 535 used to
+    get 262 144 slots, n = 65 536 only 131 072).  Load factor <= 0.25 below 64 k sites, <= 0.5 everywhere; power of two."""
+    from sgnn_amd import _lib
+    prev = 0
+    for n in list(range(0, 3000, 7)) + list(range(60000, 140000, 251)) + [65535, 65536, 131071, 131072, 131073, 10 ** 6, 10 ** 7]:
+        cap = _lib.query('sgnn_hash_capacity', n)
+        assert cap & (cap - 1) == 0 and cap >= 1024
+        assert cap >= 2 * n and (n >= 65536 or cap >= 4 * n)
+    for n in sorted(set(list(range(0, 300000, 997)) + [65535, 65536, 65537, 131072, 131073])):
+        cap = _lib.query('sgnn_hash_capacity', n)
+        assert cap >= prev, (n, cap, prev)
+        prev = cap
+
+
+def test_tune_table_sets_reads_and_rejects():
+    """include/sgnn_hip.h struct sgnn_tune: every field settable by name, booleans normalised, ranges enforced, unknown names
+    raise; the struct the header documents is the table the library exports (field count and order)."""
+    import ctypes
+    import re
+    from sgnn_amd import _lib
+    lib = _lib.load()
+    names = lib.sgnn_tune_names().decode().split(',')
+    header = open(os.path.join(ROOT, 'include', 'sgnn_hip.h')).read()
+    body = re.sub(r'/\*.*?\*/', '', header[header.index('typedef struct sgnn_tune {'):header.index('} sgnn_tune;')], flags=re.S)
+    assert re.findall(r'int64_t\s+(\w+);', body) == names
+    cur = ctypes.cast(lib.sgnn_tune_current(), ctypes.POINTER(ctypes.c_int64 * len(names))).contents
+    for i, n in enumerate(names):
+        assert _lib.tune(n) == cur[i]
+    prev = _lib.tune('conv_dw_blocks', 341)
+    try:
+        assert _lib.tune('conv_dw_blocks') == 341 and cur[names.index('conv_dw_blocks')] == 341
+        with pytest.raises(_lib.SgnnError):
+            _lib.tune('conv_dw_blocks', 0)
+        assert _lib.tune('conv_dw_blocks') == 341
+    finally:
+        _lib.tune('conv_dw_blocks', prev)
+    p = _lib.tune('prog_fusion', 7)
+    assert _lib.tune('prog_fusion') == 1
+    _lib.tune('prog_fusion', p)
+    with pytest.raises(_lib.SgnnError):
+        _lib.tune('no_such_switch', 1)
+    with pytest.raises(_lib.SgnnError):
+        _lib.tune('no_such_switch')

@@ -82,7 +82,8 @@ def check_grads_vs_fp64_fixture(g, grads, what, report=None):
     every gradient upstream of it by per cent (genmodel_train_rect: the reference's own fp32 run is 1.5 % from its exact
     value in the 2-norm and up to 4.8 % on a tensor; genmodel_train_32 / _empty: 1e-5).  So the yardstick is the
     reference's own distance, per tensor and per fixture:
-      every tensor    <= max(3 e_ref + 5e-3, 1.25 x the reference's worst tensor of this fixture)
+      every tensor    <= max(3 e_ref + 5e-3, 1.25 x the reference's worst tensor of this fixture) where its own e_ref >= 1e-3,
+                      <= max(3 e_ref + 5e-3, 1e-2) where the reference's fp32 run is within 1e-3 itself
       97 % of them    <= 2 e_ref + 1e-3        (fixtures where the reference's fp32 run has no flip: worst e_ref < 2e-3)
       90 % of them    <= 3 e_ref + 5e-3        (fixtures where it has)
       whole vector    2-norm distance <= 2 x the reference's + 1e-3
@@ -107,7 +108,11 @@ def check_grads_vs_fp64_fixture(g, grads, what, report=None):
     l2, l2_ref = (d2 / n2) ** 0.5, float(g['grad_eref_l2'])
     tight = [r for r in rows if r[0] > 2 * r[1] + 1e-3]
     wide = [r for r in rows if r[0] > 3 * r[1] + 5e-3]
-    hard = [r for r in rows if r[0] > max(3 * r[1] + 5e-3, 1.25 * e_worst)]
+    # the 1.25 x e_worst allowance covers tensors downstream of a mask flip in the reference's OWN fp32 run (their e_ref is
+    # large); a tensor the reference gets right to 1e-3 is held to 1e-2 whatever the fixture's worst tensor is
+    def hard_bar(eo):
+        return max(3 * eo + 5e-3, 1.25 * e_worst) if eo >= 1e-3 else max(3 * eo + 5e-3, 1e-2)
+    hard = [r for r in rows if r[0] > hard_bar(r[1])]
     if report is not None:
         report('    %s: gradient vector 2-norm distance from fp64 %.3e (reference fp32: %.3e); %d of %d tensors over 2 e_ref + '
                '1e-3, %d over 3 e_ref + 5e-3; reference fp32 worst tensor %.3e' % (what, l2, l2_ref, len(tight), total,

@@ -124,7 +124,7 @@ typedef struct sgnn_tune {
   int64_t conv_dw_c1;
   /* 1 = sgnn_prog_backward runs 16-channel 3x3x3 layers on levels of >= conv_bwd_fused_rows rows through the fused backward
    * kernel (sgnn_conv_bwd_fused: dX and dW from one gather of dy).  dX rows bit-identical, dW another fixed summation
-   * order.  Default 0: 0.95x the two kernels stand-alone, slower in the step (profiles/r06_fused_backward.txt). */
+   * order.  Default 0: 0.95x the two kernels stand-alone, +0.04 .. +0.14 ms per step (profiles/r06_fused_backward.txt). */
   int64_t conv_bwd_fused;
   int64_t conv_bwd_fused_rows;   /* >= 256.  Default 40 960. */
   /* 1 = the 3x3x3 rulebook builder hashes the voxel index of a 768-row window around each 256-row tile into LDS (global
@@ -306,8 +306,8 @@ int sgnn_conv_bwd_weight(const float *x, int64_t n_in, int cin, const float *dy,
  * sgnn_conv_fwd_epi(flags = TRANSPOSE_W | FLIP_K).  Served shapes: sgnn_conv_bwd_fused_supported (cin = cout = 16, K = 27,
  * levels of at least sgnn_tune.conv_bwd_fused_rows rows, default 40 960); others return SGNN_EINVAL.  Row strides multiples of
  * 4 floats, bases 16-byte aligned.  n_dev: capacity mode (NULL = n is exact).  sgnn_tune.conv_bwd_fused = 1 makes
- * sgnn_prog_backward use it (default 0: stand-alone it is 0.95x the two kernels it replaces, beside the weight-gradient
- * lane's kernels it loses — profiles/r06_fused_backward.txt); set it before the first step (workspace sizes follow it). */
+ * sgnn_prog_backward use it (default 0: stand-alone it is 0.95x the two kernels it replaces, in the step it costs
+ * +0.04 .. +0.14 ms — profiles/r06_fused_backward.txt); set it before the first step (workspace sizes follow it). */
 int64_t sgnn_conv_bwd_fused_ws_bytes(int64_t n, int cin, int cout);
 int sgnn_conv_bwd_fused_supported(int64_t n, int cin, int cout, int K);
 int sgnn_conv_bwd_fused(const float *dy, int64_t n, int cout, int64_t ld_dy, const float *x, int cin, int64_t ldx,

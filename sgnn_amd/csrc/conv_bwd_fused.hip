@@ -22,11 +22,10 @@
 // waves per SIMD (108 + 16 accumulators).
 //
 // Measured (profiles/r06_fused_backward.txt), 366 k rows: 131 us against 62 (dX with its backward epilogue) + 77 (dW + reduce)
-// = 0.95x the two kernels, dX rows bit-identical, dW to fp32 summation order.  In the step it LOSES: 5.76 -> 6.55 ms with the
-// six launches of >= 40 960 rows fused, although the summed convolution time falls — a workgroup needs a free 256-register
-// slot on all four SIMDs of a CU, the weight-gradient lane's kernels (the layers that cannot be fused) keep every CU partly
-// occupied, and the launch waits for them and then runs at half residency.  With nothing beside it (no lane) it is worth its
-// stand-alone ratio (6.82 -> 6.77 ms).  sgnn_prog_backward therefore uses it only on request (sgnn_conv_set_bwd_fused(1)).
+// = 0.95x the two kernels, dX rows bit-identical, dW to fp32 summation order.  In the step: 5.78 -> 5.93 ms with the six
+// launches of >= 40 960 rows fused, 5.83 with only the two of the 450 k-row level — the summed convolution time falls
+// (5.13 -> 4.73 ms) but the launch puts twice the MFMA work on the training stream and takes work off a lane that was hiding
+// it.  sgnn_prog_backward therefore uses it only on request (sgnn_tune.conv_bwd_fused = 1).
 #include "common.h"
 
 #include "conv_common.h"
@@ -395,7 +394,14 @@ int sgnn_conv_bwd_fused_impl(const float *dy, int64_t n, int cout, const float *
               (float *)ws, (int)pblocks);
   sgnn_prof_end_launch(prof, s);
   SGNN_CHECK_LAUNCH();
-  return sgnn_dw_reduce_or_defer((const float *)ws, dw, pblocks, (int64_t)FUSED_K * cin * cout, s);
+  // The reduce runs HERE, on the caller's stream, not in the program's deferred batch on the weight-gradient lane: that batch
+  // would need one more cross-stream edge per program (lane waits for the training stream's last kernel), and such an edge
+  // costs a replayed step 0.15 ms apiece (profiles/r06l_ab_endfork.txt: +0.75 ms for five of them with no kernel moved).
+  DwBatch *const batch = sgnn_dw_batch;
+  sgnn_dw_batch = nullptr;
+  const int rc = sgnn_dw_reduce_or_defer((const float *)ws, dw, pblocks, (int64_t)FUSED_K * cin * cout, s);
+  sgnn_dw_batch = batch;
+  return rc;
 }
 
 SGNN_EXPORT int64_t sgnn_conv_bwd_fused_ws_bytes(int64_t n, int cin, int cout) { return sgnn_conv_bwd_fused_ws(n, cin, cout); }

@@ -676,7 +676,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
   std::unique_lock<std::mutex> lane_lock(g_side_mu, std::try_to_lock);
   const bool side = lane_lock.owns_lock() && g_side.stream && g_side.stream != hs && g_side.ws &&
                     g_side.ws_bytes >= dw_ws_need(v);
-  bool forked = false, fused_any = false;
+  bool forked = false;
   auto dw_lane = [&]() -> hipStream_t {
     if (!side) return hs;
     (void)hipEventRecord(g_side.fork, hs);                 // dy of this op is final here (all its consumers ran)
@@ -731,8 +731,12 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
         const int64_t ld_f = down ? lev_ld[lev + 1] : lev_ld[lev];
         const int32_t *tab_b = (const int32_t *)(down ? lev_ptable[lev] : lev_nbr[lev]);
         const int flags_b = down ? SGNN_CONV_TRANSPOSE_W : (SGNN_CONV_TRANSPOSE_W | SGNN_CONV_FLIP_K);
-        // dX and dW from ONE kernel on the training stream where the shape allows (conv_bwd_fused.hip): no lane fork.  Otherwise
-        // the lane forks HERE, in front of the data-gradient launch: the weight gradient runs beside the dX kernel of its layer
+        // dX and dW from ONE kernel on the training stream where the shape allows and sgnn_tune.conv_bwd_fused asks for it
+        // (conv_bwd_fused.hip; its reduce runs on the training stream too): no lane fork.  Otherwise the lane forks HERE, in
+        // front of the data-gradient launch: the weight gradient runs beside the dX kernel of its layer.
+        // (Never make the lane wait for a LATER kernel of the training stream: one such edge per program — no kernel moved —
+        //  costs a replayed step +0.75 ms, profiles/r06l_ab_endfork.txt; every variant of round 3-6 that re-timed the forks lost
+        //  0.8-0.9 ms the same way.)
         bool fused_bwd = false;
         const bool fused_try = !down && wants(in0) && g_fuse && n > 0 &&
                                sgnn_conv_epi_supported(cout, cin) && sgnn_conv_bwd_fused_ok(n, cin, cout, K);
@@ -769,7 +773,6 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
             if (fused_bwd) {
               PROG_TRY(sgnn_conv_bwd_fused_impl(dy, n, cout, P(par), tab_b, lev_ld[lev], cin, G(in0), epi, X(in0), LD(in0),
                                                 PG(par), dw_base + dw_off, dw_slice(v, i), stream));
-              fused_any = true;
             } else {
               PROG_TRY(sgnn_conv_fwd_impl(dy, n_dy, cout, P(par), K, tab_b, lev_ld[lev], n, cin, G(in0), flags_b, 0, nullptr,
                                           nullptr, 1, 1, K, &epi, stream));
@@ -958,7 +961,6 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
       PROG_TRY(sgnn_fill32(G(b), 0u, L.buf_floats[b], hs));
   }
   {
-    if (side && fused_any) (void)dw_lane();           // the lane's reduce also reads partials the training stream wrote
     const hipStream_t lane = side ? g_side.stream : hs;
     PROG_TRY(sgnn_dw_batch_flush(&batch, lane));      // all deferred weight-gradient reduces: one launch
     for (const PendingExpand &pe : pending_expand)

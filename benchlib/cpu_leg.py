@@ -5,7 +5,7 @@ bounded sample of the same workload.
 How it uses "all cores": the step's BatchNorm statistics, rulebook builds and glue are serial sections between OpenMP
 regions, so ONE step does not scale past ~16 threads (round 3: 12.6 blocks/s at 16 threads, 1.95 at 128).  The reference
 parallelises over samples; the unit that is independent end to end here is a REPLICA — a step over its own blocks with its own
-BatchNorm statistics, exactly the partitioning the multi-GPU run uses.  The all-cores figure therefore
+BatchNorm statistics, exactly the partitioning the multi-GPU run uses (HISTORY.md section 6).  The all-cores figure therefore
 runs R = cores / T replicas side by side (T threads each, pinned to disjoint cores, idle OpenMP threads sleeping) and reports
 the aggregate blocks/s.  Measured on the 2 x 64-core EPYC 9575F of the GPU boxes (profiles/r04j_cpu_leg.txt): the aggregate
 saturates at ~20 blocks/s from 8 replicas on (4 x 32 threads 16.0, 8 x 16: 18.5, 16 x 8: 19.9, 32 x 4: 20.1) while every

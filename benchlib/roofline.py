@@ -9,7 +9,7 @@ from . import HBM_PEAK_GBS, FP32_MFMA_PEAK_TF
 
 
 def conv_alg_bytes(kind, n_out, cin, cout, K):
-    """Algorithmic HBM bytes of one conv launch: feature slab read once, output written once, the
+    """Algorithmic HBM bytes of one conv launch (HISTORY.md section 4): feature slab read once, output written once, the
     K x n_out int32 rule table, the weights.  The weight gradient reads x and dy and writes K*cin*cout: the same count."""
     b = 4 * n_out * (cin + cout) + 4 * K * n_out + 4 * K * cin * cout
     if kind == 2:      # fused backward (csrc/conv_bwd_fused.hip): dy read, dx written, + the layer's input rows read, dW written

@@ -1,5 +1,5 @@
 """BatchNorm kernel timings per level size (forward = partial + finalize + apply, backward = partial + finalize +
-apply), with their HBM roofline: forward 12*N*C algorithmic bytes, backward 20*N*C."""
+apply), with their HBM roofline: forward 12*N*C algorithmic bytes, backward 20*N*C (HISTORY.md §4)."""
 import os
 import sys
 

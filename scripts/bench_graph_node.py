@@ -1,6 +1,6 @@
 """What does one dependent, near-empty kernel cost inside a replayed HIP graph — without a profiler attached?
 
-DESIGN.md §4d argues from a same-box A/B (39 launches fewer, step unchanged) that the 4-5 us such kernels show in a
+HISTORY.md §4d argues from a same-box A/B (39 launches fewer, step unchanged) that the 4-5 us such kernels show in a
 rocprofv3 trace are mostly the profiler's.  This measures the thing directly: a captured chain of N dependent launches of the
 library's smallest kernel (sgnn_add over 256 floats, in place, so every launch depends on the one before), replayed R times,
 wall clock / (R * N); the same chain issued eagerly on the stream for comparison.  Usage (GPU box):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# LDS counters of the weight-gradient and forward kernels on the 420 k-row level (evidence for DESIGN.md 4b).
+# LDS counters of the weight-gradient and forward kernels on the 420 k-row level (evidence for HISTORY.md 4b).
 export TMPDIR=/tmp; ROOT=$(pwd); OUT=$ROOT/gpurun_out/r04q_pmc_dw.txt; : > $OUT
 for pass in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   D=/tmp/pmc_$RANDOM; rm -rf $D

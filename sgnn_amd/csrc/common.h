@@ -39,7 +39,7 @@ struct ConvEpi {
   const float *mean, *invstd, *gamma, *beta;
   float leak;
   // capacity mode: the output row count lives in device memory (*n_dev, clamped to the n_out the launch was sized
-  // for); NULL = the host value is exact.  Lets a whole training step be captured in a HIP graph.
+  // for); NULL = the host value is exact.  Lets a whole training step be captured in a HIP graph (HISTORY.md §2).
   const int64_t *n_dev;
 };
 

@@ -31,24 +31,9 @@
 #include "conv_common.h"
 
 #define FUSED_K 27
-#ifndef FUSED_ABL
-#define FUSED_ABL 0      // measurement builds only (scripts/build_variant.sh): 1 no dW MFMAs, 2 no transposition of the gathered tile,
-#endif                   // 4 no gathers, 8 no dX MFMAs, 16 no x-tile reads  (wrong results, timing only)
 #define FUSED_TSTRIDE 296                    // floats per 16-row tile image in the transposition buffer
 #define FUSED_TB (4 * FUSED_TSTRIDE)         // per wave
 
-#ifdef FUSED_TRACE   // measurement builds only: s_memtime stamps of workgroup FUSED_TRACE's wave 0 (scripts/trace_fused.py)
-__device__ unsigned long long g_fused_trace[512];
-#define FUSED_STAMP(i)                                                                                    \
-  do {                                                                                                    \
-    if (blockIdx.x == (FUSED_TRACE) && tid == 0 && (i) < 512) g_fused_trace[i] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-extern "C" __attribute__((visibility("default"))) int sgnn_debug_fused_trace(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_trace), sizeof(g_fused_trace));
-}
-#else
-#define FUSED_STAMP(i) do { } while (0)
-#endif
 
 // float offset of channel-phase j's 64-float image inside a tile image (skew: see the header comment)
 __device__ __forceinline__ constexpr int fused_img(int j) { return j * 64 + (j & 1) * 8 + (j >> 1) * 32; }
@@ -68,7 +53,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  FUSED_STAMP(0);
   if (epi.n_dev) n_out = sgnn_dyn_n(n_out, epi.n_dev);
   // one round of workgroups, as k_conv_fwd: every live workgroup takes J consecutive 256-row tiles
   int J = 1;
@@ -115,22 +99,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   double s1[1] = {0.0}, s2[1] = {0.0};
   conv_epi_wide_constants<C>(ecst, epi, epi.stats);
   conv_stage_weights<C, C>(wl, w, K, 0, K, true, true);                 // W[26 - k]^T as wl[k][n][c] (contains the barriers)
-  FUSED_STAMP(1);
 
-  auto load_idx = [&](int k) -> int32_t {
-    if constexpr (FUSED_ABL & 32) return (int32_t)lane_off + k;
-    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0);
-  };
+  auto load_idx = [&](int k) -> int32_t { return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_t, lane_off, k * ld4, 0); };
   auto gather = [&](int32_t iv, float(&a)[M][V]) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const int32_t id = (FUSED_ABL & 32) ? iv + m : __builtin_amdgcn_ds_bpermute(perm[m], iv);
-      if constexpr (FUSED_ABL & 4) {
-#pragma unroll
-        for (int s = 0; s < V; ++s) a[m][s] = __int_as_float(id + s);
-      } else {
-        buf_load_floats<V>(rs_g, (uint32_t)id * ldg4 + (uint32_t)(q * V * 4), a[m]);
-      }
+      const int32_t id = __builtin_amdgcn_ds_bpermute(perm[m], iv);
+      buf_load_floats<V>(rs_g, (uint32_t)id * ldg4 + (uint32_t)(q * V * 4), a[m]);
     }
   };
   auto load_b = [&](int kk, float(&b)[V]) {   // B fragment of the data-gradient product: W[26 - kk]^T, one ds_read_b128
@@ -183,7 +158,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       lane_off = (uint32_t)(row0 + lane) * 4u;
     }
     EpiRows<M> erows;
-    FUSED_STAMP(2 + j * 32);
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the wave's own rows of the convolution's INPUT, transposed once per tile into the wave's x buffer:
@@ -195,7 +169,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         buf_load_floats<V>(rs_x, (uint32_t)(row0 + m * 16 + r) * ldx4 + (uint32_t)(q * V * 4), xr[m]);
       tr_write(xw_wr, xr);
     }
-    FUSED_STAMP(3 + j * 32);
     // three register sets: rows gathered TWO offsets ahead of their MFMAs.  With two waves per SIMD the gathers in flight per
     // CU, not the texture path's rate, bound the walk (one offset ahead: 131 us at 366 k rows, profiles/r06b_fused.txt)
     float a0[M][V], a1[M][V], a2[M][V];
@@ -208,58 +181,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (every phase fenced for the machine scheduler: left alone it groups the dW MFMAs into dependent runs and reads the
     //  transposed tiles piecewise right in front of their use, behind an lgkmcnt(0).  The transposed 16-row tiles t[m] / xa[m]
     //  are read back two phases ahead of their MFMAs, two of each live at a time)
-#define TR_READ_T(mm)                                                                  \
-  do {                                                                                 \
-    if constexpr (FUSED_ABL & 2) {                                                     \
-      t[mm][0] = a[mm][3]; t[mm][1] = a[mm][2]; t[mm][2] = a[mm][1]; t[mm][3] = a[mm][0]; \
-    } else {                                                                           \
-      tr_read(tw_rd, mm, t[mm]);                                                       \
-    }                                                                                  \
-  } while (0)
-#define TR_READ_X(mm)                                                                  \
-  do {                                                                                 \
-    if constexpr (FUSED_ABL & 16) {                                                    \
-      xa[mm][0] = b[3]; xa[mm][1] = b[2]; xa[mm][2] = b[1]; xa[mm][3] = b[0];          \
-    } else {                                                                           \
-      tr_read(xw_rd, mm, xa[mm]);                                                      \
-    }                                                                                  \
-  } while (0)
     auto stage = [&](int k, f32x4 &ad, float(&a)[M][V]) {
       float b[V], t[M][4], xa[M][4];
       load_b(k, b);
-      if constexpr (!(FUSED_ABL & 2)) tr_write(tw_wr, a);
-      TR_READ_T(0);
-      TR_READ_X(0);
-      TR_READ_T(1);
-      TR_READ_X(1);
+      tr_write(tw_wr, a);
+      tr_read(tw_rd, 0, t[0]);
+      tr_read(xw_rd, 0, xa[0]);
+      tr_read(tw_rd, 1, t[1]);
+      tr_read(xw_rd, 1, xa[1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        if constexpr (!(FUSED_ABL & 8)) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][0], b[0], acc[m][0], 0, 0, 0);
-        else acc[m][0][0] += a[m][0] + b[0];
-      }
+      for (int m = 0; m < M; ++m) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][0], b[0], acc[m][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 1; s < V; ++s) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          if constexpr (!(FUSED_ABL & 1)) ad = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s - 1][m], t[s - 1][m], ad, 0, 0, 0);
-          else ad[m] += xa[s - 1][m] + t[s - 1][m];
-          if constexpr (!(FUSED_ABL & 8)) acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][0], 0, 0, 0);
-          else acc[m][0][s] += a[m][s] + b[s];
+          ad = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s - 1][m], t[s - 1][m], ad, 0, 0, 0);
+          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][0], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < M) {
-          TR_READ_T(s + 1);
-          TR_READ_X(s + 1);
+          tr_read(tw_rd, s + 1, t[s + 1]);
+          tr_read(xw_rd, s + 1, xa[s + 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (!(FUSED_ABL & 1)) ad = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3][i], t[3][i], ad, 0, 0, 0);
-        else ad[i] += xa[3][i] + t[3][i];
-      }
+      for (int i = 0; i < 4; ++i) ad = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3][i], t[3][i], ad, 0, 0, 0);
     };
 
     static_assert(K % 3 == 0, "the walk rotates three register sets");
@@ -269,7 +218,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (kk + 5 < K) iv2 = load_idx(kk + 5);
       __builtin_amdgcn_sched_barrier(0);
       stage(kk, accd[kk], a0);
-      FUSED_STAMP(4 + j * 32 + kk);
       __builtin_amdgcn_sched_barrier(0);
       if (kk + 3 < K) {
         gather(iv3, a0);                                   // rows of offset kk + 3
@@ -277,7 +225,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       __builtin_amdgcn_sched_barrier(0);
       stage(kk + 1, accd[kk + 1], a1);
-      FUSED_STAMP(5 + j * 32 + kk);
       __builtin_amdgcn_sched_barrier(0);
       if (kk + 4 < K) {
         gather(iv4, a1);                                   // rows of offset kk + 4
@@ -290,15 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       __builtin_amdgcn_sched_barrier(0);
       stage(kk + 2, accd[kk + 2], a2);
-      FUSED_STAMP(6 + j * 32 + kk);
       __builtin_amdgcn_sched_barrier(0);
     }
     conv_epi_wide_finish<C, M>(acc, erows, row0, n_out, dx, epi, epi.stats, ecst, s1, s2, dy);
-    FUSED_STAMP(31 + j * 32);
   }
-  FUSED_STAMP(500);
   conv_epilogue_stats<C, 1>(s1, s2, epi, epi.stats, sred, blockIdx.x);
-  FUSED_STAMP(501);
 
   // the workgroup's weight-gradient partial: the four waves in fixed order through LDS (the weight tile is dead)
   __syncthreads();
@@ -322,7 +265,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int k = e >> 8;
     dw_out[(K - 1 - k) * (C * C) + (e & 255)] = red[e];   // walk offset k used weight slice 26 - k
   }
-  FUSED_STAMP(502);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

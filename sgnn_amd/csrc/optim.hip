@@ -4,7 +4,7 @@
 // torch's fused multi-tensor Adam needs 8 launches for SG-NN's 307 parameter tensors and a host-side list walk;
 // here the 643 735 parameters live in one buffer (train.FlatAdam re-points every nn.Parameter at a view of it), so
 // the update is a single HBM stream: 4 reads + 3 writes of 2.6 MB.  Two things make the launch graph-capturable
-// with the rest of the step (capacity mode):
+// with the rest of the step (HISTORY.md §2, capacity mode):
 //   * segments — the flat buffer is cut into [begin, end) ranges (encoder, each generative stage); a segment is
 //     updated only if it was reached this step (its stage had at least one input site: *cnt > 0, or the
 //     all-reduced flag > 0 under data parallelism).  This is torch.optim.Adam's "skip parameters whose grad is None"

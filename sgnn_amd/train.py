@@ -698,7 +698,7 @@ class GraphStep(object):
             import warnings
             warnings.warn('GPU_MAX_HW_QUEUES=%d: with more than 4 hardware queues two concurrently active branches of the '
                           'replayed step (training chain / side lane) were measured to share one hardware pipe on MI355X — '
-                          '17-19 ms instead of 6 ms per step (DESIGN.md section 5a).  Leave it at the default of 4.' % hwq)
+                          '17-19 ms instead of 6 ms per step (HISTORY.md section 5a).  Leave it at the default of 4.' % hwq)
 
     # -- pieces --------------------------------------------------------------------------------------------
     @staticmethod
@@ -945,7 +945,7 @@ class GraphStep(object):
 
     def _capture_kw(self):
         """SGNN_CAPTURE_PRIORITY=-1: capture on a high-priority stream (kernel nodes inherit it), so that the critical chain
-        wins CU arbitration against the weight-gradient lane.  Measured: no effect on this ROCm."""
+        wins CU arbitration against the weight-gradient lane.  Measured: no effect on this ROCm (HISTORY.md 5a)."""
         pr = int(os.environ.get('SGNN_CAPTURE_PRIORITY', '0'))
         if pr == 0:
             return {}

@@ -1,4 +1,4 @@
-"""Inference layout of the program executor (sgnn_prog_forward with training | 2; DESIGN.md section 2, INTEGRATION.md
+"""Inference layout of the program executor (sgnn_prog_forward with training | 2; HISTORY.md section 2, INTEGRATION.md
 "Inference memory"): when nothing asks for a gradient, the buffers of a program share storage by liveness, all programs of
 a device share ONE arena and the outputs are copied out.  The arithmetic is the training layout's: outputs must be
 bit-identical, in eval and in training mode, and results of an earlier call must survive later calls."""

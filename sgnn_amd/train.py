@@ -943,16 +943,6 @@ class GraphStep(object):
                           'parameter update was applied' % (index, self._n_issued - 1 - index))
         return redo
 
-    def _capture_kw(self):
-        """SGNN_CAPTURE_PRIORITY=-1: capture on a high-priority stream (kernel nodes inherit it), so that the critical chain
-        wins CU arbitration against the weight-gradient lane.  Measured: no effect on this ROCm (HISTORY.md 5a)."""
-        pr = int(os.environ.get('SGNN_CAPTURE_PRIORITY', '0'))
-        if pr == 0:
-            return {}
-        if getattr(self, '_cap_stream', None) is None:
-            self._cap_stream = torch.cuda.Stream(device=self.static['sdf'].device, priority=pr)
-        return {'stream': self._cap_stream}
-
     def _capture(self, loss_weights):
         from .scn.metadata import runtime
         dev = self.static['sdf'].device
@@ -960,19 +950,19 @@ class GraphStep(object):
         torch.cuda.synchronize(dev)
         if self.grad_sync is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **self._capture_kw()):
+            with torch.cuda.graph(g):
                 loss, losses, _ = self._fwd_bwd(loss_weights)
                 self._opt_step(loss_weights, rt)
             self.graphs = (g,)
         else:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, **self._capture_kw()):
+            with torch.cuda.graph(g1):
                 loss, losses, _ = self._fwd_bwd(loss_weights)
                 cnts = self._seg_cnts(loss_weights)
                 active = self._active_segments(loss_weights)
                 zero = self.capacity.counts[SLOT_ZERO:SLOT_ZERO + 1]
                 self.opt.write_flags([(c if a else zero) for c, a in zip(cnts, active)], rt.status32)
-            with torch.cuda.graph(g2, pool=g1.pool(), **self._capture_kw()):
+            with torch.cuda.graph(g2, pool=g1.pool()):
                 self.opt.merge_overflow(rt.status32)
                 self._opt_step(loss_weights, rt)
             self.graphs = (g1, g2)

@@ -131,6 +131,9 @@ typedef struct sgnn_tune {
    * table only for neighbours not found there); 0 = the global-probe kernel, faster on MI355X (96.7 vs 123.9 us at N =
    * 366 k).  Identical tables.  Default 0. */
   int64_t rulebook_lds;
+  /* sgnn_rulebook_subm3_multi: 1 = all levels in one pre-fill launch and one builder launch, 0 = one sgnn_rulebook_subm3
+   * per level.  Identical tables.  Default 1. */
+  int64_t rulebook_multi;
   /* compactions / stride-2 levels: 1 = the write kernels sum the (<= 4096) raw block counts themselves, 0 = a scan launch
    * between the count and the write kernel.  Identical results.  Default 1. */
   int64_t scan_inline;
@@ -164,6 +167,16 @@ const sgnn_tune *sgnn_tune_current(void);
 int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, int64_t cap,
                         const int32_t *coords, int64_t n, int32_t *nbr, int64_t ld,
                         const int64_t *n_dev, sgnn_stream_t stream);
+
+/* `count` <= SGNN_RULEBOOK_MULTI_MAX such rulebooks in one pair of launches (capacity mode: every n_devs[i] != NULL):
+ * the coarse levels of one hierarchy (scn.InputLayer + the Convolution(2,2) chain, torch/model.py:228-236) have
+ * 0.4 k - 40 k rows each and their single launches are mostly ramp.  Each array holds one entry per level with the
+ * meaning of the matching sgnn_rulebook_subm3 argument; table i equals sgnn_rulebook_subm3's for level i entry by
+ * entry.  Levels with ns[i] == 0 are skipped. */
+#define SGNN_RULEBOOK_MULTI_MAX 4
+int sgnn_rulebook_subm3_multi(int count, const uint64_t *const *keys, const int32_t *const *vals, const int64_t *caps,
+                              const int32_t *const *coords, const int64_t *ns, int32_t *const *nbrs, const int64_t *lds,
+                              const int64_t *const *n_devs, sgnn_stream_t stream);
 
 /* The same table through a dense index volume (volume[((b*Z + z)*Y + y)*X + x] = row, -1 elsewhere): one coalesced
  * 4-byte read per neighbour instead of a hash probe.  `volume` is a persistent workspace of volume_entries int32 that

@@ -29,6 +29,7 @@ PROTOTYPES = {
     'sgnn_hash_build': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_hash_lookup': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_rulebook_subm3': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'sgnn_rulebook_subm3_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'sgnn_rulebook_subm3_dense': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'sgnn_rulebook_subm3_volume': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'sgnn_down2_ws_bytes': (c_i64, [c_i64]),
@@ -174,6 +175,7 @@ def load():
 
 
 TUNE_UNKNOWN = -(1 << 63)
+RULEBOOK_MULTI_MAX = 4      # SGNN_RULEBOOK_MULTI_MAX of include/sgnn_hip.h
 
 
 def tune(name, value=None):

@@ -187,12 +187,9 @@ __global__ __launch_bounds__(256) void k_fill_rows_dyn(int32_t *__restrict__ t, 
 // also writes its mirror entry (unique writer per entry, no atomics).  Rows 14..26 are pre-filled with -1.
 // Probes are the cost (random L2 lines); the direct per-offset stores are coalesced 256-B runs.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restrict__ keys,
-                                                       const int32_t *__restrict__ vals, uint64_t mask,
-                                                       const int4 *__restrict__ coords, int64_t n,
-                                                       int32_t *__restrict__ nbr, int64_t ld, const int64_t *n_dev) {
-  n = sgnn_dyn_n(n, n_dev);
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void rulebook_subm3_site(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                                    uint64_t mask, const int4 *__restrict__ coords, int64_t n,
+                                                    int32_t *__restrict__ nbr, int64_t ld, int64_t j) {
   if (j >= pad_end(n, ld)) return;
   if (j >= n) {  // padding entries: the conv kernels rely on them being -1 (rows 14..26 come from the memset)
 #pragma unroll
@@ -234,6 +231,52 @@ __global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restri
     if (r[k] >= 0) nbr[(int64_t)(26 - k) * ld + r[k]] = (int32_t)j;
   }
   nbr[(int64_t)13 * ld + j] = (int32_t)j;
+}
+
+__global__ __launch_bounds__(256) void k_rulebook_subm3(const uint64_t *__restrict__ keys,
+                                                       const int32_t *__restrict__ vals, uint64_t mask,
+                                                       const int4 *__restrict__ coords, int64_t n,
+                                                       int32_t *__restrict__ nbr, int64_t ld, const int64_t *n_dev) {
+  rulebook_subm3_site(keys, vals, mask, coords, sgnn_dyn_n(n, n_dev), nbr, ld, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Several levels in one launch (the coarse levels of one hierarchy: 2-3 rulebooks of 0.4 k - 40 k rows each, whose launches
+// are mostly ramp): the descriptor table travels by value in the kernel arguments, workgroup -> level by the block prefix.
+// The site body is the single-level kernel's, so the tables are the same entries.
+struct RbMulti {
+  const uint64_t *keys[SGNN_RULEBOOK_MULTI_MAX];
+  const int32_t *vals[SGNN_RULEBOOK_MULTI_MAX];
+  const int4 *coords[SGNN_RULEBOOK_MULTI_MAX];
+  int32_t *nbr[SGNN_RULEBOOK_MULTI_MAX];
+  const int64_t *n_dev[SGNN_RULEBOOK_MULTI_MAX];
+  uint64_t mask[SGNN_RULEBOOK_MULTI_MAX];
+  int64_t n[SGNN_RULEBOOK_MULTI_MAX], ld[SGNN_RULEBOOK_MULTI_MAX];
+  unsigned blk0[SGNN_RULEBOOK_MULTI_MAX + 1];        // first workgroup of level i; blk0[count] = grid
+  int count;
+};
+
+__device__ __forceinline__ int rb_multi_level(const RbMulti &b, unsigned blk) {
+  int i = 0;
+#pragma unroll
+  for (int q = 1; q < SGNN_RULEBOOK_MULTI_MAX; ++q) i += (q < b.count && blk >= b.blk0[q]) ? 1 : 0;
+  return i;
+}
+
+// rows 14..26 of every level := -1 over the live (padded) range — the mirror writes of the builder land there
+__global__ __launch_bounds__(256) void k_fill_rows_dyn_multi(RbMulti b) {
+  const int i = rb_multi_level(b, blockIdx.x);
+  const int64_t ld = b.ld[i];
+  const int64_t end = pad_end(sgnn_dyn_n(b.n[i], b.n_dev[i]), ld);
+  int32_t *t = b.nbr[i] + 14 * ld;
+  const int64_t total = end * 13, stride = (int64_t)(b.blk0[i + 1] - b.blk0[i]) * 256;
+  for (int64_t g = (int64_t)(blockIdx.x - b.blk0[i]) * 256 + threadIdx.x; g < total; g += stride)
+    t[(g / end) * ld + (g % end)] = -1;
+}
+
+__global__ __launch_bounds__(256) void k_rulebook_subm3_multi(RbMulti b) {
+  const int i = rb_multi_level(b, blockIdx.x);
+  rulebook_subm3_site(b.keys[i], b.vals[i], b.mask[i], b.coords[i], sgnn_dyn_n(b.n[i], b.n_dev[i]), b.nbr[i], b.ld[i],
+                      (int64_t)(blockIdx.x - b.blk0[i]) * 256 + threadIdx.x);
 }
 
 // (Round 5: a 26-probe variant — every entry written by the site's own thread, no mirror scatter, no pre-fill launch of
@@ -501,6 +544,53 @@ SGNN_EXPORT int sgnn_rulebook_subm3(const uint64_t *keys, const int32_t *vals, i
     if (sgnn_fill32(nbr + 14 * ld, 0xFFFFFFFFu, 13 * ld, (hipStream_t)stream) != SGNN_OK) return SGNN_EHIP;
   SGNN_LAUNCH(k_rulebook_subm3, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      keys, vals, (uint64_t)(cap - 1), (const int4 *)coords, n, nbr, ld, n_dev);
+  SGNN_CHECK_LAUNCH();
+  return SGNN_OK;
+}
+
+SGNN_EXPORT int sgnn_rulebook_subm3_multi(int count, const uint64_t *const *keys, const int32_t *const *vals,
+                                          const int64_t *caps, const int32_t *const *coords, const int64_t *ns,
+                                          int32_t *const *nbrs, const int64_t *lds, const int64_t *const *n_devs,
+                                          sgnn_stream_t stream) {
+  SGNN_CHECK_ARG(count >= 0 && count <= SGNN_RULEBOOK_MULTI_MAX);
+  if (count == 0) return SGNN_OK;
+  SGNN_CHECK_ARG(keys && vals && caps && coords && ns && nbrs && lds && n_devs);
+  if (!g_tune.rulebook_multi || g_tune.rulebook_lds) {
+    for (int i = 0; i < count; ++i) {
+      SGNN_CHECK_ARG(ns[i] == 0 || n_devs[i]);
+      const int rc = sgnn_rulebook_subm3(keys[i], vals[i], caps[i], coords[i], ns[i], nbrs[i], lds[i], n_devs[i], stream);
+      if (rc != SGNN_OK) return rc;
+    }
+    return SGNN_OK;
+  }
+  RbMulti fill{}, rb{};
+  unsigned fblk = 0, rblk = 0;
+  int m = 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t n = ns[i], ld = lds[i], cap = caps[i];
+    SGNN_CHECK_ARG(n >= 0 && ld >= n && keys[i] && vals[i] && cap >= 2 && (cap & (cap - 1)) == 0);
+    if (n == 0) continue;
+    SGNN_CHECK_ARG(coords[i] && nbrs[i] && n_devs[i]);       // capacity-mode entry: every level carries its device count
+    fill.nbr[m] = rb.nbr[m] = nbrs[i];
+    fill.n[m] = rb.n[m] = n;
+    fill.ld[m] = rb.ld[m] = ld;
+    fill.n_dev[m] = rb.n_dev[m] = n_devs[i];
+    rb.keys[m] = keys[i];
+    rb.vals[m] = vals[i];
+    rb.mask[m] = (uint64_t)(cap - 1);
+    rb.coords[m] = (const int4 *)coords[i];
+    fill.blk0[m] = fblk;
+    rb.blk0[m] = rblk;
+    fblk += (unsigned)sgnn_grid_for(13 * n, 256, 4096);
+    rblk += (unsigned)((ld + 255) / 256);
+    ++m;
+  }
+  if (m == 0) return SGNN_OK;
+  fill.blk0[m] = fblk;
+  rb.blk0[m] = rblk;
+  fill.count = rb.count = m;
+  SGNN_LAUNCH(k_fill_rows_dyn_multi, dim3(fblk), dim3(256), 0, (hipStream_t)stream, fill);
+  SGNN_LAUNCH(k_rulebook_subm3_multi, dim3(rblk), dim3(256), 0, (hipStream_t)stream, rb);
   SGNN_CHECK_LAUNCH();
   return SGNN_OK;
 }

@@ -16,6 +16,7 @@ sgnn_tune g_tune = {
     /* conv_bwd_fused      */ 0,
     /* conv_bwd_fused_rows */ 40960,
     /* rulebook_lds        */ 0,
+    /* rulebook_multi      */ 1,
     /* scan_inline         */ 1,
     /* chain_merged        */ 1,
     /* prog_fusion         */ 1,
@@ -41,6 +42,7 @@ const Field kFields[] = {
     {"conv_bwd_fused", &sgnn_tune::conv_bwd_fused, 0, 1, true},
     {"conv_bwd_fused_rows", &sgnn_tune::conv_bwd_fused_rows, 256, (int64_t)1 << 36, false},
     {"rulebook_lds", &sgnn_tune::rulebook_lds, 0, 1, true},
+    {"rulebook_multi", &sgnn_tune::rulebook_multi, 0, 1, true},
     {"scan_inline", &sgnn_tune::scan_inline, 0, 1, true},
     {"chain_merged", &sgnn_tune::chain_merged, 0, 1, true},
     {"prog_fusion", &sgnn_tune::prog_fusion, 0, 1, true},

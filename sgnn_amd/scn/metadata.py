@@ -382,10 +382,13 @@ class PendingChain(object):
                 g = d.coarse
                 g._nbr = torch.empty(27 * g.ld, dtype=torch.int32, device=g.device)        # training-stream allocation
             with torch.cuda.stream(self.side):
-                for d in downs:
-                    g = d.coarse
-                    _lib.call('sgnn_rulebook_subm3', ptr(g.keys), ptr(g.vals), g.cap, ptr(g.coords), g.n, ptr(g._nbr),
-                              g.ld, ptr(g.cnt))
+                for i in range(0, len(downs), _lib.RULEBOOK_MULTI_MAX):
+                    gs = [d.coarse for d in downs[i:i + _lib.RULEBOOK_MULTI_MAX]]
+                    arr = [np.array(v, dtype=np.int64) for v in (
+                        [ptr(g.keys) for g in gs], [ptr(g.vals) for g in gs], [g.cap for g in gs],
+                        [ptr(g.coords) for g in gs], [g.n for g in gs], [ptr(g._nbr) for g in gs], [g.ld for g in gs],
+                        [ptr(g.cnt) for g in gs])]
+                    _lib.call('sgnn_rulebook_subm3_multi', len(gs), *[a.ctypes.data for a in arr])
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             for d in downs:

@@ -259,6 +259,57 @@ def test_dense_volume_rulebook_equals_hash_rulebook(order, volume_blocks):
     assert int((vol != -1).sum()) == 0
 
 
+@pytest.mark.parametrize('live', ['all', 'fewer'])
+def test_multi_level_rulebook_equals_per_level_rulebooks(live):
+    """sgnn_rulebook_subm3_multi (the coarse levels of a hierarchy in one pre-fill + one builder launch) against one
+    sgnn_rulebook_subm3 per level: every table entry for entry, entries beyond the padded live range untouched, with an
+    empty level in the list, ld > n, and device-resident counts below the capacity."""
+    import numpy as np
+    from sgnn_amd import synth, _lib
+    from sgnn_amd.scn.metadata import Grid, coords_from_locs
+    dev = torch.device('cuda')
+    levels = []
+    for i, (dims, occ) in enumerate([((32, 32, 32), 0.12), ((16, 16, 16), 0.3), ((8, 8, 8), 0.0), ((8, 8, 8), 0.5)]):
+        if occ == 0.0:
+            levels.append(None)
+            continue
+        locs = synth.make_batch(3, dims, cfg=20 + i, occupancy=occ)['input'][0]
+        g = Grid(coords_from_locs(locs, dev))
+        keys, vals, cap = g.hash()
+        n_live = g.n if live == 'all' else max(1, (g.n * 2) // 3)
+        levels.append((g, keys, vals, cap, torch.tensor([n_live], dtype=torch.int64, device=dev)))
+    some = next(l for l in levels if l is not None)
+
+    def build(multi):
+        outs = [torch.full((27 * (l[0].ld + 256 if l else 256),), 12345, dtype=torch.int32, device=dev) for l in levels]
+        a = lambda f, z=0: np.array([f(l) if l else z for l in levels], dtype=np.int64)
+        arrs = [a(lambda l: l[1].data_ptr(), some[1].data_ptr()), a(lambda l: l[2].data_ptr(), some[2].data_ptr()),
+                a(lambda l: l[3], 2), a(lambda l: l[0].coords.data_ptr()), a(lambda l: l[0].n),
+                np.array([o.data_ptr() for o in outs], dtype=np.int64), a(lambda l: l[0].ld + 256, 256),
+                a(lambda l: l[4].data_ptr())]
+        old = _lib.tune('rulebook_multi', multi)
+        try:
+            _lib.call('sgnn_rulebook_subm3_multi', len(levels), *[x.ctypes.data for x in arrs])
+            torch.cuda.synchronize()
+        finally:
+            _lib.tune('rulebook_multi', old)
+        return outs
+    one, many = build(0), build(1)
+    for l, o, m in zip(levels, one, many):
+        assert torch.equal(o, m)
+        if l is None:
+            assert int((m != 12345).sum()) == 0
+        else:
+            g, n_live = l[0], int(l[4])
+            t = m.view(27, g.ld + 256)
+            assert torch.equal(t[13, :n_live], torch.arange(n_live, dtype=torch.int32, device=dev))
+            if live == 'all':        # (a grid hashed beyond the live count hands out rows >= n_live: same in both builds)
+                assert torch.equal(t[:, :g.n], g.subm_table().view(27, g.ld)[:, :g.n])
+                assert int((t[:, g.n:(g.n + 255) // 256 * 256] != -1).sum()) == 0
+    with pytest.raises(_lib.SgnnError):
+        _lib.call('sgnn_rulebook_subm3_multi', 5, *[np.zeros(5, dtype=np.int64).ctypes.data] * 8)
+
+
 def test_registered_levels_use_the_dense_rulebook_and_match():
     """Grids registered in a Metadata know their spatial size and build large rulebooks through the volume."""
     from sgnn_amd import synth

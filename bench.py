@@ -219,8 +219,11 @@ def main():
             step(i)
         host0 = gs.stats['replay_host_ms']
         replays0 = gs.stats['replays']
+        torch.cuda.reset_peak_memory_stats(dev)
         elapsed = timed(step, args.warmup, args.steps)
         graph_info = dict(gs.stats)
+        # device bytes live at any point of the replayed steps (graph pool + static buffers + parameters / Adam state)
+        graph_info['peak_allocated_gb'] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         graph_info.pop('replay_host_ms')
         # host time inside hipGraphLaunch per replay, over the warm-up + timed steps of THIS leg (hidden behind the GPU)
         graph_info['replay_host_ms_per_step'] = round((gs.stats['replay_host_ms'] - host0) /

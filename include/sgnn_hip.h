@@ -723,6 +723,19 @@ int sgnn_prof_dropped(void);
 int64_t sgnn_launch_count(void);
 int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *cout, int *K, int *flags, float *ms);
 
+/* Device time stamps inside a captured graph (measurement only; scripts/lane_stamps.py).  sgnn_stamp launches a one-thread
+ * kernel that writes the device's constant 100 MHz clock into the next slot of `buf` and remembers `label` for it; while no
+ * buffer is enabled it launches nothing and returns -1.  Slots are handed out in call order since the last
+ * sgnn_stamp_reset / _enable, so a captured step re-writes the same slots on every replay.  buf: max_stamps int64 on
+ * the device (NULL, 0 switches stamps off).  SGNN_STAMP_ONLY=label,label,... in the environment keeps only those labels
+ * (a stamp is a graph node, and WHERE a node sits decides which stream the HIP graph executor gives its successors:
+ * profiles/r06y_graph_executor.txt). */
+int sgnn_stamp_enable(int64_t *buf, int max_stamps);
+int sgnn_stamp_reset(void);
+int sgnn_stamp(const char *label, sgnn_stream_t stream);
+int sgnn_stamp_count(void);
+const char *sgnn_stamp_label(int i);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,11 @@ PROTOTYPES = {
     'sgnn_prof_count': (c_i32, []),
     'sgnn_prof_dropped': (c_i32, []),
     'sgnn_prof_get': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'sgnn_stamp_enable': (c_i32, [c_vp, c_i32]),
+    'sgnn_stamp_reset': (c_i32, []),
+    'sgnn_stamp': (c_i32, [c_cp, c_vp]),
+    'sgnn_stamp_count': (c_i32, []),
+    'sgnn_stamp_label': (c_cp, [c_i32]),
 }
 
 _lib = None
@@ -186,6 +191,15 @@ def tune(name, value=None):
     if r == TUNE_UNKNOWN:
         raise SgnnError(lib.sgnn_last_error().decode())
     return r
+
+
+STAMPS = False          # scripts/lane_stamps.py: device time stamps at the lane forks / joins of a captured step
+
+
+def stamp(label):
+    """A device time stamp on the current stream (sgnn_stamp) — nothing at all unless STAMPS was switched on."""
+    if STAMPS:
+        load().sgnn_stamp(label.encode(), stream())
 
 
 def require_gpu():

@@ -7,6 +7,7 @@
 
 #define SGNN_EXPORT extern "C" __attribute__((visibility("default")))
 
+extern "C" int sgnn_stamp(const char *label, sgnn_stream_t stream);   // prof.hip: nothing unless enabled
 extern sgnn_tune g_tune;   // tune.hip: the library's one table of measurement switches (include/sgnn_hip.h documents every field)
 
 void sgnn_set_error(const char *fmt, ...);

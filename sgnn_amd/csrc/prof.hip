@@ -1,5 +1,7 @@
 // Optional per-launch timing of the convolution kernels with HIP events recorded on the caller's
 // stream (bench.py's live roofline leg).  Disabled by default: zero overhead unless enabled.
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "common.h"
 
@@ -75,3 +77,53 @@ SGNN_EXPORT int sgnn_prof_get(int i, int *kind, int64_t *n_out, int *cin, int *c
 // number of kernel launches this library has issued in this process (all streams; see SGNN_LAUNCH in common.h)
 long long sgnn_launch_counter = 0;
 SGNN_EXPORT int64_t sgnn_launch_count(void) { return (int64_t)sgnn_launch_counter; }
+
+
+// ---------------------------------------------------------------------------
+// Device time stamps inside a captured graph (scripts/lane_stamps.py): events cannot be recorded in a replayed graph and a
+// kernel trace perturbs exactly what is being asked (which branch of the graph waits for which), so a one-thread kernel
+// writes the constant 100 MHz clock (s_memrealtime) into a caller-owned slot.  Labels are kept host-side in capture
+// order; every replay rewrites the same slots.  Disabled (no launch at all) unless sgnn_stamp_enable was given a buffer.
+// ---------------------------------------------------------------------------
+#define STAMP_LABEL 64
+static int64_t *g_stamp_buf = nullptr;
+static int g_stamp_max = 0, g_stamp_used = 0;
+static std::vector<char> g_stamp_labels;
+
+__global__ void k_stamp(int64_t *slot) { *slot = (int64_t)wall_clock64(); }
+
+SGNN_EXPORT int sgnn_stamp_enable(int64_t *buf, int max_stamps) {
+  SGNN_CHECK_ARG(max_stamps >= 0 && (buf || max_stamps == 0));
+  g_stamp_buf = max_stamps ? buf : nullptr;
+  g_stamp_max = max_stamps;
+  g_stamp_used = 0;
+  g_stamp_labels.assign((size_t)max_stamps * STAMP_LABEL, 0);
+  return SGNN_OK;
+}
+SGNN_EXPORT int sgnn_stamp_reset(void) {
+  g_stamp_used = 0;
+  return SGNN_OK;
+}
+SGNN_EXPORT int sgnn_stamp_count(void) { return g_stamp_used; }
+SGNN_EXPORT const char *sgnn_stamp_label(int i) {
+  return (i >= 0 && i < g_stamp_used) ? &g_stamp_labels[(size_t)i * STAMP_LABEL] : "";
+}
+// returns the slot written, or -1 when stamps are off / the buffer is full
+SGNN_EXPORT int sgnn_stamp(const char *label, sgnn_stream_t stream) {
+  if (!g_stamp_buf || g_stamp_used >= g_stamp_max) return -1;
+  if (const char *only = getenv("SGNN_STAMP_ONLY")) {       // comma-separated labels: which stamps disturb the replay?
+    const size_t len = strlen(label ? label : "");
+    bool hit = false;
+    for (const char *p = only; *p && !hit;) {
+      const char *e = strchr(p, ',');
+      const size_t l = e ? (size_t)(e - p) : strlen(p);
+      hit = l == len && strncmp(p, label, len) == 0;
+      p += l + (e ? 1 : 0);
+    }
+    if (!hit) return -1;
+  }
+  const int slot = g_stamp_used++;
+  snprintf(&g_stamp_labels[(size_t)slot * STAMP_LABEL], STAMP_LABEL, "%s", label ? label : "");
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, g_stamp_buf + slot);
+  return slot;
+}

@@ -503,7 +503,9 @@ SGNN_EXPORT int sgnn_prog_forward(const int32_t *ops, const float *opf, int nops
     if (type == OP_CONV_DOWN && wait_event) {
       // the stride-2 tables and everything of the coarser levels (hash, 3x3x3 rulebooks, row counts) may still be in
       // flight on the caller's pyramid lane: the first Convolution(2,2) is the first operation that touches them
+      sgnn_stamp("down-wait<", stream);
       SGNN_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_event, 0));
+      sgnn_stamp("down-wait>", stream);
       wait_event = nullptr;
     }
     switch (type) {
@@ -794,6 +796,7 @@ SGNN_EXPORT int sgnn_prog_backward(const int32_t *ops, const float *opf, int nop
           PROG_TRY(sgnn_conv_bwd_weight_impl(X(in0), n, cin, LD(in0), dy, cout, ld_dy, tab_f, ld_f, K, n_dy, PG(par), 0,
                                              nullptr, nullptr, 1, 1, K, dw_base + dw_off, dw_slice(v, i),
                                              (sgnn_stream_t)lane, CNT(down ? lev + 1 : lev)));
+          if (lane != hs) sgnn_stamp("dw>", (sgnn_stream_t)lane);      // (nothing unless stamps are on: scripts/lane_stamps.py)
         }
         dw_off += dw_slice(v, i);
         break;

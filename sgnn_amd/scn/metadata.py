@@ -338,10 +338,12 @@ class PendingChain(object):
                     if rt2.ws.numel() < wsb:
                         self.side.synchronize()        # growing: the old scratch may still be in use over there
                     ws = rt2.workspace(wsb)
+                _lib.stamp('fork')
                 self.side.wait_stream(torch.cuda.current_stream(dev))
             else:
                 ws = rt.workspace(wsb)
             with (torch.cuda.stream(self.side) if self.side is not None else _nullcontext()):
+                _lib.stamp('lane<')
                 _lib.call('sgnn_down2_chain_tables', ptr(coords_cap), ptr(n0_cnt), cap, depth,
                           self._keep[0].ctypes.data, self._keep[1].ctypes.data, self.ccap, self._keep[2].ctypes.data,
                           self._keep[3].ctypes.data, ptr(counts), caps_np.ctypes.data, self._keep[4].ctypes.data,
@@ -389,6 +391,7 @@ class PendingChain(object):
                         [ptr(g.coords) for g in gs], [g.n for g in gs], [ptr(g._nbr) for g in gs], [g.ld for g in gs],
                         [ptr(g.cnt) for g in gs])]
                     _lib.call('sgnn_rulebook_subm3_multi', len(gs), *[a.ctypes.data for a in arr])
+                _lib.stamp('lane>')
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             for d in downs:
@@ -493,7 +496,11 @@ def join_pyramid_lane(device):
     rt = runtime(device)
     side = getattr(rt, '_side_stream', None)
     if side is not None:
+        _lib.stamp('join<')
+        with torch.cuda.stream(side):
+            _lib.stamp('lane-end')
         torch.cuda.current_stream(rt.device).wait_stream(side)
+        _lib.stamp('join>')
 
 
 def coords_from_locs(locs, device):

@@ -354,12 +354,14 @@ class _ProgramFn(Function):
         # capacity mode: the pyramid below level 0 may still be in flight on the pyramid lane (metadata.SIDE_PYRAMID)
         ready = next((d.ready for d in run.downs if d.ready is not None), None)
         wait = ready.cuda_event if ready is not None else None
+        _lib.stamp('prog<')
         _lib.call('sgnn_prog_forward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                   lev_n.ctypes.data, lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                   run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
                   run.pptr.ctypes.data, len(params),
                   run.eptr.ctypes.data, run.iptr.ctypes.data, len(run.idx), arena.data_ptr(), fwd_total,
                   keep.ctypes.data, int(run.training) | (2 if infer else 0), wait, ws.data_ptr(), wsb)
+        _lib.stamp('prog>')
         run.offsets = {}
         outs = []
         for b in run.out_bufs:
@@ -439,6 +441,7 @@ class _ProgramFn(Function):
         if defer:
             _deferred.append((arena, garena, held, ext, params, run))
         try:
+            _lib.stamp('bwd<')
             _lib.call('sgnn_prog_backward', ops.ctypes.data, opf.ctypes.data, nops, bufs.ctypes.data, nbuf, n_ext,
                       run.lev_n.ctypes.data, run.lev_ld.ctypes.data, run.tabs[0].ctypes.data, run.tabs[1].ctypes.data,
                       run.tabs[2].ctypes.data, run.tabs[3].ctypes.data, run.tabs[4].ctypes.data, ncls,
@@ -448,6 +451,7 @@ class _ProgramFn(Function):
                       int(run.training), ws.data_ptr(), run.wsb)
         finally:
             _lib.query('sgnn_prog_defer_join', prev_defer)
+        _lib.stamp('bwd>')
         return (None,) + tuple(gext) + tuple(views)
 
 

@@ -948,6 +948,9 @@ class GraphStep(object):
         dev = self.static['sdf'].device
         rt = runtime(dev)
         torch.cuda.synchronize(dev)
+        from . import _lib
+        if _lib.STAMPS:
+            _lib.load().sgnn_stamp_reset()             # (scripts/lane_stamps.py) slots in capture order
         if self.grad_sync is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -222,7 +222,10 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
         elapsed = timed(step, args.warmup, args.steps)
         graph_info = dict(gs.stats)
-        # device bytes live at any point of the replayed steps (graph pool + static buffers + parameters / Adam state)
+        # device memory of the replayed steps: `reserved` is what the process holds (the graph's private pool — every
+        # intermediate of the captured step — static buffers, parameters / Adam state, workspaces); `allocated` counts only
+        # tensors with a live owner outside the graph
+        graph_info['reserved_gb'] = round(torch.cuda.memory_reserved(dev) / 1e9, 2)
         graph_info['peak_allocated_gb'] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)
         graph_info.pop('replay_host_ms')
         # host time inside hipGraphLaunch per replay, over the warm-up + timed steps of THIS leg (hidden behind the GPU)

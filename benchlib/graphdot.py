@@ -11,10 +11,11 @@ Node = collections.namedtuple('Node', 'id name stream signals')
 
 
 def short(name):
-    m = re.search(r'(k_[a-z0-9_]+?)(?:I|\d*$|P|[A-Z])', name)
-    m2 = re.match(r'_Z\d+(k_[a-z0-9_]+)', name)
-    if m2:
-        return re.sub(r'\d+$', '', m2.group(1))
+    """Kernel family of a (mangled) node label: `_Z13k_chain_countPKi...` -> `k_chain_count`."""
+    m = re.match(r'_Z\d+(k_[a-z0-9_]+)', name)
+    if m:
+        return re.sub(r'\d+$', '', m.group(1))       # (a by-value struct argument leaves its length digits behind the name)
+    m = re.search(r'(k_[a-z0-9_]+)', name)
     return m.group(1) if m else name[:40]
 
 
